@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Headline benchmark: end-to-end queries/sec (+ Recall@1/5/10) of exact top-100 retrieval over a synthetic
+1M x 768 index with 10k queries (BASELINE.json configs[3]), on 1/2/4/8 MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full search pass: query embeddings resident in HBM -> final top-100 (scores + row labels) on the
+host.  With N > 1 the index is sharded row-wise (rank r holds N_rows/N rows), every rank owns 1/N of the queries and
+a step is all-gather(queries) -> local fused search -> all-to-all(partial top-k) -> merge (lightningdot_amd.sharded).
+Total work is fixed as N grows ("strong" scaling).  Rank 0 prints ONE JSON line.
+
+Synthetic data (no network: there is no dataset / checkpoint): index rows i.i.d. N(0,1) fp32, NOT normalised
+(the reference scores raw inner products), generated per 125 000-row chunk c from seed 1234 + c; queries
+q_i = X[(i * 9973) mod N] + 0.5 * eps_i (seed 4321) so that rank-1 is known and Recall@k is meaningful.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+CHUNK = 125_000
+
+
+def gen_rows(r0: int, r1: int, d: int, device) -> torch.Tensor:
+    """Rows [r0, r1) of the synthetic index; chunk c = rows [c*CHUNK, (c+1)*CHUNK) comes from seed 1234 + c."""
+    out = []
+    c0, c1 = r0 // CHUNK, (r1 - 1) // CHUNK
+    for c in range(c0, c1 + 1):
+        g = torch.Generator(device='cpu').manual_seed(1234 + c)
+        # generated on the host generator for cross-device reproducibility, in slabs to bound host memory
+        blk = torch.randn(CHUNK, d, generator=g, dtype=torch.float32)
+        a, b = max(r0, c * CHUNK), min(r1, (c + 1) * CHUNK)
+        out.append(blk[a - c * CHUNK:b - c * CHUNK].to(device))
+    return torch.cat(out, 0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--rows', type=int, default=1_000_000)
+    ap.add_argument('--queries', type=int, default=10_000)
+    ap.add_argument('--dim', type=int, default=768)
+    ap.add_argument('--k', type=int, default=100)
+    ap.add_argument('--mode', default='auto', choices=['auto', 'dense', 'fused'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-queries', type=int, default=256)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from lightningdot_amd import _lib as L
+    from lightningdot_amd.indexer import DenseFlatIndexer
+    L.require_gpu()
+
+    N, Q, D, K = args.rows, args.queries, args.dim, args.k
+    # ---- build this rank's shard -------------------------------------------------------------------------
+    per = (N + world - 1) // world
+    lo, hi = min(rank * per, N), min((rank + 1) * per, N)
+    x_local = gen_rows(lo, hi, D, dev)
+    # planted queries: q_i = X[g_i] + 0.5 eps_i ; every rank fills the rows it owns, then sum over ranks
+    gt = (torch.arange(Q, dtype=torch.int64) * 9973) % N
+    geps = torch.Generator(device='cpu').manual_seed(4321)
+    eps = torch.randn(Q, D, generator=geps, dtype=torch.float32).to(dev)
+    q_all = torch.zeros(Q, D, device=dev)
+    own = ((gt >= lo) & (gt < hi)).to(dev)
+    q_all[own] = x_local[(gt.to(dev)[own] - lo)]
+    if world > 1:
+        dist.all_reduce(q_all)
+    q_all += 0.5 * eps
+    mode = {'auto': L.MODE_AUTO, 'dense': L.MODE_DENSE, 'fused': L.MODE_FUSED}[args.mode]
+
+    if world == 1:
+        ix = DenseFlatIndexer(D)
+        ix.index.set_option(L.OPT_MODE, mode)
+        ix.index.set_option(L.OPT_PROFILE, 1)
+        ix.index.add(x_local)
+        flat = ix.index
+        q_mine = q_all
+        host_s = torch.empty((Q, K), dtype=torch.float32).pin_memory()
+        host_l = torch.empty((Q, K), dtype=torch.int64).pin_memory()
+
+        def step():
+            s, l = flat.search_tensors(q_mine, K)
+            host_s.copy_(s, non_blocking=True)
+            host_l.copy_(l, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            return host_s, host_l
+    else:
+        from lightningdot_amd.sharded import ShardedFlatIndexer
+        sh = ShardedFlatIndexer(D)
+        sh.local.index.set_option(L.OPT_MODE, mode)
+        sh.local.index.set_option(L.OPT_PROFILE, 1)
+        sh.index_local_shard(list(range(lo, hi)), x_local)
+        flat = sh.local.index
+        qper = (Q + world - 1) // world
+        q_mine = q_all[rank * qper:(rank + 1) * qper].contiguous()
+        host_s = torch.empty((q_mine.shape[0], K), dtype=torch.float32).pin_memory()
+        host_l = torch.empty((q_mine.shape[0], K), dtype=torch.int64).pin_memory()
+
+        def step():
+            s, l = sh.search(q_mine, K)
+            host_s.copy_(s, non_blocking=True)
+            host_l.copy_(l, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            return host_s, host_l
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    prof = dict(launches=0.0, kernel_ms=0.0, flops=0.0, bytes=0.0)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        p = flat.last_profile()
+        for k_ in prof:
+            prof[k_] += p[k_]
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- quality on the last step's results: Recall@1/5/10 against the planted ground truth ----------------
+    s_np, l_np = host_s.numpy(), host_l.numpy()
+    if world == 1:
+        gt_mine = gt.numpy()
+    else:
+        gt_mine = gt.numpy()[rank * qper:(rank + 1) * qper]
+    hits = np.array([(l_np[:, :t] == gt_mine[:, None]).any(axis=1).sum() for t in (1, 5, 10)], dtype=np.float64)
+    nq_mine = np.array([float(len(gt_mine))])
+    sorted_ok = bool((np.diff(s_np.astype(np.float64), axis=1) <= 0).all())
+    if world > 1:
+        th = torch.tensor(np.concatenate([hits, nq_mine]), device=dev)
+        dist.all_reduce(th)
+        hits, nq_tot = th[:3].cpu().numpy(), float(th[3].item())
+    else:
+        nq_tot = float(nq_mine[0])
+    recall = {f'recall@{t}': float(h / nq_tot) for t, h in zip((1, 5, 10), hits)}
+    stats = flat.last_stats()
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    value = Q * args.steps / dt
+    ach = (prof['flops'] / (prof['kernel_ms'] * 1e-3) / 1e12) if prof['kernel_ms'] > 0 else 0.0
+    out = {
+        'metric': 'queries/sec', 'value': value, 'unit': 'queries/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
+        'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': f'synthetic {N} x {D} bf16 index (fp32 master for exact re-score), {Q} queries, '
+                               f'top-{K}, un-normalised inner product (BASELINE.json configs[3] / SURVEY S1)',
+                   'index_rows': N, 'queries': Q, 'dim': D, 'k': K, 'search_mode': args.mode,
+                   'parallelism': f'row-sharded index x{world}' if world > 1 else 'single GPU'},
+        **recall, 'results_sorted': sorted_ok,
+        'overflowed_queries': int(stats['overflowed_queries']),
+        'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': ach / PEAK_BF16_TFLOPS, 'traffic': None,
+                     'kernel': 'score kernels of rank 0 (score_filter_kernel + warm-up score_dense_kernel)',
+                     'launches_per_step': prof['launches'] / max(args.steps, 1),
+                     'kernel_ms_per_step': prof['kernel_ms'] / max(args.steps, 1),
+                     'flops_per_step': prof['flops'] / max(args.steps, 1)},
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out['cpu_baseline'] = cpu_baseline(x_local, q_all, K, args.cpu_sample_queries)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(x_dev, q_dev, k, nsample):
+    """The reference's CPU scorer is faiss IndexFlatIP (fp32 sgemm + heap); faiss is not installable here, so the
+    timed leg is the oracle's restatement of the same structure (oracle.search_fast: blocked fp32 sgemm +
+    selection) on a bounded sample: the first `nsample` queries against the FULL index, all host cores."""
+    from oracle import oracle_np as O      # checker / baseline only — never on the product path
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    x = x_dev.cpu().numpy()
+    q = q_dev[:nsample].cpu().numpy()
+    O.search_fast(q[:8], x[:4096], k)                      # warm the BLAS threads
+    t0 = time.perf_counter()
+    O.search_fast(q, x, k)
+    dt = time.perf_counter() - t0
+    return {'value': len(q) / dt, 'unit': 'queries/s', 'cores': int(cores), 'kind': 'port',
+            'sample': f'first {len(q)} queries x full {x.shape[0]} x {x.shape[1]} fp32 index, top-{k}, '
+                      f'oracle.search_fast (blocked numpy sgemm + argpartition), 1 run after warm-up, {dt:.2f} s'}
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,161 @@
+/*
+ * ldot.h — C ABI of the MI355X-native retrieval hot path (lightningdot_amd).
+ *
+ * This is the drop-in boundary: the entry points below are what the reference's Python layer would bind
+ * (through ctypes) in place of the third-party native code it reaches today.  Every entry point cites the
+ * reference interface it replaces (paths relative to the reference checkout, intersun/LightningDOT).
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all pointers are raw addresses; `stream` is a hipStream_t passed as void*
+ *     (NULL = the default stream).
+ *   - every function returns an int status: LDOT_OK (0) or a negative LDOT_E*; `ldot_last_error()` returns a
+ *     thread-local human readable message for the last failure on the calling thread.  No exceptions cross
+ *     the ABI.
+ *   - `mem` arguments say where a caller buffer lives: LDOT_HOST (pageable or pinned host memory) or
+ *     LDOT_DEVICE (HIP device memory of the current device).  Caller owns all in/out buffers; the library
+ *     owns the index storage and its scratch workspaces.
+ *   - the library never falls back to a CPU implementation: without a usable HIP device every compute entry
+ *     point fails with LDOT_EDEVICE.
+ */
+#ifndef LDOT_H_
+#define LDOT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDOT_ABI_VERSION 1
+
+/* status codes */
+#define LDOT_OK 0
+#define LDOT_EINVAL (-1)   /* bad argument (dimension / dtype / k / NULL) */
+#define LDOT_EDEVICE (-2)  /* HIP runtime error, no device, launch failure */
+#define LDOT_ENOMEM (-3)   /* host or device allocation failed */
+#define LDOT_EIO (-4)      /* serialize / deserialize failure */
+#define LDOT_ESTATE (-5)   /* object in the wrong state (e.g. size mismatch on load) */
+
+/* element types of caller buffers */
+#define LDOT_F32 0
+#define LDOT_BF16 1
+#define LDOT_F16 2
+
+/* memory spaces of caller buffers */
+#define LDOT_HOST 0
+#define LDOT_DEVICE 1
+
+/* label / score used to pad result rows when fewer than k rows exist (faiss IndexFlatIP convention) */
+#define LDOT_PAD_LABEL (-1)
+#define LDOT_PAD_SCORE (-3.402823466e+38f)
+
+/* search-mode flags (ldot_index_set_option(LDOT_OPT_MODE, ...)) */
+#define LDOT_MODE_AUTO 0   /* dense for small indexes, fused filter for large ones */
+#define LDOT_MODE_DENSE 1  /* materialise score chunks + radix select */
+#define LDOT_MODE_FUSED 2  /* fused MFMA score + threshold filter (never materialises Q x N) */
+
+#define LDOT_OPT_MODE 1
+#define LDOT_OPT_RESCORE 2      /* 1 (default): exact fp32 re-score of the bf16 candidates; 0: report bf16-input scores */
+#define LDOT_OPT_CHUNK_ROWS 3   /* index rows per scoring chunk (multiple of 256) */
+#define LDOT_OPT_MARGIN 4       /* extra candidates kept beyond k before the fp32 re-score (default max(28,k/4)) */
+#define LDOT_OPT_PROFILE 5      /* 1: bracket every score-kernel launch with HIP events (see ldot_index_last_profile) */
+#define LDOT_OPT_WARM_ROWS 6    /* rows scored densely before the fused filter starts (default 8192, multiple of 256) */
+#define LDOT_OPT_GROWTH_PCT 7   /* fused launch i covers growth% of the rows already scanned (default 100 = doubling) */
+
+typedef struct ldot_index ldot_index_t;
+
+const char* ldot_last_error(void);
+int ldot_abi_version(void);
+/* number of visible HIP devices (>=0) or a negative status */
+int ldot_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Flat inner-product index — replaces faiss.IndexFlatIP as used by DenseFlatIndexer
+ *   dvl/indexer/faiss_indexers.py:67   faiss.IndexFlatIP(vector_sz)        -> ldot_index_create
+ *   dvl/indexer/faiss_indexers.py:77   self.index.add(vectors)             -> ldot_index_add
+ *   dvl/indexer/faiss_indexers.py:83   self.index.search(query_vectors, k) -> ldot_index_search
+ *   dvl/indexer/faiss_indexers.py:52   self.index.ntotal                   -> ldot_index_ntotal
+ *   dvl/indexer/faiss_indexers.py:41   faiss.write_index(index, file)      -> ldot_index_save
+ *   dvl/indexer/faiss_indexers.py:51   faiss.read_index(file)              -> ldot_index_load
+ * Semantics: exact (un-normalised) inner product; the k best rows per query in descending score
+ * order, ties broken by the lower row label; rows beyond ntotal are padded with LDOT_PAD_LABEL /
+ * LDOT_PAD_SCORE.  Candidates are generated with bf16 MFMA (fp32 accumulate) and re-scored exactly in fp32
+ * from the fp32 master copy of the rows, so reported scores are fp32 inner products.
+ * --------------------------------------------------------------------------------------------------------- */
+int ldot_index_create(int d, ldot_index_t** out);
+int ldot_index_destroy(ldot_index_t* ix);
+/* Append n rows of dimension d.  `normalize` != 0 scales every row to unit L2 norm first (opt-in; the
+ * reference never normalises). */
+int ldot_index_add(ldot_index_t* ix, const void* rows, int64_t n, int dtype, int mem, int normalize, void* stream);
+int64_t ldot_index_ntotal(const ldot_index_t* ix);
+int ldot_index_dim(const ldot_index_t* ix);
+int ldot_index_reset(ldot_index_t* ix);
+int ldot_index_set_option(ldot_index_t* ix, int option, int64_t value);
+/* out_scores: [nq*k] float, out_labels: [nq*k] int64, both in `out_mem` space. */
+int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize,
+                      int k, float* out_scores, int64_t* out_labels, int out_mem, void* stream);
+/* own on-disk format ("LDOTIDX1": header + fp32 rows); bf16 shadow is rebuilt on load */
+int ldot_index_save(ldot_index_t* ix, const char* path);
+int ldot_index_load(const char* path, ldot_index_t** out);
+/* copy rows [row0,row0+n) of the fp32 master copy to a caller buffer (inspection / resharding) */
+int ldot_index_get_rows(ldot_index_t* ix, int64_t row0, int64_t n, float* out, int out_mem, void* stream);
+/* statistics of the last search on this index: [0]=candidates appended by the fused filter, [1]=queries that
+ * overflowed their candidate pools and were redone densely, [2]=rows scored densely, [3]=rows scored fused */
+int ldot_index_last_stats(const ldot_index_t* ix, int64_t out[4]);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Partial top-k merge (sharded retrieval; no reference counterpart — the reference is single
+ * process).  Inputs: `nparts` lists per query laid out [nparts][nq][k_in] (scores fp32, labels int64 already
+ * global, LDOT_PAD_LABEL for padding).  Output [nq][k_out], score desc / label asc.
+ * --------------------------------------------------------------------------------------------------------- */
+int ldot_merge_topk(const float* scores, const int64_t* labels, int nparts, int64_t nq, int k_in, int k_out,
+                    float* out_scores, int64_t* out_labels, int mem, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * [CLS] pooling — dvl/models/bi_encoder.py:120 (BertEncoder) and :188 (UniterEncoder):
+ *     pooled_output = sequence_output[:, 0, :]
+ * seq: [B, L, D] (row strides given in elements) device memory of `dtype`; out_f32 [B, D] and/or out_bf16
+ * [B, D] (either may be NULL).  `normalize` is the opt-in L2 variant of north_star.
+ * --------------------------------------------------------------------------------------------------------- */
+int ldot_cls_pool(const void* seq, int dtype, int64_t B, int64_t stride_b, int64_t D, int normalize,
+                  float* out_f32, void* out_bf16, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * In-batch contrastive loss — dvl/models/bi_encoder.py:615-656 (BiEncoderNllLoss.calc) incl. :54-68
+ * (dot_product_scores), reached through dvl/utils.py:114-169 (_calc_loss) from train_itm.py:198-210 and
+ * dvl/trainer.py:143.
+ *   scores = (1-w) * q.ctx^T + w * q.cap^T        (cap may be NULL or w == 0 -> scores = q.ctx^T)
+ *   lse_i  = logsumexp_j scores[i][j];  row_loss_i = lse_i - scores[i][pos_i];  argmax_i = first max column
+ * All buffers are device memory, fp32, row-major: q [n1,d], ctx [n2,d], cap [n2,d] or NULL, pos int32 [n1].
+ * Outputs: scores [n1,n2], row_loss [n1], lse [n1], correct int32 [1] (= #{argmax_i == pos_i}),
+ * loss_mean [1] (= mean of row_loss).  fp32-input MFMA (exact fp32 products) is used, so results match an
+ * fp32 reference to rounding.
+ * --------------------------------------------------------------------------------------------------------- */
+int ldot_inbatch_nll_fwd(const float* q, const float* ctx, const float* cap, float w, const int32_t* pos,
+                         int64_t n1, int64_t n2, int64_t d, float* scores, float* row_loss, float* lse,
+                         int32_t* correct, float* loss_sum, void* stream);
+/* Backward: dS_ij = g_row_i * (exp(scores_ij - lse_i) - [j == pos_i]) + g_scores_ij   (g_scores may be NULL)
+ *           dq = (1-w) dS.ctx + w dS.cap ;  dctx = (1-w) dS^T.q ;  dcap = w dS^T.q   (NULL outputs skipped)
+ * `ds_work` is an [n1,n2] fp32 scratch buffer. */
+int ldot_inbatch_nll_bwd(const float* q, const float* ctx, const float* cap, float w, const int32_t* pos,
+                         int64_t n1, int64_t n2, int64_t d, const float* scores, const float* lse,
+                         const float* g_row, const float* g_scores, float* ds_work,
+                         float* dq, float* dctx, float* dcap, void* stream);
+
+/* plain score matrix (dot_product_scores, bi_encoder.py:54-68): out[n1,n2] = q.ctx^T, fp32 exact products */
+int ldot_dot_product_scores(const float* q, const float* ctx, int64_t n1, int64_t n2, int64_t d, float* out,
+                            void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Profiling hook (bench.py): with LDOT_OPT_PROFILE = 1 every score-kernel launch of a search (dense GEMM or
+ * fused filter) is bracketed by HIP events on the search stream.  After the search:
+ *   out[0] = number of score-kernel launches      out[1] = their total duration in milliseconds
+ *   out[2] = total algorithmic flops (2*Q*N*D)    out[3] = total algorithmic bytes (index + queries + results)
+ * --------------------------------------------------------------------------------------------------------- */
+int ldot_index_last_profile(const ldot_index_t* ix, double out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDOT_H_ */

@@ -1,0 +1,63 @@
+"""Build recipe for libldot.so (hand-written HIP for gfx950, C ABI in include/ldot.h).
+
+    python -m lightningdot_amd.build          # (re)build in-tree: lightningdot_amd/libldot.so
+
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the CPU-only build container; the in-tree .so
+travels to the GPU box with the repository snapshot.
+"""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, 'csrc')
+LIB = os.path.join(PKG, 'libldot.so')
+SOURCES = ['api.hip', 'convert.hip', 'score_dense.hip', 'score_filter.hip', 'select.hip', 'rescore.hip', 'loss.hip']
+HEADERS = ['ldot_common.h', 'gemm_tile.h', 'kernels.h', os.path.join('..', '..', 'include', 'ldot.h')]
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    objs = []
+    bdir = os.path.join(PKG, 'build')
+    os.makedirs(bdir, exist_ok=True)
+    procs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(bdir, s.replace('.hip', '.o'))
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = False
+    for s, p in procs:
+        out, _ = p.communicate()
+        if out and verbose:
+            sys.stdout.write(out.decode(errors='replace'))
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(f'hipcc failed on {s}\n' + (out.decode(errors='replace') if not verbose else ''))
+    if failed:
+        raise RuntimeError('libldot.so build failed')
+    if force or _stale(LIB, objs):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)
+    print(LIB)

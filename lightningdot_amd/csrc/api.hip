@@ -1,0 +1,535 @@
+// C ABI of libldot.so (see include/ldot.h): index object, search orchestration, merge, pooling.
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "gemm_tile.h"
+#include "kernels.h"
+
+namespace ldot {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return LDOT_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        LDOT_HIP_CHECK(hipMalloc(&p, need));
+        bytes = need;
+        return LDOT_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+}  // namespace ldot
+
+using namespace ldot;
+
+struct ldot_index {
+    int d = 0, dpad = 0;
+    int64_t ntotal = 0, cap_rows = 0;
+    float* x32 = nullptr;      // [cap_rows][dpad] fp32 master copy (zero padded)
+    uint16_t* x16 = nullptr;   // [cap_rows][dpad] bf16 shadow
+    // options
+    int mode = LDOT_MODE_AUTO;
+    int rescore = 1;
+    int64_t chunk_rows = 32768;
+    int margin = -1;
+    int profile = 0;
+    int64_t warm_rows = 8192;
+    int growth_pct = 100;
+    struct ProfEv {
+        hipEvent_t a, b;
+        double flops, bytes;
+    };
+    std::vector<ProfEv> prof_events;
+    double prof[4] = {0, 0, 0, 0};
+    // workspaces
+    DevBuf w_stage, w_q32, w_q16, w_ls, w_li, w_S, w_outs, w_outl, w_tau, w_pool_s, w_pool_i, w_pool_cnt, w_over;
+    int64_t stats[4] = {0, 0, 0, 0};
+};
+
+static int index_reserve(ldot_index* ix, int64_t rows, hipStream_t st) {
+    // capacity is a multiple of 256 rows (the MFMA tile) and rows beyond ntotal are kept zero
+    int64_t need = round_up(rows > 0 ? rows : 1, 256);
+    if (need <= ix->cap_rows) return LDOT_OK;
+    int64_t cap = std::max<int64_t>(need, ix->cap_rows + ix->cap_rows / 2);
+    cap = round_up(cap, 256);
+    float* n32 = nullptr;
+    uint16_t* n16 = nullptr;
+    const size_t b32 = (size_t)cap * ix->dpad * sizeof(float), b16 = (size_t)cap * ix->dpad * sizeof(uint16_t);
+    LDOT_HIP_CHECK(hipMalloc((void**)&n32, b32));
+    hipError_t e = hipMalloc((void**)&n16, b16);
+    if (e != hipSuccess) {
+        (void)hipFree(n32);
+        set_error("hipMalloc(%zu) failed: %s", b16, hipGetErrorString(e));
+        return LDOT_ENOMEM;
+    }
+    const size_t u32 = (size_t)ix->ntotal * ix->dpad * sizeof(float), u16 = (size_t)ix->ntotal * ix->dpad * 2;
+    if (ix->ntotal > 0) {
+        LDOT_HIP_CHECK(hipMemcpyAsync(n32, ix->x32, u32, hipMemcpyDeviceToDevice, st));
+        LDOT_HIP_CHECK(hipMemcpyAsync(n16, ix->x16, u16, hipMemcpyDeviceToDevice, st));
+    }
+    LDOT_HIP_CHECK(hipMemsetAsync((char*)n32 + u32, 0, b32 - u32, st));
+    LDOT_HIP_CHECK(hipMemsetAsync((char*)n16 + u16, 0, b16 - u16, st));
+    LDOT_HIP_CHECK(hipStreamSynchronize(st));
+    if (ix->x32) (void)hipFree(ix->x32);
+    if (ix->x16) (void)hipFree(ix->x16);
+    ix->x32 = n32;
+    ix->x16 = n16;
+    ix->cap_rows = cap;
+    return LDOT_OK;
+}
+
+static size_t dtype_size(int dtype) { return dtype == LDOT_F32 ? 4 : 2; }
+
+extern "C" {
+
+const char* ldot_last_error(void) { return g_err; }
+int ldot_abi_version(void) { return LDOT_ABI_VERSION; }
+
+int ldot_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return LDOT_EDEVICE;
+    }
+    return n;
+}
+
+int ldot_index_create(int d, ldot_index_t** out) {
+    LDOT_REQUIRE(out != nullptr, LDOT_EINVAL, "out is NULL");
+    LDOT_REQUIRE(d > 0 && d <= 65536, LDOT_EINVAL, "bad dimension %d", d);
+    int n = ldot_device_count();
+    if (n < 0) return n;
+    LDOT_REQUIRE(n > 0, LDOT_EDEVICE, "no HIP device visible: the MI355X path has no CPU fallback");
+    ldot_index* ix = new (std::nothrow) ldot_index();
+    LDOT_REQUIRE(ix != nullptr, LDOT_ENOMEM, "out of host memory");
+    ix->d = d;
+    ix->dpad = (int)round_up(d, kBK);
+    *out = ix;
+    return LDOT_OK;
+}
+
+int ldot_index_destroy(ldot_index_t* ix) {
+    if (!ix) return LDOT_OK;
+    if (ix->x32) (void)hipFree(ix->x32);
+    if (ix->x16) (void)hipFree(ix->x16);
+    DevBuf* bufs[] = {&ix->w_stage, &ix->w_q32, &ix->w_q16, &ix->w_ls, &ix->w_li, &ix->w_S, &ix->w_outs,
+                      &ix->w_outl, &ix->w_tau, &ix->w_pool_s, &ix->w_pool_i, &ix->w_pool_cnt, &ix->w_over};
+    for (DevBuf* b : bufs) b->release();
+    delete ix;
+    return LDOT_OK;
+}
+
+int64_t ldot_index_ntotal(const ldot_index_t* ix) { return ix ? ix->ntotal : LDOT_EINVAL; }
+int ldot_index_dim(const ldot_index_t* ix) { return ix ? ix->d : LDOT_EINVAL; }
+
+int ldot_index_reset(ldot_index_t* ix) {
+    LDOT_REQUIRE(ix != nullptr, LDOT_EINVAL, "index is NULL");
+    if (ix->cap_rows > 0) {
+        LDOT_HIP_CHECK(hipMemset(ix->x32, 0, (size_t)ix->cap_rows * ix->dpad * 4));
+        LDOT_HIP_CHECK(hipMemset(ix->x16, 0, (size_t)ix->cap_rows * ix->dpad * 2));
+    }
+    ix->ntotal = 0;
+    return LDOT_OK;
+}
+
+int ldot_index_set_option(ldot_index_t* ix, int option, int64_t value) {
+    LDOT_REQUIRE(ix != nullptr, LDOT_EINVAL, "index is NULL");
+    switch (option) {
+        case LDOT_OPT_MODE:
+            LDOT_REQUIRE(value >= 0 && value <= 2, LDOT_EINVAL, "bad mode %lld", (long long)value);
+            ix->mode = (int)value;
+            return LDOT_OK;
+        case LDOT_OPT_RESCORE:
+            ix->rescore = value ? 1 : 0;
+            return LDOT_OK;
+        case LDOT_OPT_CHUNK_ROWS:
+            LDOT_REQUIRE(value >= 256 && value % 256 == 0 && value <= (1 << 22), LDOT_EINVAL,
+                         "chunk_rows must be a multiple of 256 in [256, 4194304]");
+            ix->chunk_rows = value;
+            return LDOT_OK;
+        case LDOT_OPT_MARGIN:
+            LDOT_REQUIRE(value >= -1 && value <= kMaxKp, LDOT_EINVAL, "bad margin");
+            ix->margin = (int)value;
+            return LDOT_OK;
+        case LDOT_OPT_PROFILE:
+            ix->profile = value ? 1 : 0;
+            return LDOT_OK;
+        case LDOT_OPT_WARM_ROWS:
+            LDOT_REQUIRE(value >= 2048 && value % 256 == 0, LDOT_EINVAL, "warm_rows must be a multiple of 256 >= 2048");
+            ix->warm_rows = value;
+            return LDOT_OK;
+        case LDOT_OPT_GROWTH_PCT:
+            LDOT_REQUIRE(value >= 5 && value <= 10000, LDOT_EINVAL, "growth_pct must be in [5, 10000]");
+            ix->growth_pct = (int)value;
+            return LDOT_OK;
+        default:
+            set_error("unknown option %d", option);
+            return LDOT_EINVAL;
+    }
+}
+
+int ldot_index_add(ldot_index_t* ix, const void* rows, int64_t n, int dtype, int mem, int normalize, void* stream) {
+    LDOT_REQUIRE(ix != nullptr, LDOT_EINVAL, "index is NULL");
+    LDOT_REQUIRE(n >= 0, LDOT_EINVAL, "negative row count");
+    LDOT_REQUIRE(dtype >= 0 && dtype <= 2, LDOT_EINVAL, "bad dtype %d", dtype);
+    LDOT_REQUIRE(mem == LDOT_HOST || mem == LDOT_DEVICE, LDOT_EINVAL, "bad mem %d", mem);
+    if (n == 0) return LDOT_OK;
+    LDOT_REQUIRE(rows != nullptr, LDOT_EINVAL, "rows is NULL");
+    LDOT_REQUIRE(ix->ntotal + n < 0x7ffffff0ll, LDOT_EINVAL, "index too large for 31-bit row labels");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = index_reserve(ix, ix->ntotal + n, st);
+    if (rc) return rc;
+    const void* src = rows;
+    if (mem == LDOT_HOST) {
+        const size_t bytes = (size_t)n * ix->d * dtype_size(dtype);
+        rc = ix->w_stage.ensure(bytes);
+        if (rc) return rc;
+        LDOT_HIP_CHECK(hipMemcpyAsync(ix->w_stage.p, rows, bytes, hipMemcpyHostToDevice, st));
+        src = ix->w_stage.p;
+    }
+    rc = launch_convert_rows(src, dtype, ix->d, n, ix->d, ix->dpad, normalize, ix->x32 + ix->ntotal * ix->dpad,
+                             ix->x16 + ix->ntotal * ix->dpad, st);
+    if (rc) return rc;
+    if (mem == LDOT_HOST) LDOT_HIP_CHECK(hipStreamSynchronize(st));   // staging buffer is reused by the next call
+    ix->ntotal += n;
+    return LDOT_OK;
+}
+
+int ldot_index_get_rows(ldot_index_t* ix, int64_t row0, int64_t n, float* out, int out_mem, void* stream) {
+    LDOT_REQUIRE(ix != nullptr && out != nullptr, LDOT_EINVAL, "NULL argument");
+    LDOT_REQUIRE(row0 >= 0 && n >= 0 && row0 + n <= ix->ntotal, LDOT_EINVAL, "row range out of bounds");
+    if (n == 0) return LDOT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    LDOT_HIP_CHECK(hipMemcpy2DAsync(out, (size_t)ix->d * 4, ix->x32 + row0 * ix->dpad, (size_t)ix->dpad * 4,
+                                    (size_t)ix->d * 4, (size_t)n,
+                                    out_mem == LDOT_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
+    if (out_mem == LDOT_HOST) LDOT_HIP_CHECK(hipStreamSynchronize(st));
+    return LDOT_OK;
+}
+
+int ldot_index_last_stats(const ldot_index_t* ix, int64_t out[4]) {
+    LDOT_REQUIRE(ix != nullptr && out != nullptr, LDOT_EINVAL, "NULL argument");
+    for (int i = 0; i < 4; ++i) out[i] = ix->stats[i];
+    return LDOT_OK;
+}
+
+static int candidate_len(const ldot_index* ix, int k) {
+    int margin = ix->margin >= 0 ? ix->margin : std::max(28, k / 4);
+    if (!ix->rescore) margin = 0;
+    int kp = (int)round_up(k + margin, 32);
+    return std::min(kp, kMaxKp);
+}
+
+static void prof_begin(ldot_index* ix, hipStream_t st, double flops, double bytes) {
+    if (!ix->profile) return;
+    ldot_index::ProfEv ev;
+    if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) return;
+    ev.flops = flops;
+    ev.bytes = bytes;
+    (void)hipEventRecord(ev.a, st);
+    ix->prof_events.push_back(ev);
+}
+static void prof_end(ldot_index* ix, hipStream_t st) {
+    if (!ix->profile || ix->prof_events.empty()) return;
+    (void)hipEventRecord(ix->prof_events.back().b, st);
+}
+static void prof_collect(ldot_index* ix, hipStream_t st) {
+    for (int i = 0; i < 4; ++i) ix->prof[i] = 0;
+    if (!ix->profile) return;
+    (void)hipStreamSynchronize(st);
+    for (auto& ev : ix->prof_events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
+            ix->prof[0] += 1;
+            ix->prof[1] += ms;
+            ix->prof[2] += ev.flops;
+            ix->prof[3] += ev.bytes;
+        }
+        (void)hipEventDestroy(ev.a);
+        (void)hipEventDestroy(ev.b);
+    }
+    ix->prof_events.clear();
+}
+
+// dense scan of rows [r0, r1) for query block [q0, q0+nqb): materialise score chunks + streaming select
+static int dense_scan(ldot_index* ix, int64_t q0, int64_t nqb, int64_t nqb_pad, int64_t r0, int64_t r1, int kp,
+                      float* tau, hipStream_t st) {
+    const uint16_t* q16 = (const uint16_t*)ix->w_q16.p + q0 * ix->dpad;
+    float* ls = (float*)ix->w_ls.p + q0 * kp;
+    int32_t* li = (int32_t*)ix->w_li.p + q0 * kp;
+    const int64_t chunk = ix->chunk_rows;
+    int rc = ix->w_S.ensure((size_t)nqb_pad * chunk * sizeof(float));
+    if (rc) return rc;
+    for (int64_t r = r0; r < r1; r += chunk) {
+        const int64_t nrows = std::min(chunk, r1 - r);
+        const int64_t nrows_pad = round_up(nrows, kBN);
+        prof_begin(ix, st, 2.0 * nqb_pad * nrows_pad * ix->dpad,
+                   (double)nrows_pad * ix->dpad * 2 + (double)nqb_pad * ix->dpad * 2 + (double)nqb_pad * nrows_pad * 4);
+        rc = launch_score_dense(q16, ix->dpad, nqb_pad, ix->x16, ix->dpad, r, nrows_pad, ix->dpad, (float*)ix->w_S.p,
+                                chunk, st);
+        prof_end(ix, st);
+        if (rc) return rc;
+        rc = launch_select_dense((const float*)ix->w_S.p, chunk, nqb, nrows, r, ls, li, kp, tau ? tau + q0 : nullptr,
+                                 st);
+        if (rc) return rc;
+        ix->stats[2] += nrows * nqb;
+    }
+    return LDOT_OK;
+}
+
+static int dense_scan_all(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, int kp, float* tau, hipStream_t st) {
+    // query blocks bound the dense score workspace (<= ~2 GiB at the default chunk)
+    const int64_t qb_max = std::max<int64_t>(kBM, ((int64_t)1 << 29) / ix->chunk_rows / kBM * kBM);
+    for (int64_t q0 = 0; q0 < nq; q0 += qb_max) {
+        const int64_t nqb = std::min(qb_max, nq - q0);
+        int rc = dense_scan(ix, q0, nqb, round_up(nqb, kBM), r0, r1, kp, tau, st);
+        if (rc) return rc;
+    }
+    return LDOT_OK;
+}
+
+// fused scan: dense warm-up of the first rows (gives every query a full list and a threshold), then
+// geometrically growing fused-filter launches, each followed by the pool select that raises the thresholds.
+static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStream_t st, bool* overflowed) {
+    *overflowed = false;
+    float* tau = (float*)ix->w_tau.p;
+    int rc;
+    // Pool sizing rule: a launch over `len` rows after `r` scanned rows admits ~kp*len/r candidates per query,
+    // spread over kPoolSubs lane-private sub-pools of kPoolCap entries.  Keeping the expectation <= 1024 per query
+    // (8 per sub-pool, overflow probability ~1e-11 each) bounds len <= r*1024/kp; the smallest launch is one tile
+    // per row slice, hence the warm-up covers at least 8*kp rows.
+    const int64_t warm =
+        std::min(ix->ntotal, std::max<int64_t>(ix->warm_rows, round_up((int64_t)8 * kp, 256)));
+    if ((rc = dense_scan_all(ix, nq, 0, warm, kp, tau, st))) return rc;
+    if (warm >= ix->ntotal) return LDOT_OK;
+    if ((rc = ix->w_pool_s.ensure((size_t)nq_pad * kPoolSubs * kPoolCap * 4))) return rc;
+    if ((rc = ix->w_pool_i.ensure((size_t)nq_pad * kPoolSubs * kPoolCap * 4))) return rc;
+    if ((rc = ix->w_pool_cnt.ensure((size_t)nq_pad * kPoolSubs * 4))) return rc;
+    if ((rc = ix->w_over.ensure((size_t)nq_pad * 4))) return rc;
+    LDOT_HIP_CHECK(hipMemsetAsync(ix->w_over.p, 0, (size_t)nq_pad * 4, st));
+    LDOT_HIP_CHECK(hipMemsetAsync(ix->w_pool_cnt.p, 0, (size_t)nq_pad * kPoolSubs * 4, st));
+    if (nq_pad > nq)   // pad queries never produce candidates
+        LDOT_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(tau + nq), 0x7f800000, (size_t)(nq_pad - nq), st));
+    int64_t r = warm;
+    while (r < ix->ntotal) {
+        int64_t len = std::min<int64_t>(r * ix->growth_pct / 100, r * 1024 / kp);
+        len = std::max<int64_t>(len, kBM * kFusedSlices);
+        len = round_up(len, kBM);
+        len = std::min(len, ix->ntotal - r);
+        prof_begin(ix, st, 2.0 * nq_pad * len * ix->dpad,
+                   (double)len * ix->dpad * 2 + (double)nq_pad * ix->dpad * 2 + (double)nq_pad * kp * 8);
+        rc = launch_score_filter(ix->x16, ix->dpad, r, len, ix->w_q16.p, ix->dpad, nq_pad, ix->dpad, tau,
+                                 (float*)ix->w_pool_s.p, (int32_t*)ix->w_pool_i.p, (int32_t*)ix->w_pool_cnt.p, st);
+        prof_end(ix, st);
+        if (rc) return rc;
+        rc = launch_select_pools((const float*)ix->w_pool_s.p, (const int32_t*)ix->w_pool_i.p,
+                                 (const int32_t*)ix->w_pool_cnt.p, nq, (float*)ix->w_ls.p, (int32_t*)ix->w_li.p, kp, tau,
+                                 (int32_t*)ix->w_over.p, st);
+        if (rc) return rc;
+        ix->stats[3] += len * nq;
+        r += len;
+    }
+    // any query whose lane-private pool overflowed lost candidates: detect (one small D2H) and let the caller redo
+    std::vector<int32_t> over((size_t)nq);
+    LDOT_HIP_CHECK(hipMemcpyAsync(over.data(), ix->w_over.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    LDOT_HIP_CHECK(hipStreamSynchronize(st));
+    int64_t n_over = 0;
+    for (int32_t v : over) n_over += (v != 0);
+    ix->stats[1] = n_over;
+    *overflowed = n_over > 0;
+    return LDOT_OK;
+}
+
+int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k,
+                      float* out_scores, int64_t* out_labels, int out_mem, void* stream) {
+    LDOT_REQUIRE(ix != nullptr, LDOT_EINVAL, "index is NULL");
+    LDOT_REQUIRE(nq >= 0, LDOT_EINVAL, "negative query count");
+    LDOT_REQUIRE(k >= 1 && k <= kMaxKp, LDOT_EINVAL, "k must be in [1, %d] (got %d)", kMaxKp, k);
+    LDOT_REQUIRE(dtype >= 0 && dtype <= 2, LDOT_EINVAL, "bad dtype %d", dtype);
+    LDOT_REQUIRE((mem == LDOT_HOST || mem == LDOT_DEVICE) && (out_mem == LDOT_HOST || out_mem == LDOT_DEVICE),
+                 LDOT_EINVAL, "bad memory space");
+    if (nq == 0) return LDOT_OK;
+    LDOT_REQUIRE(queries && out_scores && out_labels, LDOT_EINVAL, "NULL buffer");
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < 4; ++i) ix->stats[i] = 0;
+    const int kp = candidate_len(ix, k);
+    const int64_t nq_pad = round_up(nq, kBM);
+    int rc;
+    if ((rc = ix->w_q32.ensure((size_t)nq_pad * ix->dpad * 4))) return rc;
+    if ((rc = ix->w_q16.ensure((size_t)nq_pad * ix->dpad * 2))) return rc;
+    if ((rc = ix->w_ls.ensure((size_t)nq_pad * kp * 4))) return rc;
+    if ((rc = ix->w_li.ensure((size_t)nq_pad * kp * 4))) return rc;
+    if ((rc = ix->w_tau.ensure((size_t)nq_pad * 4))) return rc;
+    if ((rc = ix->w_outs.ensure((size_t)nq * k * 4))) return rc;
+    if ((rc = ix->w_outl.ensure((size_t)nq * k * 8))) return rc;
+
+    // ingest queries -> fp32 (exact re-score operand) + bf16 (MFMA operand); pad rows of the last tile are zero
+    const void* src = queries;
+    if (mem == LDOT_HOST) {
+        const size_t bytes = (size_t)nq * ix->d * dtype_size(dtype);
+        if ((rc = ix->w_stage.ensure(bytes))) return rc;
+        LDOT_HIP_CHECK(hipMemcpyAsync(ix->w_stage.p, queries, bytes, hipMemcpyHostToDevice, st));
+        src = ix->w_stage.p;
+    }
+    if (nq_pad > nq) {
+        LDOT_HIP_CHECK(hipMemsetAsync((float*)ix->w_q32.p + nq * ix->dpad, 0, (size_t)(nq_pad - nq) * ix->dpad * 4, st));
+        LDOT_HIP_CHECK(hipMemsetAsync((uint16_t*)ix->w_q16.p + nq * ix->dpad, 0, (size_t)(nq_pad - nq) * ix->dpad * 2, st));
+    }
+    if ((rc = launch_convert_rows(src, dtype, ix->d, nq, ix->d, ix->dpad, normalize, (float*)ix->w_q32.p,
+                                  (uint16_t*)ix->w_q16.p, st)))
+        return rc;
+    if ((rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, st))) return rc;
+
+    if (ix->ntotal > 0) {
+        bool fused = ix->mode == LDOT_MODE_FUSED ||
+                     (ix->mode == LDOT_MODE_AUTO && ix->ntotal >= 131072 && nq_pad >= 4 * kBN);
+        if (fused) {
+            bool overflowed = false;
+            if ((rc = fused_scan(ix, nq, nq_pad, kp, st, &overflowed))) return rc;
+            if (overflowed) {   // adversarial row order: redo everything with the always-correct dense path
+                if ((rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, st))) return rc;
+                fused = false;
+            }
+        }
+        if (!fused && (rc = dense_scan_all(ix, nq, 0, ix->ntotal, kp, nullptr, st))) return rc;
+    }
+    if ((rc = launch_rescore((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, nq,
+                             (const float*)ix->w_ls.p, (const int32_t*)ix->w_li.p, kp, k, ix->rescore,
+                             (float*)ix->w_outs.p, (int64_t*)ix->w_outl.p, st)))
+        return rc;
+    const hipMemcpyKind kind = out_mem == LDOT_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    LDOT_HIP_CHECK(hipMemcpyAsync(out_scores, ix->w_outs.p, (size_t)nq * k * 4, kind, st));
+    LDOT_HIP_CHECK(hipMemcpyAsync(out_labels, ix->w_outl.p, (size_t)nq * k * 8, kind, st));
+    if (out_mem == LDOT_HOST || mem == LDOT_HOST) LDOT_HIP_CHECK(hipStreamSynchronize(st));
+    prof_collect(ix, st);
+    return LDOT_OK;
+}
+
+int ldot_index_last_profile(const ldot_index_t* ix, double out[4]) {
+    LDOT_REQUIRE(ix != nullptr && out != nullptr, LDOT_EINVAL, "NULL argument");
+    for (int i = 0; i < 4; ++i) out[i] = ix->prof[i];
+    return LDOT_OK;
+}
+
+// ---- serialisation: "LDOTIDX1" | int32 d | int64 ntotal | ntotal*d fp32 (row-major, unpadded) -------------
+int ldot_index_save(ldot_index_t* ix, const char* path) {
+    LDOT_REQUIRE(ix != nullptr && path != nullptr, LDOT_EINVAL, "NULL argument");
+    std::vector<float> host((size_t)ix->ntotal * ix->d);
+    if (ix->ntotal > 0) {
+        int rc = ldot_index_get_rows(ix, 0, ix->ntotal, host.data(), LDOT_HOST, nullptr);
+        if (rc) return rc;
+    }
+    FILE* f = fopen(path, "wb");
+    LDOT_REQUIRE(f != nullptr, LDOT_EIO, "cannot open %s for writing", path);
+    const char magic[8] = {'L', 'D', 'O', 'T', 'I', 'D', 'X', '1'};
+    int32_t d = ix->d;
+    int64_t n = ix->ntotal;
+    bool ok = fwrite(magic, 1, 8, f) == 8 && fwrite(&d, 4, 1, f) == 1 && fwrite(&n, 8, 1, f) == 1 &&
+              (host.empty() || fwrite(host.data(), sizeof(float), host.size(), f) == host.size());
+    ok = (fclose(f) == 0) && ok;
+    LDOT_REQUIRE(ok, LDOT_EIO, "short write to %s", path);
+    return LDOT_OK;
+}
+
+int ldot_index_load(const char* path, ldot_index_t** out) {
+    LDOT_REQUIRE(path != nullptr && out != nullptr, LDOT_EINVAL, "NULL argument");
+    FILE* f = fopen(path, "rb");
+    LDOT_REQUIRE(f != nullptr, LDOT_EIO, "cannot open %s", path);
+    char magic[8];
+    int32_t d = 0;
+    int64_t n = 0;
+    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "LDOTIDX1", 8) == 0 && fread(&d, 4, 1, f) == 1 &&
+              fread(&n, 8, 1, f) == 1 && d > 0 && n >= 0;
+    if (!ok) {
+        fclose(f);
+        set_error("%s is not an LDOTIDX1 file", path);
+        return LDOT_EIO;
+    }
+    std::vector<float> host((size_t)n * d);
+    ok = host.empty() || fread(host.data(), sizeof(float), host.size(), f) == host.size();
+    fclose(f);
+    LDOT_REQUIRE(ok, LDOT_EIO, "%s is truncated", path);
+    ldot_index* ix = nullptr;
+    int rc = ldot_index_create(d, &ix);
+    if (rc) return rc;
+    rc = ldot_index_add(ix, host.data(), n, LDOT_F32, LDOT_HOST, 0, nullptr);
+    if (rc) {
+        ldot_index_destroy(ix);
+        return rc;
+    }
+    *out = ix;
+    return LDOT_OK;
+}
+
+int ldot_merge_topk(const float* scores, const int64_t* labels, int nparts, int64_t nq, int k_in, int k_out,
+                    float* out_scores, int64_t* out_labels, int mem, void* stream) {
+    LDOT_REQUIRE(scores && labels && out_scores && out_labels, LDOT_EINVAL, "NULL buffer");
+    LDOT_REQUIRE(nparts >= 1 && k_in >= 1 && k_out >= 1 && k_out <= kMaxKp && nq >= 0, LDOT_EINVAL, "bad sizes");
+    if (nq == 0) return LDOT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (mem == LDOT_DEVICE)
+        return launch_select_lists(scores, labels, nq * k_in, nparts, k_in, nq, k_out, out_scores, out_labels, st);
+    LDOT_REQUIRE(mem == LDOT_HOST, LDOT_EINVAL, "bad mem");
+    const size_t n_in = (size_t)nparts * nq * k_in, n_out = (size_t)nq * k_out;
+    void *ds = nullptr, *dl = nullptr, *os = nullptr, *ol = nullptr;
+    int rc = LDOT_OK;
+    if (hipMalloc(&ds, n_in * 4) != hipSuccess || hipMalloc(&dl, n_in * 8) != hipSuccess ||
+        hipMalloc(&os, n_out * 4) != hipSuccess || hipMalloc(&ol, n_out * 8) != hipSuccess) {
+        set_error("device allocation failed in ldot_merge_topk");
+        rc = LDOT_ENOMEM;
+    }
+    if (!rc && (hipMemcpyAsync(ds, scores, n_in * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipMemcpyAsync(dl, labels, n_in * 8, hipMemcpyHostToDevice, st) != hipSuccess)) {
+        set_error("H2D copy failed in ldot_merge_topk");
+        rc = LDOT_EDEVICE;
+    }
+    if (!rc)
+        rc = launch_select_lists((const float*)ds, (const int64_t*)dl, nq * k_in, nparts, k_in, nq, k_out, (float*)os,
+                                 (int64_t*)ol, st);
+    if (!rc && (hipMemcpyAsync(out_scores, os, n_out * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(out_labels, ol, n_out * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess)) {
+        set_error("D2H copy failed in ldot_merge_topk");
+        rc = LDOT_EDEVICE;
+    }
+    (void)hipFree(ds);
+    (void)hipFree(dl);
+    (void)hipFree(os);
+    (void)hipFree(ol);
+    return rc;
+}
+
+int ldot_cls_pool(const void* seq, int dtype, int64_t B, int64_t stride_b, int64_t D, int normalize, float* out_f32,
+                  void* out_bf16, void* stream) {
+    LDOT_REQUIRE(seq != nullptr && (out_f32 || out_bf16), LDOT_EINVAL, "NULL buffer");
+    LDOT_REQUIRE(B >= 0 && D > 0 && D <= 65536 && stride_b >= D, LDOT_EINVAL, "bad shape");
+    return launch_convert_rows(seq, dtype, stride_b, B, (int)D, (int)D, normalize, out_f32, (uint16_t*)out_bf16,
+                               (hipStream_t)stream);
+}
+
+}  // extern "C"

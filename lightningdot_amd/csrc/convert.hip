@@ -1,0 +1,74 @@
+// Row ingest: caller rows (fp32 / bf16 / fp16, arbitrary row stride) -> padded fp32 master copy + bf16 shadow,
+// optional L2 normalisation.  One wave per row.  Serves index add (dvl/indexer/faiss_indexers.py:77
+// IndexFlatIP.add), query ingest for search (:83) and [CLS] pooling (dvl/models/bi_encoder.py:120,188:
+// pooled = sequence_output[:, 0, :] is a strided row gather, ld_src = L*D).
+#include "kernels.h"
+
+namespace ldot {
+
+template <int DT>
+__device__ inline float load_elem(const void* p, int64_t i) {
+    if (DT == LDOT_F32) return ((const float*)p)[i];
+    if (DT == LDOT_BF16) return bf16_bits_to_f32(((const uint16_t*)p)[i]);
+    return f16_bits_to_f32(((const uint16_t*)p)[i]);
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void convert_rows_kernel(const void* __restrict__ src, int64_t ld_src, int64_t n,
+                                                           int d, int dpad, int normalize,
+                                                           float* __restrict__ dst32,
+                                                           uint16_t* __restrict__ dst16) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int64_t so = row * ld_src;
+    float scale = 1.f;
+    if (normalize) {
+        // fp64 accumulation of the squared norm: matches x / max(||x||, eps) of the oracle to fp32 rounding
+        double ss = 0.0;
+        for (int c = lane; c < d; c += 64) {
+            const double v = (double)load_elem<DT>(src, so + c);
+            ss += v * v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        const double nrm = sqrt(ss);
+        scale = (float)(1.0 / (nrm > 1e-12 ? nrm : 1e-12));
+    }
+    for (int c = lane; c < dpad; c += 64) {
+        float v = 0.f;
+        if (c < d) {
+            v = load_elem<DT>(src, so + c);
+            if (normalize) v = v * scale;
+        }
+        if (dst32) dst32[row * dpad + c] = v;
+        if (dst16) dst16[row * dpad + c] = f32_to_bf16_bits(v);
+    }
+}
+
+int launch_convert_rows(const void* src, int dtype, int64_t ld_src, int64_t n, int d, int dpad, int normalize,
+                        float* dst32, uint16_t* dst16, hipStream_t st) {
+    if (n <= 0) return LDOT_OK;
+    const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+    switch (dtype) {
+        case LDOT_F32:
+            hipLaunchKernelGGL(convert_rows_kernel<LDOT_F32>, grid, block, 0, st, src, ld_src, n, d, dpad, normalize,
+                               dst32, dst16);
+            break;
+        case LDOT_BF16:
+            hipLaunchKernelGGL(convert_rows_kernel<LDOT_BF16>, grid, block, 0, st, src, ld_src, n, d, dpad, normalize,
+                               dst32, dst16);
+            break;
+        case LDOT_F16:
+            hipLaunchKernelGGL(convert_rows_kernel<LDOT_F16>, grid, block, 0, st, src, ld_src, n, d, dpad, normalize,
+                               dst32, dst16);
+            break;
+        default:
+            set_error("unsupported dtype %d", dtype);
+            return LDOT_EINVAL;
+    }
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+}  // namespace ldot

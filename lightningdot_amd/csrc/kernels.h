@@ -1,0 +1,59 @@
+// Host-side launchers of the HIP kernels (internal to libldot.so).
+#pragma once
+#include "ldot_common.h"
+
+namespace ldot {
+
+constexpr int kMaxKp = 2048;       // largest candidate-list length (k + margin) supported by the select kernels
+constexpr int kSelThreads = 256;
+constexpr int kSelSeg = 2048;      // candidates examined between two compaction checks
+constexpr int kSelCap = 4096;      // LDS candidate buffer (64-bit keys)
+
+// fused-filter candidate pools: per query, kPoolSubs private sub-pools of kPoolCap (score, row) pairs.
+// sub-pool id = ((slice * 2 + wm) * 2 + (lane >> 5)); slice = fused-kernel row slice 0..kFusedSlices-1
+constexpr int kFusedSlices = 32;
+constexpr int kPoolSubs = kFusedSlices * 4;
+constexpr int kPoolCap = 32;
+
+// rows: convert n rows of `dtype` (row stride ld_src elements, d valid columns) into the padded fp32 master copy
+// and/or its bf16 shadow (row stride dpad, zero padded); optional L2 normalisation.
+int launch_convert_rows(const void* src, int dtype, int64_t ld_src, int64_t n, int d, int dpad, int normalize,
+                        float* dst32, uint16_t* dst16, hipStream_t st);
+
+int launch_score_dense(const void* q16, int64_t ldq_elems, int64_t nq_pad, const void* x16, int64_t ldx_elems,
+                       int64_t xrow0, int64_t nrows_pad, int dpad, float* S, int64_t lds_elems, hipStream_t st);
+
+// lists: [nq][kp] fp32 scores + int32 rows, kept sorted (score desc, row asc); empty slots have row -1.
+int launch_init_lists(float* list_s, int32_t* list_i, int64_t n, hipStream_t st);
+int launch_select_dense(const float* S, int64_t lds_elems, int64_t nq, int64_t ncols, int64_t idx_base,
+                        float* list_s, int32_t* list_i, int kp, float* tau, hipStream_t st);
+int launch_select_pools(const float* pool_s, const int32_t* pool_i, const int32_t* pool_cnt, int64_t nq,
+                        float* list_s, int32_t* list_i, int kp, float* tau, int32_t* overflow_flags,
+                        hipStream_t st);
+// generic merge of explicit candidate lists: cand_[sl] is [nq][ncand] (labels int64, -1 = empty) -> [nq][k_out]
+int launch_select_lists(const float* cand_s, const int64_t* cand_l, int64_t part_stride, int nparts, int k_in,
+                        int64_t nq, int k_out, float* out_s, int64_t* out_l, hipStream_t st);
+
+// exact fp32 re-score of the kp candidates of every query, final ordering, top-k output.
+int launch_rescore(const float* q32, int64_t ldq, const float* x32, int64_t ldx, int dpad, int64_t nq,
+                   const float* list_s, const int32_t* list_i, int kp, int k, int do_rescore, float* out_s,
+                   int64_t* out_l, hipStream_t st);
+
+// fused MFMA score + threshold filter over index rows [row0, row0 + nrows) (nrows_pad multiple of 256)
+int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_t nrows, const void* q16,
+                        int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, float* pool_s,
+                        int32_t* pool_i, int32_t* pool_cnt, hipStream_t st);
+
+// loss path (fp32-input MFMA)
+int launch_sgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* B2, float w, float* C,
+                    int64_t ldc, int64_t M, int64_t N, int64_t K, hipStream_t st);
+int launch_sgemm_nn(const float* A, int64_t lda, const float* B, int64_t ldb, float alpha, float* C, int64_t ldc,
+                    int64_t M, int64_t N, int64_t K, int accumulate, hipStream_t st);
+int launch_sgemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float alpha, float* C, int64_t ldc,
+                    int64_t M, int64_t N, int64_t K, int accumulate, hipStream_t st);
+int launch_nll_rows(const float* scores, int64_t n1, int64_t n2, const int32_t* pos, float* row_loss, float* lse,
+                    int32_t* correct, float* loss_sum, hipStream_t st);
+int launch_nll_dscores(const float* scores, const float* lse, const int32_t* pos, const float* g_row,
+                       const float* g_scores, int64_t n1, int64_t n2, float* ds, hipStream_t st);
+
+}  // namespace ldot

@@ -1,0 +1,84 @@
+// Shared device/host helpers for the lightningdot_amd HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ldot.h"
+
+namespace ldot {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+
+// round-to-nearest-even fp32 -> bf16 bits (NaN kept quiet)
+__host__ __device__ inline uint16_t f32_to_bf16_bits(float f) {
+    union { float f; uint32_t u; } v;
+    v.f = f;
+    uint32_t u = v.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__host__ __device__ inline float bf16_bits_to_f32(uint16_t b) {
+    union { float f; uint32_t u; } v;
+    v.u = ((uint32_t)b) << 16;
+    return v.f;
+}
+__host__ __device__ inline float f16_bits_to_f32(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1fu;
+    uint32_t man = h & 0x3ffu;
+    union { float f; uint32_t u; } v;
+    if (exp == 0) {
+        if (man == 0) { v.u = sign; return v.f; }
+        // subnormal
+        float m = (float)man * (1.0f / 1024.0f) * (1.0f / 16384.0f);
+        return (h & 0x8000u) ? -m : m;
+    }
+    if (exp == 31) { v.u = sign | 0x7f800000u | (man << 13); return v.f; }
+    v.u = sign | ((exp + 112u) << 23) | (man << 13);
+    return v.f;
+}
+
+// Order-preserving map float -> uint32 such that LARGER float  <=>  SMALLER key ("descending key").
+// -0.0 and +0.0 map to different keys (+0 better than -0); NaNs sort by their bit pattern.
+__host__ __device__ inline uint32_t desc_key(float f) {
+    union { float f; uint32_t u; } v;
+    v.f = f;
+    uint32_t u = v.u;
+    uint32_t asc = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ~asc;
+}
+__host__ __device__ inline float desc_key_to_float(uint32_t k) {
+    uint32_t asc = ~k;
+    uint32_t u = (asc & 0x80000000u) ? (asc & 0x7fffffffu) : ~asc;
+    union { float f; uint32_t u; } v;
+    v.u = u;
+    return v.f;
+}
+
+__host__ __device__ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+void set_error(const char* fmt, ...);
+
+#define LDOT_HIP_CHECK(expr)                                                                         \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            ::ldot::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return (_e == hipErrorOutOfMemory) ? LDOT_ENOMEM : LDOT_EDEVICE;                         \
+        }                                                                                            \
+    } while (0)
+
+#define LDOT_REQUIRE(cond, code, ...)       \
+    do {                                    \
+        if (!(cond)) {                      \
+            ::ldot::set_error(__VA_ARGS__); \
+            return (code);                  \
+        }                                   \
+    } while (0)
+
+}  // namespace ldot

@@ -1,0 +1,92 @@
+// Exact fp32 re-score of the bf16-generated candidates + final ordering (score desc, row asc) + top-k output.
+// The reference's scorer is fp32 end to end (faiss IndexFlatIP, dvl/indexer/faiss_indexers.py:83); candidates
+// come from the bf16 MFMA pass with a safety margin (k' > k) and every reported score is recomputed here from
+// the fp32 master copy of the rows, which is what makes rank order and scores match the fp32 reference.
+#include "kernels.h"
+
+namespace ldot {
+
+constexpr int kRsThreads = 256;
+
+__device__ inline void bitonic_sort_lds_rs(uint64_t* keys, int P) {
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (P >> 1); t += kRsThreads) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int p = i | j;
+                const bool asc = ((i & k) == 0);
+                const uint64_t a = keys[i], b = keys[p];
+                if ((a > b) == asc) {
+                    keys[i] = b;
+                    keys[p] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __restrict__ q32, int64_t ldq,
+                                                             const float* __restrict__ x32, int64_t ldx, int dpad,
+                                                             const float* __restrict__ list_s,
+                                                             const int32_t* __restrict__ list_i, int kp, int k,
+                                                             int do_rescore, float* __restrict__ out_s,
+                                                             int64_t* __restrict__ out_l) {
+    __shared__ __attribute__((aligned(16))) uint64_t keys[kMaxKp];
+    const int64_t q = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* qrow = q32 + q * ldq;
+    int P = 2;
+    while (P < kp) P <<= 1;
+    for (int e = kp + threadIdx.x; e < P; e += kRsThreads) keys[e] = ~0ull;
+    for (int e = wave; e < kp; e += kRsThreads / 64) {
+        const int32_t r = list_i[q * kp + e];
+        uint64_t key = ~0ull;
+        if (r >= 0) {
+            float s;
+            if (do_rescore) {
+                const float* xr = x32 + (int64_t)r * ldx;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                for (int c = lane * 4; c < dpad; c += 256) {
+                    const f32x4 xv = *(const f32x4*)(xr + c);
+                    const f32x4 qv = *(const f32x4*)(qrow + c);
+                    a0 = fmaf(xv[0], qv[0], a0);
+                    a1 = fmaf(xv[1], qv[1], a1);
+                    a2 = fmaf(xv[2], qv[2], a2);
+                    a3 = fmaf(xv[3], qv[3], a3);
+                }
+                s = (a0 + a1) + (a2 + a3);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            } else {
+                s = list_s[q * kp + e];
+            }
+            key = ((uint64_t)desc_key(s) << 32) | (uint32_t)r;
+        }
+        if (lane == 0) keys[e] = key;
+    }
+    __syncthreads();
+    bitonic_sort_lds_rs(keys, P);
+    for (int e = threadIdx.x; e < k; e += kRsThreads) {
+        const uint64_t key = (e < P) ? keys[e] : ~0ull;
+        if (key != ~0ull) {
+            out_s[q * k + e] = desc_key_to_float((uint32_t)(key >> 32));
+            out_l[q * k + e] = (int64_t)(uint32_t)(key & 0xffffffffu);
+        } else {
+            out_s[q * k + e] = LDOT_PAD_SCORE;
+            out_l[q * k + e] = LDOT_PAD_LABEL;
+        }
+    }
+}
+
+int launch_rescore(const float* q32, int64_t ldq, const float* x32, int64_t ldx, int dpad, int64_t nq,
+                   const float* list_s, const int32_t* list_i, int kp, int k, int do_rescore, float* out_s,
+                   int64_t* out_l, hipStream_t st) {
+    if (nq <= 0) return LDOT_OK;
+    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)nq), dim3(kRsThreads), 0, st, q32, ldq, x32, ldx, dpad,
+                       list_s, list_i, kp, k, do_rescore, out_s, out_l);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+}  // namespace ldot

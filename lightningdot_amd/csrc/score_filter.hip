@@ -1,0 +1,118 @@
+// Fused bf16 MFMA score + threshold filter: the Q x N score matrix is never materialised.
+//
+// Replaces the sgemm + heap inside faiss IndexFlatIP.search (dvl/indexer/faiss_indexers.py:83) for large
+// indexes.  Orientation is "swapped": A = index rows (M side), B = queries (N side), so in the MFMA C/D layout
+// a lane owns ONE query column (col = lane & 31) and its accumulator registers hold that query's scores
+// against 64 different index rows.  The per-query admission threshold tau (the current k'-th best score, a
+// valid lower bound of the final one) therefore lives in a lane register and the filter is one v_cmp per
+// score with an exec-masked, almost never taken, append.
+//
+// Appends go to lane-private sub-pools in HBM (cursor in a VGPR, no atomics, no LDS): for a query q the
+// 4 lanes x 32 row slices that can produce candidates each own pool[q][sub][0..kPoolCap).  The select kernel
+// (select.hip) folds the pools into the running top-k' list between launches and raises tau.
+//
+// Work decomposition (256 persistent workgroups, block b observed on XCD b % 8):
+//   XCD x, slot s in [0,32): qsub = s % 8, nsub = s / 8;  row slice = x*4 + nsub  -> tiles t = slice (mod 32)
+//   for each group of 8 query blocks: query block = g*8 + qsub.
+// At any time the 32 workgroups of an XCD work on 8 query panels x 4 adjacent row tiles, so the private L2
+// holds 8 Q panels (3 MiB) and streams each row panel once per query group.
+#include "gemm_tile.h"
+#include "kernels.h"
+
+namespace ldot {
+
+// Filter epilogue.  Fast path per 4 accumulator registers (256 scores): one max tree + one compare + one
+// (almost never taken) branch.  The slow path re-tests the four registers and appends the hits to the
+// lane-private sub-pool (cursor `cur`, clamped at kPoolCap; the true count is kept so overflow is detectable).
+__device__ inline void filter_append(float v, float tau, int32_t row, int32_t row_end, int& cur, uint32_t pbase,
+                                     float* __restrict__ pool_s, int32_t* __restrict__ pool_i) {
+    if (v >= tau && row < row_end) {
+        const int p = cur;
+        cur = p + 1;
+        if (p < kPoolCap) {
+            pool_s[pbase + (uint32_t)p] = v;
+            pool_i[pbase + (uint32_t)p] = row;
+        }
+    }
+}
+
+__device__ inline void filter_epilogue(const f32x16 (&acc)[4][2], const float (&tau)[2], int (&cur)[2],
+                                       const uint32_t (&pbase)[2], float* __restrict__ pool_s,
+                                       int32_t* __restrict__ pool_i, int32_t row_lane0, int32_t row_end) {
+#pragma unroll
+    for (int nr = 0; nr < 2; ++nr) {
+#pragma unroll
+        for (int mr = 0; mr < 4; ++mr) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float a0 = acc[mr][nr][4 * g + 0], a1 = acc[mr][nr][4 * g + 1];
+                const float a2 = acc[mr][nr][4 * g + 2], a3 = acc[mr][nr][4 * g + 3];
+                const float m = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+                if (m >= tau[nr]) {
+                    // rows of register r = 4g + e:  (r & 3) + 8 * (r >> 2) = e + 8g
+                    const int32_t rb = row_lane0 + mr * 32 + 8 * g;
+                    filter_append(a0, tau[nr], rb + 0, row_end, cur[nr], pbase[nr], pool_s, pool_i);
+                    filter_append(a1, tau[nr], rb + 1, row_end, cur[nr], pbase[nr], pool_s, pool_i);
+                    filter_append(a2, tau[nr], rb + 2, row_end, cur[nr], pbase[nr], pool_s, pool_i);
+                    filter_append(a3, tau[nr], rb + 3, row_end, cur[nr], pbase[nr], pool_s, pool_i);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kGemmThreads, 2) void score_filter_kernel(
+    const char* __restrict__ X16, int64_t ldx_b, int64_t row0, int64_t nrows, const char* __restrict__ Q16,
+    int64_t ldq_b, int nqb, int nk, const float* __restrict__ tau_g, float* __restrict__ pool_s,
+    int32_t* __restrict__ pool_i, int32_t* __restrict__ pool_cnt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    TileCtx c;
+    tile_ctx_init(c);
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int qsub = slot & 7, nsub = slot >> 3;
+    const int slice = xcd * 4 + nsub;
+    const int ntiles = (int)((nrows + kBM - 1) / kBM);
+    const int32_t row_end = (int32_t)(row0 + nrows);
+    const int sub = (slice * 2 + c.wm) * 2 + (c.lane >> 5);
+    f32x16 acc[4][2];
+
+    for (int qb = qsub; qb < nqb; qb += 8) {
+        float tau[2];
+        int cur[2] = {0, 0};
+        uint32_t pbase[2];
+        int64_t qidx[2];
+#pragma unroll
+        for (int nr = 0; nr < 2; ++nr) {
+            qidx[nr] = (int64_t)qb * kBN + c.wn * 64 + nr * 32 + (c.lane & 31);
+            tau[nr] = tau_g[qidx[nr]];
+            pbase[nr] = (uint32_t)((qidx[nr] * kPoolSubs + sub) * kPoolCap);
+        }
+        for (int t = slice; t < ntiles; t += kFusedSlices) {
+            const int64_t trow = row0 + (int64_t)t * kBM;
+            gemm_tile(c, X16, ldx_b, trow, Q16, ldq_b, (int64_t)qb * kBN, nk, smem, acc);
+            const int32_t row_lane0 = (int32_t)trow + c.wm * 128 + 4 * (c.lane >> 5);
+            filter_epilogue(acc, tau, cur, pbase, pool_s, pool_i, row_lane0, row_end);
+        }
+#pragma unroll
+        for (int nr = 0; nr < 2; ++nr) pool_cnt[qidx[nr] * kPoolSubs + sub] = cur[nr];
+    }
+}
+
+int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_t nrows, const void* q16,
+                        int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, float* pool_s,
+                        int32_t* pool_i, int32_t* pool_cnt, hipStream_t st) {
+    if (nrows <= 0 || nq_pad <= 0) return LDOT_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)score_filter_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLdsBytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(score_filter_kernel, dim3(256), dim3(kGemmThreads), kGemmLdsBytes, st, (const char*)x16,
+                       ldx_elems * 2, row0, nrows, (const char*)q16, ldq_elems * 2, (int)(nq_pad / kBN), dpad / kBK,
+                       tau, pool_s, pool_i, pool_cnt);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+}  // namespace ldot

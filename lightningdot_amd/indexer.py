@@ -1,0 +1,233 @@
+"""Dense inner-product indexers — host-side mirror of dvl/indexer/faiss_indexers.py (reference), backed by the
+MI355X HIP library instead of faiss-cpu.
+
+    DenseIndexer        <- faiss_indexers.py:22-60   (id map, serialize / deserialize_from, two-file naming)
+    DenseFlatIndexer    <- faiss_indexers.py:63-87   (IndexFlatIP: index_data / search_knn)
+    FlatIPIndex         <- the faiss.IndexFlatIP object itself (ctor :67, add :77, search :83, ntotal :52,
+                           write_index :41 / read_index :51)
+
+Same names, argument meaning and return types as the reference (results sorted by descending score, one
+``(ids, scores)`` tuple per query, scores as float32 ndarray).  Additions: device tensors are accepted everywhere
+(no numpy round trip), ``search_knn_tensors`` returns device tensors, ``normalize=True`` is the opt-in
+L2 variant.  There is no CPU fallback: constructing an index without the HIP library / a GPU raises.
+"""
+import ctypes
+import logging
+import pickle
+from typing import List, Tuple
+
+import numpy as np
+
+from . import _lib as L
+
+logger = logging.getLogger()
+
+
+def _is_tensor(x):
+    return type(x).__module__.startswith('torch') and hasattr(x, 'data_ptr')
+
+
+def _stream_ptr(device_tensor=None):
+    import torch
+    if torch.cuda.is_available():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(0)
+
+
+def _describe(x, d):
+    """-> (keepalive, pointer, n_rows, dtype_code, mem_code) for a [n, d] array / tensor."""
+    if _is_tensor(x):
+        import torch
+        t = x.detach()
+        if t.dim() == 1:
+            t = t.view(1, -1)
+        if t.dim() != 2 or t.shape[1] != d:
+            raise ValueError(f'expected [n, {d}] vectors, got {tuple(t.shape)}')
+        code = {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.F16}.get(t.dtype)
+        if code is None:
+            t = t.float()
+            code = L.F32
+        t = t.contiguous()
+        return t, ctypes.c_void_p(t.data_ptr()), t.shape[0], code, (L.DEVICE if t.is_cuda else L.HOST)
+    a = np.asarray(x)
+    if a.ndim == 1:
+        a = a.reshape(1, -1)
+    if a.ndim != 2 or a.shape[1] != d:
+        raise ValueError(f'expected [n, {d}] vectors, got {a.shape}')
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, ctypes.c_void_p(a.ctypes.data), a.shape[0], L.F32, L.HOST
+
+
+class FlatIPIndex:
+    """Exact inner-product index resident in HBM (fp32 master copy + bf16 MFMA shadow).  Stands where the
+    reference holds a ``faiss.IndexFlatIP`` (faiss_indexers.py:67)."""
+
+    def __init__(self, d: int, normalize: bool = False, _handle=None):
+        self._lib = L.load_library()
+        self.normalize = bool(normalize)
+        if _handle is not None:
+            self._h = _handle
+        else:
+            h = ctypes.c_void_p()
+            L.check(self._lib.ldot_index_create(int(d), ctypes.byref(h)))
+            self._h = h
+        self.d = int(self._lib.ldot_index_dim(self._h))
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h is not None and getattr(self, '_lib', None) is not None:
+            try:
+                self._lib.ldot_index_destroy(h)
+            except Exception:  # pragma: no cover
+                pass
+
+    @property
+    def ntotal(self) -> int:
+        return int(self._lib.ldot_index_ntotal(self._h))
+
+    def set_option(self, option: int, value: int):
+        L.check(self._lib.ldot_index_set_option(self._h, int(option), int(value)))
+
+    def reset(self):
+        L.check(self._lib.ldot_index_reset(self._h))
+
+    def add(self, vectors):
+        keep, ptr, n, dt, mem = _describe(vectors, self.d)
+        L.check(self._lib.ldot_index_add(self._h, ptr, n, dt, mem, int(self.normalize), _stream_ptr()))
+        if mem == L.DEVICE:
+            import torch
+            torch.cuda.current_stream().synchronize()   # `keep` may be a temporary
+        del keep
+
+    def search(self, queries, k: int):
+        """faiss-style: (scores [nq, k] float32, labels [nq, k] int64) as numpy arrays."""
+        keep, ptr, nq, dt, mem = _describe(queries, self.d)
+        scores = np.empty((nq, k), dtype=np.float32)
+        labels = np.empty((nq, k), dtype=np.int64)
+        L.check(self._lib.ldot_index_search(self._h, ptr, nq, dt, mem, int(self.normalize), int(k),
+                                            ctypes.c_void_p(scores.ctypes.data), ctypes.c_void_p(labels.ctypes.data),
+                                            L.HOST, _stream_ptr()))
+        del keep
+        return scores, labels
+
+    def search_tensors(self, queries, k: int):
+        """Device-resident variant: queries is a CUDA tensor; returns (scores, labels) CUDA tensors."""
+        import torch
+        keep, ptr, nq, dt, mem = _describe(queries, self.d)
+        if mem != L.DEVICE:
+            raise ValueError('search_tensors expects a CUDA tensor')
+        scores = torch.empty((nq, k), dtype=torch.float32, device=keep.device)
+        labels = torch.empty((nq, k), dtype=torch.int64, device=keep.device)
+        L.check(self._lib.ldot_index_search(self._h, ptr, nq, dt, mem, int(self.normalize), int(k),
+                                            ctypes.c_void_p(scores.data_ptr()), ctypes.c_void_p(labels.data_ptr()),
+                                            L.DEVICE, _stream_ptr()))
+        return scores, labels
+
+    def get_rows(self, row0: int, n: int) -> np.ndarray:
+        out = np.empty((n, self.d), dtype=np.float32)
+        L.check(self._lib.ldot_index_get_rows(self._h, int(row0), int(n), ctypes.c_void_p(out.ctypes.data), L.HOST,
+                                              _stream_ptr()))
+        return out
+
+    def last_stats(self):
+        a = (ctypes.c_int64 * 4)()
+        L.check(self._lib.ldot_index_last_stats(self._h, a))
+        return dict(fused_candidates=a[0], overflowed_queries=a[1], dense_pairs=a[2], fused_pairs=a[3])
+
+    def last_profile(self):
+        a = (ctypes.c_double * 4)()
+        L.check(self._lib.ldot_index_last_profile(self._h, a))
+        return dict(launches=a[0], kernel_ms=a[1], flops=a[2], bytes=a[3])
+
+    def save(self, path: str):
+        L.check(self._lib.ldot_index_save(self._h, path.encode()))
+
+    @classmethod
+    def load(cls, path: str, normalize: bool = False):
+        lib = L.load_library()
+        h = ctypes.c_void_p()
+        L.check(lib.ldot_index_load(path.encode(), ctypes.byref(h)))
+        return cls(0, normalize=normalize, _handle=h)
+
+
+class DenseIndexer(object):
+    """faiss_indexers.py:22-60"""
+
+    def __init__(self, buffer_size: int = 50000):
+        self.buffer_size = buffer_size
+        self.index_id_to_db_id = []
+        self.index = None
+
+    def index_data(self, data: List[Tuple[object, np.array]]):
+        raise NotImplementedError
+
+    def search_knn(self, query_vectors: np.array, top_docs: int) -> List[Tuple[List[object], List[float]]]:
+        raise NotImplementedError
+
+    def serialize(self, file: str):
+        """Two files like the reference (:35-43): ``file + '.index.dpr'`` (own LDOTIDX1 binary instead of the
+        third-party faiss format) and ``file + '.index_meta.dpr'`` (pickled id list)."""
+        logger.info('Serializing index to %s', file)
+        index_file = file + '.index.dpr'
+        meta_file = file + '.index_meta.dpr'
+        self.index.save(index_file)
+        with open(meta_file, mode='wb') as f:
+            pickle.dump(self.index_id_to_db_id, f)
+
+    def deserialize_from(self, file: str):
+        logger.info('Loading index from %s', file)
+        index_file = file + '.index.dpr'
+        meta_file = file + '.index_meta.dpr'
+        self.index = FlatIPIndex.load(index_file, normalize=getattr(self.index, 'normalize', False))
+        logger.info('Loaded index of type %s and size %d', type(self.index), self.index.ntotal)
+        with open(meta_file, 'rb') as reader:
+            self.index_id_to_db_id = pickle.load(reader)
+        assert len(
+            self.index_id_to_db_id) == self.index.ntotal, 'Deserialized index_id_to_db_id should match faiss index size'
+
+    def _update_id_mapping(self, db_ids: List):
+        self.index_id_to_db_id.extend(db_ids)
+
+
+class DenseFlatIndexer(DenseIndexer):
+    """faiss_indexers.py:63-87"""
+
+    def __init__(self, vector_sz: int, buffer_size: int = 50000, normalize: bool = False):
+        super(DenseFlatIndexer, self).__init__(buffer_size=buffer_size)
+        self.index = FlatIPIndex(vector_sz, normalize=normalize)
+
+    def index_data(self, data: List[Tuple[object, np.array]]):
+        n = len(data)
+        # same chunking as the reference (:72-77); vectors may be numpy rows or (device) tensors
+        for i in range(0, n, self.buffer_size):
+            chunk = data[i:i + self.buffer_size]
+            db_ids = [t[0] for t in chunk]
+            if chunk and _is_tensor(chunk[0][1]):
+                import torch
+                vectors = torch.stack([t[1].reshape(-1) for t in chunk], dim=0)
+            else:
+                vectors = np.concatenate([np.reshape(t[1], (1, -1)) for t in chunk], axis=0)
+            self._update_id_mapping(db_ids)
+            self.index.add(vectors)
+        indexed_cnt = len(self.index_id_to_db_id)
+        logger.info('Total data indexed %d', indexed_cnt)
+
+    def index_tensor(self, db_ids: List, vectors):
+        """Device path: ids + one [n, d] tensor, no per-row Python objects."""
+        if len(db_ids) != vectors.shape[0]:
+            raise ValueError('ids / vectors length mismatch')
+        self._update_id_mapping(list(db_ids))
+        self.index.add(vectors)
+
+    def search_knn(self, query_vectors: np.array, top_docs: int) -> List[Tuple[List[object], List[float]]]:
+        scores, indexes = self.index.search(query_vectors, top_docs)
+        # convert to external ids exactly like :85 — a padding label (-1, fewer than top_docs rows indexed) maps to
+        # the LAST id through Python's negative indexing, the reference's observable behaviour
+        ids = self.index_id_to_db_id
+        db_ids = [[ids[i] for i in query_top_idxs] for query_top_idxs in indexes.tolist()]
+        result = [(db_ids[i], scores[i]) for i in range(len(db_ids))]
+        return result
+
+    def search_knn_tensors(self, query_vectors, top_docs: int):
+        """(scores [nq, k], row labels [nq, k]) as device tensors; map labels with ``index_id_to_db_id``."""
+        return self.index.search_tensors(query_vectors, top_docs)

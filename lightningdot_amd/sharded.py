@@ -1,0 +1,127 @@
+"""Row-sharded exact retrieval over the GPUs of one node (the reference is single-process, F4).
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Rank r holds index rows
+[offset_r, offset_r + n_r); a search is
+    1. all-gather of the query embeddings each rank encoded            (10 000 x 768 fp32 ~ 30 MB in total)
+    2. local fused search of ALL queries against the local shard       (libldot.so)
+    3. exchange of the partial top-k lists by query slice               (all-to-all on RCCL; Q x k x 12 B per rank)
+    4. merge of the G partial lists of the local query slice           (ldot_merge_topk, HIP)
+so every rank ends with the final global top-k of the queries it contributed.  The scores against disjoint row
+shards are independent, so there is no other data-path collective.
+
+``local_search`` / ``merge`` are injectable for the CPU (gloo) tests of the collective logic; the defaults are the
+HIP implementations and raise without a GPU.
+"""
+import ctypes
+from typing import Callable, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from .indexer import DenseFlatIndexer
+
+
+def _hip_merge(scores: torch.Tensor, labels: torch.Tensor, k: int):
+    """scores/labels: [nparts, nq, k_in] CUDA tensors -> ([nq, k], [nq, k])"""
+    lib = L.load_library()
+    nparts, nq, k_in = scores.shape
+    scores = scores.contiguous().float()
+    labels = labels.contiguous().to(torch.int64)
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=scores.device)
+    out_l = torch.empty((nq, k), dtype=torch.int64, device=scores.device)
+    L.check(lib.ldot_merge_topk(ctypes.c_void_p(scores.data_ptr()), ctypes.c_void_p(labels.data_ptr()), nparts, nq,
+                                k_in, k, ctypes.c_void_p(out_s.data_ptr()), ctypes.c_void_p(out_l.data_ptr()), L.DEVICE,
+                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return out_s, out_l
+
+
+class ShardedFlatIndexer:
+    def __init__(self, vector_sz: int, group=None, local_search: Optional[Callable] = None,
+                 merge: Optional[Callable] = None, normalize: bool = False):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.d = vector_sz
+        self._custom = local_search is not None
+        self.local = None if self._custom else DenseFlatIndexer(vector_sz, normalize=normalize)
+        self._local_search = local_search
+        self._merge = merge or _hip_merge
+        self.n_local = 0
+        self.offsets: List[int] = [0] * (self.world + 1)
+        self.index_id_to_db_id: list = []        # GLOBAL id list (gathered), row label -> external id
+
+    # ---- build -------------------------------------------------------------------------------------------
+    def index_local_shard(self, db_ids: list, vectors, n_rows: Optional[int] = None):
+        """Add this rank's rows, then agree on the global row offsets (exclusive scan of shard sizes) and gather
+        the external id lists so that any rank can map a global label."""
+        n = len(db_ids) if n_rows is None else n_rows
+        if self.local is not None:
+            self.local.index_tensor(db_ids, vectors)
+        self.n_local += n
+        sizes = [None] * self.world
+        dist.all_gather_object(sizes, self.n_local, group=self.group)
+        self.offsets = [0]
+        for s in sizes:
+            self.offsets.append(self.offsets[-1] + int(s))
+        all_ids = [None] * self.world
+        dist.all_gather_object(all_ids, list(db_ids), group=self.group)
+        self.index_id_to_db_id = [i for part in all_ids for i in part]
+
+    @property
+    def ntotal(self) -> int:
+        return self.offsets[-1]
+
+    # ---- search ------------------------------------------------------------------------------------------
+    def _gather_queries(self, q: torch.Tensor) -> Tuple[torch.Tensor, List[int]]:
+        counts = [None] * self.world
+        dist.all_gather_object(counts, int(q.shape[0]), group=self.group)
+        mx = max(counts)
+        pad = q if q.shape[0] == mx else torch.cat([q, q.new_zeros(mx - q.shape[0], q.shape[1])], 0)
+        bufs = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(bufs, pad.contiguous(), group=self.group)
+        return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0), counts
+
+    def search(self, local_queries: torch.Tensor, k: int):
+        """-> (scores [nq_local, k] fp32, GLOBAL row labels [nq_local, k] int64) for the local queries."""
+        q_all, counts = self._gather_queries(local_queries.float())
+        if self._custom:
+            s, l = self._local_search(q_all, k)
+        else:
+            s, l = self.local.search_knn_tensors(q_all, k)
+        l = torch.where(l >= 0, l + self.offsets[self.rank], l)          # local row -> global row, padding stays -1
+        starts = [0]
+        for c in counts:
+            starts.append(starts[-1] + c)
+        mine = slice(starts[self.rank], starts[self.rank + 1])
+        nq_mine = counts[self.rank]
+        backend = dist.get_backend(self.group)
+        if backend == 'nccl' and self.world > 1:
+            # all-to-all by query slice: rank r receives, from every rank, the partial lists of ITS queries
+            mx = max(counts)
+            send_s = s.new_full((self.world, mx, k), L.PAD_SCORE)
+            send_l = l.new_full((self.world, mx, k), -1)
+            for r in range(self.world):
+                send_s[r, :counts[r]] = s[starts[r]:starts[r + 1]]
+                send_l[r, :counts[r]] = l[starts[r]:starts[r + 1]]
+            recv_s, recv_l = torch.empty_like(send_s), torch.empty_like(send_l)
+            dist.all_to_all_single(recv_s, send_s.contiguous(), group=self.group)
+            dist.all_to_all_single(recv_l, send_l.contiguous(), group=self.group)
+            part_s, part_l = recv_s[:, :nq_mine], recv_l[:, :nq_mine]
+        else:
+            gs = [torch.empty_like(s) for _ in range(self.world)]
+            gl = [torch.empty_like(l) for _ in range(self.world)]
+            dist.all_gather(gs, s.contiguous(), group=self.group)
+            dist.all_gather(gl, l.contiguous(), group=self.group)
+            part_s = torch.stack([t[mine] for t in gs], 0)
+            part_l = torch.stack([t[mine] for t in gl], 0)
+        if nq_mine == 0:
+            return s.new_empty((0, k)), l.new_empty((0, k))
+        return self._merge(part_s.contiguous(), part_l.contiguous(), k)
+
+    def search_knn(self, local_queries, top_docs: int):
+        """DenseIndexer-style result for the local queries: [(ids, scores ndarray)]."""
+        s, l = self.search(local_queries, top_docs)
+        s, l = s.cpu().numpy(), l.cpu().tolist()
+        ids = self.index_id_to_db_id
+        return [([ids[i] for i in row], s[j]) for j, row in enumerate(l)]

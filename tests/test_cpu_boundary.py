@@ -1,0 +1,81 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/ldot.h declares,
+and fails loudly (no CPU fallback) when no GPU is present."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, 'include', 'ldot.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(ldot_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    from lightningdot_amd import _lib, build
+    build.build(verbose=False)
+    lib = _lib.load_library()
+    declared = _header_functions()
+    assert declared, 'no functions parsed from include/ldot.h'
+    assert sorted(_lib.SYMBOLS) == declared, set(_lib.SYMBOLS) ^ set(declared)
+    for name in declared:
+        assert hasattr(lib, name), f'{name} not exported by libldot.so'
+    assert lib.ldot_abi_version() == 1
+    out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.lib_path()]).decode()
+    exported = set(re.findall(r'\bT (ldot_[a-z0-9_]+)', out))
+    assert set(declared) <= exported
+
+
+def test_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from lightningdot_amd import LdotError
+    from lightningdot_amd.indexer import DenseFlatIndexer
+    with pytest.raises(LdotError):
+        DenseFlatIndexer(768)
+    from lightningdot_amd.loss import BiEncoderNllLoss
+    with pytest.raises(LdotError):
+        BiEncoderNllLoss().calc(torch.zeros(2, 4), torch.zeros(2, 4), None, [0, 1])
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'lightningdot_amd')
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith(('.py', '.hip', '.h', '.cpp')):
+                txt = open(os.path.join(dp, fn), errors='replace').read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', txt, flags=re.M), fn
+                assert 'oracle_np' not in txt, fn
+
+
+def test_dedup_semantics_match_dict_update():
+    from lightningdot_amd.harness import _dedup_last
+    ids = ['b', 'a', 'b', 'c', 'a']
+    keys, last = _dedup_last(ids)
+    d = {}
+    d.update({k: i for i, k in enumerate(ids)})
+    assert keys == list(d.keys()) and last == list(d.values())
+
+
+def test_hard_negative_postprocess_matches_golden(golden_dir):
+    import json
+    from lightningdot_amd.hn import num_hard_sampled, postprocess_hard_negatives
+    g = json.load(open(os.path.join(golden_dir, 'g4_hardneg.json')))
+    assert num_hard_sampled(g['nh']) == g['num_tops']
+    pops = []
+
+    def fake_sample(pop, k):
+        pops.append(sorted(pop))
+        return sorted(pop)[:k]
+
+    hn_txt, hn_img = postprocess_hard_negatives({k: list(v) for k, v in g['hard_neg_img'].items()},
+                                                {k: list(v) for k, v in g['hard_neg_txt'].items()},
+                                                g['img2txt'], g['txt2img'], g['nh'], sample=fake_sample)
+    assert hn_txt == g['out_txt'] and hn_img == g['out_img']
+    assert dict(zip(g['hard_neg_txt'].keys(), pops[:len(g['hard_neg_txt'])])) == g['pops_txt_sorted']

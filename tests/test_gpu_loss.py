@@ -1,0 +1,138 @@
+"""GPU parity tests of the in-batch contrastive loss (HIP fp32-MFMA kernels) vs golden vectors captured from the
+reference (G1/G2) and vs the fp64 CPU oracle at the config-5 shape (S3)."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _cuda(a, grad=False):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t.requires_grad_() if grad else t
+
+
+def test_g1_loss_forward_backward(golden_dir):
+    import torch
+    from lightningdot_amd.loss import BiEncoderNllLoss
+    g = np.load(os.path.join(golden_dir, 'g1_loss.npz'))
+    cases = json.load(open(os.path.join(golden_dir, 'g1_loss_cases.json')))
+    for ci, c in enumerate(cases):
+        p = f'c{ci}_'
+        q, ctx = _cuda(g[p + 'q'], True), _cuda(g[p + 'ctx'], True)
+        cap = _cuda(g[p + 'cap'], True) if c['has_cap'] else None
+        loss, correct, scores = BiEncoderNllLoss().calc(q, ctx, cap, g[p + 'pos'].tolist(), None, float(g[p + 'w']),
+                                                        None, c['reduction'])
+        assert scores.dtype == torch.float32 and tuple(scores.shape) == (c['n1'], c['n2'])
+        np.testing.assert_allclose(scores.detach().cpu().numpy(), g[p + 'scores'], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(loss.detach().cpu().numpy(), g[p + 'loss'], rtol=2e-5, atol=2e-5)
+        assert int(correct.item()) == int(g[p + 'correct']), (ci, c)
+        torch.autograd.backward([loss, scores], [_cuda(g[p + 'gl']), _cuda(g[p + 'gs'])])
+        np.testing.assert_allclose(q.grad.cpu().numpy(), g[p + 'dq'], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(ctx.grad.cpu().numpy(), g[p + 'dctx'], rtol=1e-4, atol=1e-5)
+        if (p + 'dcap') in g.files:
+            np.testing.assert_allclose(cap.grad.cpu().numpy(), g[p + 'dcap'], rtol=1e-4, atol=1e-5)
+        elif c['has_cap']:
+            assert cap.grad is None or float(cap.grad.abs().max()) == 0.0
+
+
+def test_g2_train_step(golden_dir):
+    from lightningdot_amd.loss import train_step_loss
+    g = np.load(os.path.join(golden_dir, 'g2_train_step.npz'))
+    cases = json.load(open(os.path.join(golden_dir, 'g2_train_step_cases.json')))
+    for ci, c in enumerate(cases):
+        p = f'c{ci}_'
+        bs, nh = c['bs'], c['nh']
+        args = types.SimpleNamespace(caption_score_weight=c['w'], num_hard_negatives=nh)
+        batch = dict(sample_size=bs, pos_ctx_indices=list(range(bs)),
+                     neg_ctx_indices=[[bs + i * nh + j for j in range(nh)] for i in range(bs)])
+        loss, is_correct, scores, (lt, li) = train_step_loss(args, _cuda(g[p + 'txt']), _cuda(g[p + 'img']), None, batch)
+        np.testing.assert_allclose(loss.cpu().numpy(), g[p + 'loss'], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(lt.cpu().numpy(), g[p + 'loss_txt'], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(li.cpu().numpy(), g[p + 'loss_img'], rtol=2e-5, atol=2e-5)
+        assert is_correct == float(g[p + 'is_correct'])
+        np.testing.assert_allclose(scores.cpu().numpy(), g[p + 'scores'], rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('n1,n2,nh,w', [(512, 512, 0, 0.0), (512, 1536, 2, 0.0), (96, 96, 0, 0.1), (7, 13, 0, 0.3)])
+def test_s3_config5_shape_vs_fp64_oracle(n1, n2, nh, w):
+    """txt, img in R^{512 x 768} (+ hard negatives), seed 99; loss / grad parity vs the fp64 oracle."""
+    import torch
+    from lightningdot_amd.loss import BiEncoderNllLoss, dot_product_scores
+    rng = np.random.default_rng(99)
+    d = 768
+    q = (rng.standard_normal((n1, d)) * 0.2).astype(np.float32)
+    ctx = (rng.standard_normal((n2, d)) * 0.2).astype(np.float32)
+    ctx[:min(n1, n2)] += q[:min(n1, n2)]
+    cap = (rng.standard_normal((n2, d)) * 0.2).astype(np.float32) if w else None
+    pos = [i % n2 for i in range(n1)]
+    tq, tc = _cuda(q, True), _cuda(ctx, True)
+    tcap = _cuda(cap, True) if w else None
+    loss, correct, scores = BiEncoderNllLoss().calc(tq, tc, tcap, pos, None, w if w else 0.1)
+    l64, c64, s64 = O.biencoder_nll_loss(q, ctx, cap, pos, w if w else 0.1, 'mean', dtype=np.float64)
+    np.testing.assert_allclose(scores.detach().cpu().numpy(), s64, rtol=0, atol=1e-3 * 0.05)   # << the 1e-3 budget
+    assert abs(float(loss.item()) - float(l64)) < 1e-4
+    assert int(correct.item()) == c64
+    loss.backward()
+    dq, dctx, dcap = O.biencoder_nll_grads(q, ctx, cap, pos, w if w else 0.1, 'mean')
+    np.testing.assert_allclose(tq.grad.cpu().numpy(), dq, rtol=1e-4, atol=2e-7)
+    np.testing.assert_allclose(tc.grad.cpu().numpy(), dctx, rtol=1e-4, atol=2e-7)
+    if w:
+        np.testing.assert_allclose(tcap.grad.cpu().numpy(), dcap, rtol=1e-4, atol=2e-7)
+    # plain score matrix + its autograd
+    tq2, tc2 = _cuda(q, True), _cuda(ctx, True)
+    r = dot_product_scores(tq2, tc2)
+    np.testing.assert_allclose(r.detach().cpu().numpy(), q.astype(np.float64) @ ctx.astype(np.float64).T, atol=5e-5)
+    gr = rng.standard_normal((n1, n2)).astype(np.float32)
+    r.backward(_cuda(gr))
+    np.testing.assert_allclose(tq2.grad.cpu().numpy(), gr.astype(np.float64) @ ctx, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(tc2.grad.cpu().numpy(), gr.astype(np.float64).T @ q, rtol=1e-4, atol=1e-4)
+
+
+def test_loss_rejects_cpu_tensors():
+    import torch
+    from lightningdot_amd import LdotError
+    from lightningdot_amd.loss import BiEncoderNllLoss
+    with pytest.raises(LdotError):
+        BiEncoderNllLoss().calc(torch.zeros(2, 4), torch.zeros(2, 4), None, [0, 1])
+
+
+def test_g3_recall_harness_on_gpu(golden_dir):
+    """End-to-end eval_model_on_dataloader (fake towers) on the HIP path vs the reference's own outputs."""
+    import torch
+    from lightningdot_amd.harness import eval_model_on_dataloader
+    from tests.test_oracle_golden import _stream_from_kw
+
+    class Fake:
+        def eval(self):
+            return self
+
+        def __call__(self, batch):
+            return batch['_q'], batch['_ctx'], batch.get('_cap')
+
+    allg = json.load(open(os.path.join(golden_dir, 'g3_recall.json')))
+    for name, g in allg.items():
+        batches, img2txt = _stream_from_kw(g['kw'])
+        rb = []
+        for b in batches:
+            e = dict(txt_index=b['txt_index'], img_fname=b['img_fname'],
+                     txts={'input_ids': torch.zeros(len(b['txt_index']), 4, dtype=torch.long)},
+                     _q=_cuda(b['q']), _ctx=_cuda(b['ctx']))
+            if 'cap' in b:
+                e['_cap'] = _cuda(b['cap'])
+            rb.append(e)
+        args = types.SimpleNamespace(hnsw_index=False, vector_size=g['kw']['d'], caption_score_weight=g['w'])
+        loss, acc, _, (r_txt, r_img), (rank_txt, rank_img) = eval_model_on_dataloader(Fake(), rb, args, img2txt,
+                                                                                      g['num_tops'])
+        assert abs(loss - g['loss']) < 1e-4
+        assert abs(acc - g['acc']) < 1e-12
+        assert {str(k): v for k, v in r_txt.items()} == g['recall_txt']
+        assert {str(k): v for k, v in r_img.items()} == g['recall_img']
+        assert rank_txt == g['rank_txt'], name
+        assert rank_img == g['rank_img'], name

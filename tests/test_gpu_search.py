@@ -1,0 +1,268 @@
+"""GPU parity tests of the retrieval path: HIP library (through the C ABI / DenseFlatIndexer) vs the CPU oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_np as O
+from tests.util import assert_topk_matches, planted_queries
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def L():
+    from lightningdot_amd import _lib
+    _lib.require_gpu()
+    return _lib
+
+
+def _index(x, **opts):
+    from lightningdot_amd import _lib as LL
+    from lightningdot_amd.indexer import FlatIPIndex
+    ix = FlatIPIndex(x.shape[1], normalize=opts.pop('normalize', False))
+    for k, v in opts.items():
+        ix.set_option(getattr(LL, 'OPT_' + k.upper()), v)
+    if x.shape[0]:
+        ix.add(x)
+    return ix
+
+
+@pytest.mark.parametrize('nq,n,d,k', [
+    (37, 1000, 768, 100),      # Flickr text->image shape (reduced nq)
+    (300, 5000, 768, 100),     # Flickr image->text shape
+    (5, 300, 48, 10),          # D not a multiple of 64
+    (1, 257, 100, 1),          # single query, k = 1, ragged rows
+    (513, 70, 64, 100),        # k > ntotal -> padding
+    (260, 33000, 128, 50),     # more than one dense chunk (32768) and more than one query tile
+])
+def test_dense_matches_oracle(L, nq, n, d, k):
+    rng = np.random.default_rng(nq * 7 + n)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    ix = _index(x, mode=L.MODE_DENSE)
+    assert ix.ntotal == n
+    s, l = ix.search(q, k)
+    assert_topk_matches(q, x, s, l, k)
+    # oracle (fp32 blocked sgemm + selection) agrees as well
+    os_, ol = O.FlatIP(d), None
+    os_.add(x)
+    so, lo = os_.search(q, k)
+    np.testing.assert_allclose(s, so, rtol=0, atol=1e-3)
+    assert (l[:, 0] == lo[:, 0]).mean() > 0.999
+
+
+def test_empty_and_errors(L):
+    from lightningdot_amd.indexer import FlatIPIndex
+    ix = FlatIPIndex(32)
+    s, l = ix.search(np.zeros((3, 32), np.float32), 5)
+    assert (l == -1).all() and (s == np.float32(O.NEG_FLT_MAX)).all()
+    with pytest.raises(L.LdotError):
+        ix.search(np.zeros((3, 32), np.float32), 0)
+    with pytest.raises(L.LdotError):
+        ix.search(np.zeros((3, 32), np.float32), L.MAX_K + 1)
+    with pytest.raises(ValueError):
+        ix.add(np.zeros((3, 31), np.float32))
+    with pytest.raises(L.LdotError):
+        FlatIPIndex(0)
+
+
+def test_incremental_add_and_ties(L):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((3000, 96)).astype(np.float32)
+    x[100] = x[50]
+    x[2999] = x[50]                      # exact ties -> lower label first
+    q = np.concatenate([x[50:51] * 2.0, rng.standard_normal((40, 96)).astype(np.float32)])
+    from lightningdot_amd.indexer import FlatIPIndex
+    ix = FlatIPIndex(96)
+    ix.set_option(L.OPT_MODE, L.MODE_DENSE)
+    for a, b in [(0, 1), (1, 700), (700, 701), (701, 3000)]:
+        ix.add(x[a:b])
+    s, l = ix.search(q, 20)
+    assert list(l[0, :3]) == [50, 100, 2999]
+    assert s[0, 0] == s[0, 1] == s[0, 2]
+    assert_topk_matches(q, x, s, l, 20)
+    np.testing.assert_array_equal(ix.get_rows(699, 3), x[699:702])
+
+
+def test_device_tensors_and_dtypes(L):
+    import torch
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((2000, 256)).astype(np.float32)
+    q = rng.standard_normal((65, 256)).astype(np.float32)
+    from lightningdot_amd.indexer import FlatIPIndex
+    ix = FlatIPIndex(256)
+    ix.add(torch.from_numpy(x).cuda())
+    s, l = ix.search_tensors(torch.from_numpy(q).cuda(), 30)
+    assert s.is_cuda and l.is_cuda and l.dtype == torch.int64
+    assert_topk_matches(q, x, s.cpu().numpy(), l.cpu().numpy(), 30)
+    # bf16 / fp16 inputs are widened exactly
+    xb = torch.from_numpy(x).cuda().bfloat16()
+    qb = torch.from_numpy(q).cuda().half()
+    ix2 = FlatIPIndex(256)
+    ix2.add(xb)
+    s2, l2 = ix2.search(qb, 30)
+    assert_topk_matches(qb.float().cpu().numpy(), xb.float().cpu().numpy(), s2, l2, 30)
+
+
+def test_normalize_option(L):
+    rng = np.random.default_rng(8)
+    x = (rng.standard_normal((1500, 768)) * rng.uniform(0.1, 5, (1500, 1))).astype(np.float32)
+    q = (rng.standard_normal((50, 768)) * 3).astype(np.float32)
+    ix = _index(x, normalize=True)
+    s, l = ix.search(q, 10)
+    xn = x / np.linalg.norm(x.astype(np.float64), axis=1, keepdims=True)
+    qn = q / np.linalg.norm(q.astype(np.float64), axis=1, keepdims=True)
+    assert_topk_matches(qn, xn, s, l, 10, atol=1e-5)
+    assert np.abs(s).max() <= 1.0 + 1e-5
+
+
+@pytest.mark.parametrize('nq,n,d,k', [(300, 20000, 768, 100), (1100, 70000, 128, 10), (257, 40000, 64, 1000)])
+def test_fused_matches_oracle(L, nq, n, d, k):
+    rng = np.random.default_rng(n + k)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    q, g = planted_queries(x, nq)
+    ix = _index(x, mode=L.MODE_FUSED, warm_rows=2048)
+    s, l = ix.search(q, k)
+    st = ix.last_stats()
+    assert st['fused_pairs'] > 0 and st['overflowed_queries'] == 0, st
+    assert (l[:, 0] == g).all()
+    assert_topk_matches(q, x, s, l, k)
+    # fused == dense, bit for bit (both end in the same fp32 re-score and ordering)
+    ixd = _index(x, mode=L.MODE_DENSE)
+    sd, ld = ixd.search(q, k)
+    np.testing.assert_array_equal(l, ld)
+    np.testing.assert_array_equal(s, sd)
+
+
+def test_fused_adversarial_order_falls_back(L):
+    """Rows sorted so that every later row beats all earlier ones for every query: the lane-private pools
+    overflow, the library detects it and redoes the search densely — results stay exact."""
+    rng = np.random.default_rng(11)
+    n, d, nq = 12000, 64, 256
+    base = rng.standard_normal(d).astype(np.float32)
+    base /= np.linalg.norm(base)
+    x = (rng.standard_normal((n, d)) * 0.01).astype(np.float32) + np.outer(np.linspace(0.0, 50.0, n), base).astype(np.float32)
+    q = (np.outer(np.ones(nq), base) + rng.standard_normal((nq, d)) * 0.01).astype(np.float32)
+    ix = _index(x, mode=L.MODE_FUSED, warm_rows=2048)
+    s, l = ix.search(q, 100)
+    st = ix.last_stats()
+    assert st['overflowed_queries'] > 0, st
+    assert_topk_matches(q, x, s, l, 100)
+
+
+def test_no_rescore_reports_bf16_input_scores(L):
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((4000, 768)).astype(np.float32)
+    q, g = planted_queries(x, 64)
+    ix = _index(x, rescore=0)
+    s, l = ix.search(q, 10)
+    assert (l[:, 0] == g).all()
+    full = q.astype(np.float64) @ x.astype(np.float64).T
+    err = np.abs(s - np.take_along_axis(full, l, axis=1))
+    assert err.max() < 1.0 and err.max() > 1e-4      # bf16-input error is visible, fp32 re-score removes it
+
+
+def test_g7_golden_indexer_wrapper(L, golden_dir):
+    from lightningdot_amd.indexer import DenseFlatIndexer
+    g = json.load(open(os.path.join(golden_dir, 'g7_indexer.json')))
+    a = np.load(os.path.join(golden_dir, 'g7_indexer_inputs.npz'))
+    data = list(zip(g['ids'], a['x']))
+    for k, res in g['results'].items():
+        ix = DenseFlatIndexer(a['x'].shape[1], buffer_size=20)
+        ix.index_data(data)
+        out = ix.search_knn(a['q'], int(k))
+        assert [r[0] for r in out] == res['ids']          # incl. the k > ntotal -> last-id behaviour
+        np.testing.assert_allclose(np.stack([r[1] for r in out]), np.asarray(res['scores'], np.float32),
+                                   rtol=0, atol=1e-4)
+        assert out[0][1].dtype == np.float32
+
+
+def test_serialize_roundtrip(L, tmp_path):
+    from lightningdot_amd.indexer import DenseFlatIndexer
+    rng = np.random.default_rng(13)
+    x = rng.standard_normal((777, 40)).astype(np.float32)
+    ix = DenseFlatIndexer(40)
+    ix.index_data([(f'k{i}', x[i]) for i in range(len(x))])
+    f = str(tmp_path / 'idx')
+    ix.serialize(f)
+    assert os.path.exists(f + '.index.dpr') and os.path.exists(f + '.index_meta.dpr')
+    ix2 = DenseFlatIndexer(40)
+    ix2.deserialize_from(f)
+    assert ix2.index.ntotal == 777 and ix2.index_id_to_db_id == ix.index_id_to_db_id
+    q = rng.standard_normal((9, 40)).astype(np.float32)
+    r1, r2 = ix.search_knn(q, 7), ix2.search_knn(q, 7)
+    assert [a[0] for a in r1] == [a[0] for a in r2]
+    np.testing.assert_array_equal(np.stack([a[1] for a in r1]), np.stack([a[1] for a in r2]))
+    ix2.index_id_to_db_id.pop()
+    with open(f + '.index_meta.dpr', 'wb') as fh:
+        import pickle
+        pickle.dump(ix2.index_id_to_db_id, fh)
+    with pytest.raises(AssertionError):
+        DenseFlatIndexer(40).deserialize_from(f)
+
+
+def test_merge_topk(L):
+    import ctypes
+    rng = np.random.default_rng(14)
+    x = rng.standard_normal((5000, 64)).astype(np.float32)
+    q = rng.standard_normal((70, 64)).astype(np.float32)
+    k = 40
+    parts_s, parts_l = [], []
+    bounds = [(0, 1500), (1500, 1530), (1530, 5000)]      # a shard smaller than k -> padded partial list
+    for a, b in bounds:
+        ix = _index(x[a:b])
+        s, l = ix.search(q, k)
+        parts_s.append(s)
+        parts_l.append(np.where(l >= 0, l + a, -1))
+    S = np.ascontiguousarray(np.stack(parts_s)).astype(np.float32)
+    Lb = np.ascontiguousarray(np.stack(parts_l)).astype(np.int64)
+    out_s = np.empty((70, k), np.float32)
+    out_l = np.empty((70, k), np.int64)
+    lib = L.load_library()
+    L.check(lib.ldot_merge_topk(S.ctypes.data, Lb.ctypes.data, 3, 70, k, k, out_s.ctypes.data, out_l.ctypes.data,
+                                L.HOST, None))
+    ms, ml = O.merge_topk(list(zip(parts_s, parts_l)), k)
+    np.testing.assert_array_equal(out_l, ml)
+    np.testing.assert_array_equal(out_s, ms)
+    whole_s, whole_l = _index(x).search(q, k)
+    np.testing.assert_array_equal(out_l, whole_l)
+    np.testing.assert_array_equal(out_s, whole_s)
+
+
+def test_cls_pool(L):
+    import ctypes
+    import torch
+    lib = L.load_library()
+    B, Ls, D = 9, 21, 768
+    seq = torch.randn(B, Ls, D, device='cuda')
+    for dt, code in [(torch.float32, L.F32), (torch.bfloat16, L.BF16), (torch.float16, L.F16)]:
+        s = seq.to(dt).contiguous()
+        o32 = torch.empty(B, D, device='cuda')
+        o16 = torch.empty(B, D, device='cuda', dtype=torch.bfloat16)
+        L.check(lib.ldot_cls_pool(s.data_ptr(), code, B, Ls * D, D, 0, o32.data_ptr(), o16.data_ptr(), None))
+        torch.cuda.synchronize()
+        ref = O.cls_pool(s.float().cpu().numpy())
+        np.testing.assert_array_equal(o32.cpu().numpy(), ref)
+        np.testing.assert_array_equal(o16.float().cpu().numpy(), torch.from_numpy(ref).bfloat16().float().numpy())
+        L.check(lib.ldot_cls_pool(s.data_ptr(), code, B, Ls * D, D, 1, o32.data_ptr(), None, None))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(o32.cpu().numpy(), O.cls_pool(s.float().cpu().numpy(), l2_normalize=True),
+                                   rtol=2e-7, atol=1e-8)
+
+
+def test_s1_reduced_planted(L):
+    """SURVEY §8d S1 at 1/5 scale: 200k x 768 index, 2048 planted queries, top-100, fused path."""
+    rng = np.random.default_rng(1234)
+    n, d, nq, k = 200_000, 768, 2048, 100
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    q, g = planted_queries(x, nq)
+    ix = _index(x)
+    s, l = ix.search(q, k)
+    st = ix.last_stats()
+    assert st['fused_pairs'] > 0 and st['overflowed_queries'] == 0, st
+    assert (l[:, 0] == g).all()                                   # Recall@1 == 1 on planted data
+    assert (np.diff(s.astype(np.float64), axis=1) <= 0).all()
+    sub = slice(0, 96)
+    assert_topk_matches(q[sub], x, s[sub], l[sub], k)
