@@ -33,7 +33,7 @@ def test_g1_loss_forward_backward(golden_dir):
         np.testing.assert_allclose(scores.detach().cpu().numpy(), g[p + 'scores'], rtol=1e-5, atol=2e-5)
         np.testing.assert_allclose(loss.detach().cpu().numpy(), g[p + 'loss'], rtol=2e-5, atol=2e-5)
         assert int(correct.item()) == int(g[p + 'correct']), (ci, c)
-        torch.autograd.backward([loss, scores], [_cuda(g[p + 'gl']), _cuda(g[p + 'gs'])])
+        torch.autograd.backward([loss, scores], [_cuda(g[p + 'gl']).reshape(loss.shape), _cuda(g[p + 'gs'])])
         np.testing.assert_allclose(q.grad.cpu().numpy(), g[p + 'dq'], rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(ctx.grad.cpu().numpy(), g[p + 'dctx'], rtol=1e-4, atol=1e-5)
         if (p + 'dcap') in g.files:
