@@ -88,7 +88,10 @@ __device__ inline void zero_acc(f32x16 (&acc)[4][2]) {
             for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.f;
 }
 
+// Ablation switches (debug builds of the filter kernel only; VAR = 0 is the product path):
+//   bit 1: no staging after the first slab      bit 2: no MFMA/ds_read work      bit 3: (reserved)
 // Full K loop for one 256x256 tile (non-persistent form).  A rows [m0,m0+256), B rows [n0,n0+256); K = nk*64.
+template <int VAR = 0>
 __device__ inline void gemm_tile(const TileCtx& c, const char* __restrict__ A, int64_t lda_b, int64_t m0,
                                  const char* __restrict__ B, int64_t ldb_b, int64_t n0, int nk, char* lds,
                                  f32x16 (&acc)[4][2]) {
@@ -99,12 +102,12 @@ __device__ inline void gemm_tile(const TileCtx& c, const char* __restrict__ A, i
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         char* st = lds + cur * kStageBytes;
-        if (kt + 1 < nk) {
+        if (kt + 1 < nk && !(VAR & 2)) {
             char* nx = lds + (cur ^ 1) * kStageBytes;
             stage_slab(c, A, lda_b, m0, (kt + 1) * 128, nx);
             stage_slab(c, B, ldb_b, n0, (kt + 1) * 128, nx + kTileBytes);
         }
-        compute_slab(c, st, st + kTileBytes, acc);
+        if (!(VAR & 4)) compute_slab(c, st, st + kTileBytes, acc);
         __syncthreads();
         cur ^= 1;
     }

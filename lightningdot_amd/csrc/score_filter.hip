@@ -16,6 +16,8 @@
 //   for each group of 8 query blocks: query block = g*8 + qsub.
 // At any time the 32 workgroups of an XCD work on 8 query panels x 4 adjacent row tiles, so the private L2
 // holds 8 Q panels (3 MiB) and streams each row panel once per query group.
+#include <stdlib.h>
+
 #include "gemm_tile.h"
 #include "kernels.h"
 
@@ -61,6 +63,7 @@ __device__ inline void filter_epilogue(const f32x16 (&acc)[4][2], const float (&
     }
 }
 
+template <int VAR>
 __global__ __launch_bounds__(kGemmThreads, 2) void score_filter_kernel(
     const char* __restrict__ X16, int64_t ldx_b, int64_t row0, int64_t nrows, const char* __restrict__ Q16,
     int64_t ldq_b, int nqb, int nk, const float* __restrict__ tau_g, float* __restrict__ pool_s,
@@ -89,9 +92,16 @@ __global__ __launch_bounds__(kGemmThreads, 2) void score_filter_kernel(
         }
         for (int t = slice; t < ntiles; t += kFusedSlices) {
             const int64_t trow = row0 + (int64_t)t * kBM;
-            gemm_tile(c, X16, ldx_b, trow, Q16, ldq_b, (int64_t)qb * kBN, nk, smem, acc);
+            gemm_tile<VAR>(c, X16, ldx_b, trow, Q16, ldq_b, (int64_t)qb * kBN, nk, smem, acc);
             const int32_t row_lane0 = (int32_t)trow + c.wm * 128 + 4 * (c.lane >> 5);
-            filter_epilogue(acc, tau, cur, pbase, pool_s, pool_i, row_lane0, row_end);
+            if (!(VAR & 1)) {
+                filter_epilogue(acc, tau, cur, pbase, pool_s, pool_i, row_lane0, row_end);
+            } else {   // ablation: keep the accumulators live without the filter
+#pragma unroll
+                for (int mr = 0; mr < 4; ++mr)
+#pragma unroll
+                    for (int nr = 0; nr < 2; ++nr) asm volatile("" ::"v"(acc[mr][nr]));
+            }
         }
 #pragma unroll
         for (int nr = 0; nr < 2; ++nr) pool_cnt[qidx[nr] * kPoolSubs + sub] = cur[nr];
@@ -102,15 +112,26 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
                         int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, float* pool_s,
                         int32_t* pool_i, int32_t* pool_cnt, hipStream_t st) {
     if (nrows <= 0 || nq_pad <= 0) return LDOT_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)score_filter_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLdsBytes));
-        attr_set = true;
+    // LDOT_DEBUG_VARIANT selects an ablation build of the kernel (profiling only; results are then meaningless)
+    static int variant = -1;
+    if (variant < 0) {
+        const char* e = getenv("LDOT_DEBUG_VARIANT");
+        variant = e ? atoi(e) : 0;
     }
-    hipLaunchKernelGGL(score_filter_kernel, dim3(256), dim3(kGemmThreads), kGemmLdsBytes, st, (const char*)x16,
-                       ldx_elems * 2, row0, nrows, (const char*)q16, ldq_elems * 2, (int)(nq_pad / kBN), dpad / kBK,
-                       tau, pool_s, pool_i, pool_cnt);
+    auto kern = score_filter_kernel<0>;
+    switch (variant) {
+        case 1: kern = score_filter_kernel<1>; break;
+        case 2: kern = score_filter_kernel<2>; break;
+        case 3: kern = score_filter_kernel<3>; break;
+        case 4: kern = score_filter_kernel<4>; break;
+        case 5: kern = score_filter_kernel<5>; break;
+        case 7: kern = score_filter_kernel<7>; break;
+        default: break;
+    }
+    LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLdsBytes));
+    hipLaunchKernelGGL(kern, dim3(256), dim3(kGemmThreads), kGemmLdsBytes, st, (const char*)x16, ldx_elems * 2, row0,
+                       nrows, (const char*)q16, ldq_elems * 2, (int)(nq_pad / kBN), dpad / kBK, tau, pool_s, pool_i,
+                       pool_cnt);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }
