@@ -288,8 +288,9 @@ static int dense_scan(ldot_index* ix, int64_t q0, int64_t nqb, int64_t nqb_pad, 
     for (int64_t r = r0; r < r1; r += chunk) {
         const int64_t nrows = std::min(chunk, r1 - r);
         const int64_t nrows_pad = round_up(nrows, kBN);
-        prof_begin(ix, st, 2.0 * nqb_pad * nrows_pad * ix->dpad,
-                   (double)nrows_pad * ix->dpad * 2 + (double)nqb_pad * ix->dpad * 2 + (double)nqb_pad * nrows_pad * 4);
+        // algorithmic work: the VALID queries x rows x d (tile padding is overhead, not work)
+        prof_begin(ix, st, 2.0 * nqb * nrows * ix->d,
+                   (double)nrows * ix->d * 2 + (double)nqb * ix->d * 2 + (double)nqb * nrows * 4);
         rc = launch_score_dense(q16, ix->dpad, nqb_pad, ix->x16, ix->dpad, r, nrows_pad, ix->dpad, (float*)ix->w_S.p,
                                 chunk, st);
         prof_end(ix, st);
@@ -341,8 +342,8 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
         len = std::max<int64_t>(len, kBM * kFusedSlices);
         len = round_up(len, kBM);
         len = std::min(len, ix->ntotal - r);
-        prof_begin(ix, st, 2.0 * nq_pad * len * ix->dpad,
-                   (double)len * ix->dpad * 2 + (double)nq_pad * ix->dpad * 2 + (double)nq_pad * kp * 8);
+        prof_begin(ix, st, 2.0 * nq * len * ix->d,
+                   (double)len * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * kp * 8);
         rc = launch_score_filter(ix->x16, ix->dpad, r, len, ix->w_q16.p, ix->dpad, nq_pad, ix->dpad, tau,
                                  (float*)ix->w_pool_s.p, (int32_t*)ix->w_pool_i.p, (int32_t*)ix->w_pool_cnt.p, st);
         prof_end(ix, st);

@@ -33,7 +33,7 @@ struct TileCtx {
     int st_col;        // per-lane source byte offset inside the 128-byte slab row
 };
 
-__device__ inline void tile_ctx_init(TileCtx& c) {
+__device__ __forceinline__ void tile_ctx_init(TileCtx& c) {
     c.lane = threadIdx.x & 63;
     c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     c.wm = c.wave >> 2;   // 0..1
@@ -51,7 +51,7 @@ __device__ inline void tile_ctx_init(TileCtx& c) {
 }
 
 // Issue the direct-to-LDS loads of one operand slab: rows [row0, row0+256) x k-bytes [k0b, k0b+128).
-__device__ inline void stage_slab(const TileCtx& c, const char* __restrict__ base, int64_t ld_bytes, int64_t row0,
+__device__ __forceinline__ void stage_slab(const TileCtx& c, const char* __restrict__ base, int64_t ld_bytes, int64_t row0,
                                   int k0b, char* lds_slab) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -61,7 +61,7 @@ __device__ inline void stage_slab(const TileCtx& c, const char* __restrict__ bas
 }
 
 // One 64-deep slab of MFMAs for this wave: acc[4][2] += A(128 x 64) . B(64 x 64)^T
-__device__ inline void compute_slab(const TileCtx& c, const char* a_slab, const char* b_slab, f32x16 (&acc)[4][2]) {
+__device__ __forceinline__ void compute_slab(const TileCtx& c, const char* a_slab, const char* b_slab, f32x16 (&acc)[4][2]) {
     const char* a_w = a_slab + c.wm * (128 * 128);
     const char* b_w = b_slab + c.wn * (64 * 128);
 #pragma unroll
@@ -79,7 +79,7 @@ __device__ inline void compute_slab(const TileCtx& c, const char* a_slab, const 
     }
 }
 
-__device__ inline void zero_acc(f32x16 (&acc)[4][2]) {
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[4][2]) {
 #pragma unroll
     for (int mr = 0; mr < 4; ++mr)
 #pragma unroll
@@ -92,7 +92,7 @@ __device__ inline void zero_acc(f32x16 (&acc)[4][2]) {
 //   bit 1: no staging after the first slab      bit 2: no MFMA/ds_read work      bit 3: (reserved)
 // Full K loop for one 256x256 tile (non-persistent form).  A rows [m0,m0+256), B rows [n0,n0+256); K = nk*64.
 template <int VAR = 0>
-__device__ inline void gemm_tile(const TileCtx& c, const char* __restrict__ A, int64_t lda_b, int64_t m0,
+__device__ __forceinline__ void gemm_tile(const TileCtx& c, const char* __restrict__ A, int64_t lda_b, int64_t m0,
                                  const char* __restrict__ B, int64_t ldb_b, int64_t n0, int nk, char* lds,
                                  f32x16 (&acc)[4][2]) {
     zero_acc(acc);
@@ -115,7 +115,7 @@ __device__ inline void gemm_tile(const TileCtx& c, const char* __restrict__ A, i
 
 // Bijective XCD-aware remap of a linear workgroup id (block b runs on XCD b % 8): gives each XCD a contiguous
 // range of logical ids so that neighbouring tiles share an L2.
-__device__ inline int xcd_remap(int bid, int nwg) {
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int nx = 8;
     const int q = nwg / nx, r = nwg % nx;
     const int xcd = bid % nx, loc = bid / nx;

@@ -16,8 +16,12 @@
 //   for each group of 8 query blocks: query block = g*8 + qsub.
 // At any time the 32 workgroups of an XCD work on 8 query panels x 4 adjacent row tiles, so the private L2
 // holds 8 Q panels (3 MiB) and streams each row panel once per query group.
+#include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
+#include "gemm_ring.h"
 #include "gemm_tile.h"
 #include "kernels.h"
 
@@ -26,19 +30,21 @@ namespace ldot {
 // Filter epilogue.  Fast path per 4 accumulator registers (256 scores): one max tree + one compare + one
 // (almost never taken) branch.  The slow path re-tests the four registers and appends the hits to the
 // lane-private sub-pool (cursor `cur`, clamped at kPoolCap; the true count is kept so overflow is detectable).
-__device__ inline void filter_append(float v, float tau, int32_t row, int32_t row_end, int& cur, uint32_t pbase,
+template <bool NOSTORE = false>
+__device__ __forceinline__ void filter_append(float v, float tau, int32_t row, int32_t row_end, int& cur, uint32_t pbase,
                                      float* __restrict__ pool_s, int32_t* __restrict__ pool_i) {
     if (v >= tau && row < row_end) {
         const int p = cur;
         cur = p + 1;
-        if (p < kPoolCap) {
+        if (p < kPoolCap && !NOSTORE) {
             pool_s[pbase + (uint32_t)p] = v;
             pool_i[pbase + (uint32_t)p] = row;
         }
     }
 }
 
-__device__ inline void filter_epilogue(const f32x16 (&acc)[4][2], const float (&tau)[2], int (&cur)[2],
+template <bool NOSTORE = false>
+__device__ __forceinline__ void filter_epilogue(const f32x16 (&acc)[4][2], const float (&tau)[2], int (&cur)[2],
                                        const uint32_t (&pbase)[2], float* __restrict__ pool_s,
                                        int32_t* __restrict__ pool_i, int32_t row_lane0, int32_t row_end) {
 #pragma unroll
@@ -53,10 +59,10 @@ __device__ inline void filter_epilogue(const f32x16 (&acc)[4][2], const float (&
                 if (m >= tau[nr]) {
                     // rows of register r = 4g + e:  (r & 3) + 8 * (r >> 2) = e + 8g
                     const int32_t rb = row_lane0 + mr * 32 + 8 * g;
-                    filter_append(a0, tau[nr], rb + 0, row_end, cur[nr], pbase[nr], pool_s, pool_i);
-                    filter_append(a1, tau[nr], rb + 1, row_end, cur[nr], pbase[nr], pool_s, pool_i);
-                    filter_append(a2, tau[nr], rb + 2, row_end, cur[nr], pbase[nr], pool_s, pool_i);
-                    filter_append(a3, tau[nr], rb + 3, row_end, cur[nr], pbase[nr], pool_s, pool_i);
+                    filter_append<NOSTORE>(a0, tau[nr], rb + 0, row_end, cur[nr], pbase[nr], pool_s, pool_i);
+                    filter_append<NOSTORE>(a1, tau[nr], rb + 1, row_end, cur[nr], pbase[nr], pool_s, pool_i);
+                    filter_append<NOSTORE>(a2, tau[nr], rb + 2, row_end, cur[nr], pbase[nr], pool_s, pool_i);
+                    filter_append<NOSTORE>(a3, tau[nr], rb + 3, row_end, cur[nr], pbase[nr], pool_s, pool_i);
                 }
             }
         }
@@ -108,15 +114,167 @@ __global__ __launch_bounds__(kGemmThreads, 2) void score_filter_kernel(
     }
 }
 
+// ---- second generation: continuous slab stream through the 4-stage LDS ring (gemm_ring.h) ---------------------
+// VAR bit 0: skip the filter epilogue, bit 3: count hits but do not store them, bit 4: tau = +inf  (ablations)
+template <int VAR>
+__global__ __launch_bounds__(kRingThreads, 2) void score_filter_ring_kernel(
+    const char* __restrict__ X16, int64_t ldx_b, int64_t row0, int64_t nrows, const char* __restrict__ Q16,
+    int64_t ldq_b, int nqb, int nk, const float* __restrict__ tau_g, float* __restrict__ pool_s,
+    int32_t* __restrict__ pool_i, int32_t* __restrict__ pool_cnt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    RingCtx c;
+    ring_ctx_init(c);
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int qsub = slot & 7, nsub = slot >> 3;
+    const int slice = xcd * 4 + nsub;
+    const int ntiles = (int)((nrows + kRBM - 1) / kRBM);
+    const int32_t row_end = (int32_t)(row0 + nrows);
+    const int sub = (slice * 2 + c.wm) * 2 + (c.lane >> 5);
+    const int nq_iter = (nqb > qsub) ? (nqb - qsub + 7) / 8 : 0;
+    const int nt_iter = (ntiles > slice) ? (ntiles - slice + kFusedSlices - 1) / kFusedSlices : 0;
+    const int ntile_total = nq_iter * nt_iter;
+    if (ntile_total == 0) return;
+    const int64_t S = (int64_t)ntile_total * nk;
+
+    // ---- load cursor: slab `issued` goes to ring stage issued % 4.  Past the last slab the cursor stops and the
+    // same slab is re-loaded into stages nobody reads again: the number of loads in flight stays uniform, so one
+    // counted wait serves every iteration.
+    RingSrc sa, sb;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        sa.voff[j] = c.st_row[j] * (int)ldx_b + c.st_col;
+        sb.voff[j] = c.st_row[j] * (int)ldq_b + c.st_col;
+    }
+    int l_q = 0, l_t = 0, l_k = 0;
+    sa.rsrc = ring_make_rsrc(X16 + (row0 + (int64_t)slice * kRBM) * ldx_b, ldx_b);
+    sb.rsrc = ring_make_rsrc(Q16 + (int64_t)qsub * kRBN * ldq_b, ldq_b);
+    int64_t issued = 0;
+    auto issue = [&]() {
+        char* st = smem + (int)(issued & 3) * kRStageBytes;
+        if (!(VAR & 2) || issued < 4) {
+            ring_stage_operand_buf<(VAR & 32) ? 2 : 0>(c, sa, l_k * (kRBK * 2), st);
+            ring_stage_operand_buf<(VAR & 64) ? 2 : 0>(c, sb, l_k * (kRBK * 2), st + kROpBytes);
+        }
+        ++issued;
+        if (issued < S) {
+            if (++l_k == nk) {
+                l_k = 0;
+                if (++l_t == nt_iter) {
+                    l_t = 0;
+                    ++l_q;
+                    sb.rsrc = ring_make_rsrc(Q16 + (int64_t)(qsub + l_q * 8) * kRBN * ldq_b, ldq_b);
+                }
+                sa.rsrc = ring_make_rsrc(X16 + (row0 + (int64_t)(slice + l_t * kFusedSlices) * kRBM) * ldx_b, ldx_b);
+            }
+        }
+    };
+    issue();
+    issue();
+    issue();
+    issue();
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- compute side --------------------------------------------------------------------------------------
+    float tau[2];
+    int cur[2] = {0, 0};
+    uint32_t pbase[2];
+    int64_t qidx[2];
+    f32x16 acc[4][2];
+    Frags F, G;
+    ring_read_frags(c, smem, 0, F);
+    G = F;
+    int64_t s = 0;
+
+    // one slab: G <- k-step 1 of slab s; MFMA(F = k-step 0); open slab s+1; F <- k-step 0 of slab s+1; MFMA(G)
+    auto slab = [&]() {
+        if (!(VAR & 4)) {
+            if (!(VAR & 256)) ring_read_frags(c, smem + (int)(s & 3) * kRStageBytes, 1, G);
+            ring_mfma(F, acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);                   // keep the 8 MFMAs ahead of the waits: they cover them
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of slab s are complete (WAR on its stage)
+        if (VAR & 2)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // slab s+1 has landed (this thread's part) ...
+        if (!(VAR & 128)) __builtin_amdgcn_s_barrier();      // ... and everybody else's
+        ++s;
+        if (!(VAR & 4)) {
+            if (!(VAR & 256)) ring_read_frags(c, smem + (int)(s & 3) * kRStageBytes, 0, F);
+            ring_mfma(G, acc);
+        }
+        // the loads go out AFTER the 8 MFMAs are queued: a wave that is back-pressured on VMEM issue (TA FIFO full)
+        // then still has matrix work in the pipe
+        __builtin_amdgcn_sched_barrier(0);
+        issue();                                             // slab s+3 (or a dummy) -> the stage slab s-1 vacated
+    };
+
+#pragma unroll 1
+    for (int c_q = 0; c_q < nq_iter; ++c_q) {
+#pragma unroll
+        for (int nr = 0; nr < 2; ++nr) {
+            qidx[nr] = (int64_t)(qsub + c_q * 8) * kRBN + c.wn * 64 + nr * 32 + (c.lane & 31);
+            tau[nr] = (VAR & 16) ? INFINITY : ring_launder(tau_g[qidx[nr]]);
+            pbase[nr] = (uint32_t)((qidx[nr] * kPoolSubs + sub) * kPoolCap);
+            cur[nr] = 0;
+        }
+#pragma unroll 1
+        for (int c_t = 0; c_t < nt_iter; ++c_t) {
+            ring_zero(acc);
+#pragma unroll 1
+            for (int kk = 0; kk < nk; ++kk) slab();
+            const int64_t trow = row0 + (int64_t)(slice + c_t * kFusedSlices) * kRBM;
+            const int32_t row_lane0 = (int32_t)trow + c.wm * 128 + 4 * (c.lane >> 5);
+            if (!(VAR & 1)) {
+                filter_epilogue<(VAR & 8) != 0>(acc, tau, cur, pbase, pool_s, pool_i, row_lane0, row_end);
+            } else {
+#pragma unroll
+                for (int mr = 0; mr < 4; ++mr)
+#pragma unroll
+                    for (int nr = 0; nr < 2; ++nr) asm volatile("" ::"v"(acc[mr][nr]));
+            }
+        }
+#pragma unroll
+        for (int nr = 0; nr < 2; ++nr) pool_cnt[qidx[nr] * kPoolSubs + sub] = cur[nr];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing dummy loads must land before the LDS is released
+}
+
 int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_t nrows, const void* q16,
                         int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, float* pool_s,
                         int32_t* pool_i, int32_t* pool_cnt, hipStream_t st) {
     if (nrows <= 0 || nq_pad <= 0) return LDOT_OK;
     // LDOT_DEBUG_VARIANT selects an ablation build of the kernel (profiling only; results are then meaningless)
-    static int variant = -1;
+    // LDOT_FILTER_IMPL: 2 (default) = ring kernel, 1 = first-generation two-stage kernel
+    static int variant = -1, impl = 2;
     if (variant < 0) {
         const char* e = getenv("LDOT_DEBUG_VARIANT");
         variant = e ? atoi(e) : 0;
+        const char* f = getenv("LDOT_FILTER_IMPL");
+        if (f) impl = atoi(f);
+    }
+    if (impl == 2) {
+        auto rk = score_filter_ring_kernel<0>;
+        if (variant == 1) rk = score_filter_ring_kernel<1>;
+        if (variant == 16) rk = score_filter_ring_kernel<16>;
+        if (variant == 8) rk = score_filter_ring_kernel<8>;
+        if (variant == 3) rk = score_filter_ring_kernel<3>;
+        if (variant == 5) rk = score_filter_ring_kernel<5>;
+        if (variant == 131) rk = score_filter_ring_kernel<131>;
+        if (variant == 387) rk = score_filter_ring_kernel<387>;
+        if (variant == 259) rk = score_filter_ring_kernel<259>;
+        if (variant == 135) rk = score_filter_ring_kernel<135>;
+        if (variant == 32) rk = score_filter_ring_kernel<32>;
+        if (variant == 96) rk = score_filter_ring_kernel<96>;
+        if (variant == 37) rk = score_filter_ring_kernel<37>;
+        if (variant == 101) rk = score_filter_ring_kernel<101>;
+        LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, kRingLdsBytes));
+        hipLaunchKernelGGL(rk, dim3(256), dim3(kRingThreads), kRingLdsBytes, st, (const char*)x16, ldx_elems * 2, row0,
+                           nrows, (const char*)q16, ldq_elems * 2, (int)(nq_pad / kRBN), dpad / kRBK, tau, pool_s,
+                           pool_i, pool_cnt);
+        LDOT_HIP_CHECK(hipGetLastError());
+        return LDOT_OK;
     }
     auto kern = score_filter_kernel<0>;
     switch (variant) {
