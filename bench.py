@@ -54,6 +54,8 @@ def main():
     ap.add_argument('--dim', type=int, default=768)
     ap.add_argument('--k', type=int, default=100)
     ap.add_argument('--mode', default='auto', choices=['auto', 'dense', 'fused'])
+    ap.add_argument('--growth', type=int, default=0, help='fused launch growth percent (0 = library default)')
+    ap.add_argument('--warm', type=int, default=0, help='dense warm-up rows (0 = library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-queries', type=int, default=256)
     args = ap.parse_args()
@@ -93,6 +95,10 @@ def main():
         ix = DenseFlatIndexer(D)
         ix.index.set_option(L.OPT_MODE, mode)
         ix.index.set_option(L.OPT_PROFILE, 1)
+        if args.growth:
+            ix.index.set_option(L.OPT_GROWTH_PCT, args.growth)
+        if args.warm:
+            ix.index.set_option(L.OPT_WARM_ROWS, args.warm)
         ix.index.add(x_local)
         flat = ix.index
         q_mine = q_all

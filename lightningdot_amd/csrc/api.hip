@@ -57,7 +57,7 @@ struct ldot_index {
     int64_t chunk_rows = 32768;
     int margin = -1;
     int profile = 0;
-    int64_t warm_rows = 8192;
+    int64_t warm_rows = 2048;
     int growth_pct = 100;
     struct ProfEv {
         hipEvent_t a, b;

@@ -19,7 +19,7 @@ __device__ inline uint64_t make_key(float s, uint32_t row) { return ((uint64_t)d
 __device__ inline void bitonic_sort_lds(uint64_t* keys, int P) {
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < (P >> 1); t += kSelThreads) {
+            for (int t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
                 const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 const int p = i | j;
                 const bool asc = ((i & k) == 0);
@@ -35,23 +35,33 @@ __device__ inline void bitonic_sort_lds(uint64_t* keys, int P) {
 }
 
 struct Selector {
-    uint64_t* keys;   // LDS [kSelCap]
+    uint64_t* keys;   // LDS [cap]
     int* count;       // LDS
     uint64_t tau;     // uniform
     int kp;
+    int cap;          // LDS buffer length (power of two, >= 2 * kp)
 
-    __device__ inline void init(uint64_t* k, int* c, int kp_) {
+    __device__ inline void init(uint64_t* k, int* c, int kp_, int cap_) {
         keys = k;
         count = c;
         kp = kp_;
+        cap = cap_;
         tau = kEmptyKey;
         if (threadIdx.x == 0) *count = 0;
         __syncthreads();
     }
-    __device__ inline void push(uint64_t key) {
-        if (key < tau) {
-            const int pos = atomicAdd(count, 1);
-            keys[pos] = key;
+    // Wave-aggregated append: must be called by ALL lanes of a wave together (valid = false for lanes without a
+    // candidate).  One LDS atomic per wave per call instead of one per hit.
+    __device__ inline void push(uint64_t key, bool valid) {
+        const bool hit = valid && key < tau;
+        const unsigned long long mask = __ballot(hit);
+        if (mask) {
+            const int lane = threadIdx.x & 63;
+            const int leader = __ffsll((long long)mask) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(count, __popcll(mask));
+            base = __shfl(base, leader);
+            if (hit) keys[base + __popcll(mask & ((1ull << lane) - 1ull))] = key;
         }
     }
     // sort, truncate to kp, refresh tau.  Must be called by all threads.
@@ -60,7 +70,7 @@ struct Selector {
         const int n = *count;
         int P = 2;
         while (P < n) P <<= 1;
-        for (int i = n + threadIdx.x; i < P; i += kSelThreads) keys[i] = kEmptyKey;
+        for (int i = n + threadIdx.x; i < P; i += blockDim.x) keys[i] = kEmptyKey;
         __syncthreads();
         bitonic_sort_lds(keys, P);
         const int m = n < kp ? n : kp;
@@ -70,23 +80,32 @@ struct Selector {
         tau = t;
         __syncthreads();
     }
-    // call before streaming up to kSelSeg more candidates
-    __device__ inline void reserve_segment() {
+    // call (all threads) before streaming up to `upcoming` more candidates (upcoming <= cap - kp)
+    __device__ inline void reserve(int upcoming) {
         __syncthreads();
         const int n = *count;
         __syncthreads();                              // everyone has read count before anyone pushes again
-        if (n + kSelSeg > kSelCap) compact();         // uniform branch
+        if (n + upcoming > cap) compact();            // uniform branch
     }
+    // The running list is kept sorted (best first, empty slots last): adopt it as keys[0..n) without sorting and
+    // take the threshold from its last element.
     __device__ inline void load_list(const float* ls, const int32_t* li) {
-        for (int e = threadIdx.x; e < kp; e += kSelThreads) {
-            const int32_t r = li[e];
-            if (r >= 0) push(make_key(ls[e], (uint32_t)r));
+        for (int e0 = 0; e0 < kp; e0 += blockDim.x) {
+            const int e = e0 + threadIdx.x;
+            const bool valid = e < kp && li[e] >= 0;
+            if (valid) keys[e] = make_key(ls[e], (uint32_t)li[e]);
+            const unsigned long long mask = __ballot(valid);
+            if ((threadIdx.x & 63) == 0 && mask) atomicAdd(count, __popcll(mask));
         }
+        __syncthreads();
+        const int n = *count;
+        tau = (n >= kp) ? keys[kp - 1] : kEmptyKey;
+        __syncthreads();
     }
     __device__ inline void finish(float* ls, int32_t* li, float* tau_out) {
         compact();
         const int n = *count;
-        for (int e = threadIdx.x; e < kp; e += kSelThreads) {
+        for (int e = threadIdx.x; e < kp; e += blockDim.x) {
             if (e < n) {
                 const uint64_t k = keys[e];
                 ls[e] = desc_key_to_float((uint32_t)(k >> 32));
@@ -109,74 +128,92 @@ __global__ __launch_bounds__(kSelThreads) void init_lists_kernel(float* ls, int3
     }
 }
 
-// dense source: one row of a materialised score chunk
+// LDS budget of a select launch: cap 64-bit keys (power of two, >= 2 * kp so a full list plus a segment fits)
+static inline int select_cap(int kp, int want) {
+    int c = want;
+    while (c < 2 * kp) c <<= 1;
+    return c;
+}
+
+// dense source: one row of a materialised score chunk (256 threads, 4096-key buffer)
 __global__ __launch_bounds__(kSelThreads) void select_dense_kernel(const float* __restrict__ S, int64_t lds_elems,
                                                                    int64_t ncols, int64_t idx_base,
                                                                    float* __restrict__ list_s,
-                                                                   int32_t* __restrict__ list_i, int kp,
+                                                                   int32_t* __restrict__ list_i, int kp, int cap,
                                                                    float* __restrict__ tau) {
-    __shared__ __attribute__((aligned(16))) uint64_t keys[kSelCap];
+    extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
     __shared__ int count;
     const int64_t q = blockIdx.x;
     Selector sel;
-    sel.init(keys, &count, kp);
+    sel.init(keys, &count, kp, cap);
     float* ls = list_s + q * kp;
     int32_t* li = list_i + q * kp;
     sel.load_list(ls, li);
-    sel.compact();
     const float* row = S + q * lds_elems;
-    for (int64_t c0 = 0; c0 < ncols; c0 += kSelSeg) {
-        sel.reserve_segment();
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int64_t c = c0 + h * (kSelSeg / 2) + threadIdx.x * 4;
-            if (c + 3 < ncols) {
-                const f32x4 v = *(const f32x4*)(row + c);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sel.push(make_key(v[e], (uint32_t)(idx_base + c + e)));
-            } else {
-                for (int e = 0; e < 4; ++e)
-                    if (c + e < ncols) sel.push(make_key(row[c + e], (uint32_t)(idx_base + c + e)));
-            }
+    // a segment = 1024 columns (4 per thread) <= cap - kp
+    for (int64_t c0 = 0; c0 < ncols; c0 += 4 * kSelThreads) {
+        sel.reserve(4 * kSelThreads);
+        const int64_t c = c0 + threadIdx.x * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c + 3 < ncols) {
+            v = *(const f32x4*)(row + c);
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (c + e < ncols) v[e] = row[c + e];
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sel.push(make_key(v[e], (uint32_t)(idx_base + c + e)), c + e < ncols);
     }
     sel.finish(ls, li, tau ? tau + q : nullptr);
 }
 
-// pool source: the per-query sub-pools filled by the fused filter kernel; resets the counters afterwards
-__global__ __launch_bounds__(kSelThreads) void select_pools_kernel(const float* __restrict__ pool_s,
-                                                                   const int32_t* __restrict__ pool_i,
-                                                                   int32_t* __restrict__ pool_cnt,
-                                                                   float* __restrict__ list_s,
-                                                                   int32_t* __restrict__ list_i, int kp,
-                                                                   float* __restrict__ tau,
-                                                                   int32_t* __restrict__ overflow) {
-    __shared__ __attribute__((aligned(16))) uint64_t keys[kSelCap];
+// pool source: the per-query sub-pools filled by the fused filter kernel; resets the counters afterwards.
+// One wave per query (no cross-wave barriers), small LDS footprint -> many queries resident per CU.
+constexpr int kPoolSelThreads = 64;
+__global__ __launch_bounds__(kPoolSelThreads) void select_pools_kernel(const float* __restrict__ pool_s,
+                                                                       const int32_t* __restrict__ pool_i,
+                                                                       int32_t* __restrict__ pool_cnt,
+                                                                       float* __restrict__ list_s,
+                                                                       int32_t* __restrict__ list_i, int kp, int cap,
+                                                                       float* __restrict__ tau,
+                                                                       int32_t* __restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
     __shared__ int count;
     __shared__ int cnts[kPoolSubs];
-    __shared__ int any_over;
     const int64_t q = blockIdx.x;
     Selector sel;
-    sel.init(keys, &count, kp);
-    if (threadIdx.x == 0) any_over = 0;
+    sel.init(keys, &count, kp, cap);
     float* ls = list_s + q * kp;
     int32_t* li = list_i + q * kp;
-    for (int s = threadIdx.x; s < kPoolSubs; s += kSelThreads) {
+    bool over = false;
+    for (int s = threadIdx.x; s < kPoolSubs; s += kPoolSelThreads) {
         const int c = pool_cnt[q * kPoolSubs + s];
-        cnts[s] = c;
+        cnts[s] = c < kPoolCap ? c : kPoolCap;
+        over |= c > kPoolCap;
         pool_cnt[q * kPoolSubs + s] = 0;
     }
-    __syncthreads();
-    for (int s = threadIdx.x; s < kPoolSubs; s += kSelThreads)
-        if (cnts[s] > kPoolCap) any_over = 1;
+    const bool any_over = __any(over);
     sel.load_list(ls, li);
-    sel.compact();
     const int64_t base = q * (int64_t)(kPoolSubs * kPoolCap);
-    for (int s0 = 0; s0 < kPoolSubs * kPoolCap; s0 += kSelSeg) {
-        sel.reserve_segment();
-        for (int sl = s0 + threadIdx.x; sl < s0 + kSelSeg; sl += kSelThreads) {
-            const int sub = sl / kPoolCap, e = sl % kPoolCap;
-            if (e < cnts[sub]) sel.push(make_key(pool_s[base + sl], (uint32_t)pool_i[base + sl]));
+    // each lane walks two sub-pools (kPoolSubs = 2 * 64); entries of a sub-pool are contiguous
+    for (int half = 0; half < kPoolSubs / kPoolSelThreads; ++half) {
+        const int sub = half * kPoolSelThreads + threadIdx.x;
+        const int n = cnts[sub];
+        int nmax = n;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+        for (int e0 = 0; e0 < nmax; e0 += 4) {
+            sel.reserve(4 * kPoolSelThreads);   // wave-uniform loop (nmax is wave-uniform); compacts only when needed
+            float vs[4];
+            int32_t vi[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = e0 + u < n;
+                vs[u] = ok ? pool_s[base + sub * kPoolCap + e0 + u] : 0.f;
+                vi[u] = ok ? pool_i[base + sub * kPoolCap + e0 + u] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sel.push(make_key(vs[u], (uint32_t)vi[u]), e0 + u < n);
         }
     }
     sel.finish(ls, li, tau ? tau + q : nullptr);
@@ -187,22 +224,27 @@ __global__ __launch_bounds__(kSelThreads) void select_pools_kernel(const float* 
 __global__ __launch_bounds__(kSelThreads) void select_lists_kernel(const float* __restrict__ cand_s,
                                                                    const int64_t* __restrict__ cand_l,
                                                                    int64_t part_stride, int nparts, int k_in,
-                                                                   int k_out, float* __restrict__ out_s,
+                                                                   int k_out, int cap, float* __restrict__ out_s,
                                                                    int64_t* __restrict__ out_l) {
-    __shared__ __attribute__((aligned(16))) uint64_t keys[kSelCap];
+    extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
     __shared__ int count;
     const int64_t q = blockIdx.x;
     Selector sel;
-    sel.init(keys, &count, k_out);
+    sel.init(keys, &count, k_out, cap);
     const int total = nparts * k_in;
-    for (int s0 = 0; s0 < total; s0 += kSelSeg) {
-        sel.reserve_segment();
-        for (int sl = s0 + threadIdx.x; sl < s0 + kSelSeg && sl < total; sl += kSelThreads) {
+    for (int s0 = 0; s0 < total; s0 += kSelThreads) {
+        sel.reserve(kSelThreads);
+        const int sl = s0 + threadIdx.x;
+        bool valid = sl < total;
+        uint64_t key = kEmptyKey;
+        if (valid) {
             const int p = sl / k_in, e = sl % k_in;
             const int64_t off = (int64_t)p * part_stride + q * k_in + e;
             const int64_t l = cand_l[off];
-            if (l >= 0) sel.push(make_key(cand_s[off], (uint32_t)l));
+            valid = l >= 0;
+            if (valid) key = make_key(cand_s[off], (uint32_t)l);
         }
+        sel.push(key, valid);
     }
     sel.compact();
     const int n = count;
@@ -228,8 +270,9 @@ int launch_init_lists(float* list_s, int32_t* list_i, int64_t n, hipStream_t st)
 int launch_select_dense(const float* S, int64_t lds_elems, int64_t nq, int64_t ncols, int64_t idx_base,
                         float* list_s, int32_t* list_i, int kp, float* tau, hipStream_t st) {
     if (nq <= 0) return LDOT_OK;
-    hipLaunchKernelGGL(select_dense_kernel, dim3((unsigned)nq), dim3(kSelThreads), 0, st, S, lds_elems, ncols,
-                       idx_base, list_s, list_i, kp, tau);
+    const int cap = select_cap(kp, 2048);   // 16 KiB of keys for kp <= 1024: segment of 1024 columns always fits
+    hipLaunchKernelGGL(select_dense_kernel, dim3((unsigned)nq), dim3(kSelThreads), (size_t)cap * 8, st, S, lds_elems,
+                       ncols, idx_base, list_s, list_i, kp, cap, tau);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }
@@ -238,8 +281,9 @@ int launch_select_pools(const float* pool_s, const int32_t* pool_i, const int32_
                         float* list_s, int32_t* list_i, int kp, float* tau, int32_t* overflow_flags,
                         hipStream_t st) {
     if (nq <= 0) return LDOT_OK;
-    hipLaunchKernelGGL(select_pools_kernel, dim3((unsigned)nq), dim3(kSelThreads), 0, st, pool_s, pool_i,
-                       (int32_t*)pool_cnt, list_s, list_i, kp, tau, overflow_flags);
+    const int cap = select_cap(kp, 1024);
+    hipLaunchKernelGGL(select_pools_kernel, dim3((unsigned)nq), dim3(kPoolSelThreads), (size_t)cap * 8, st, pool_s,
+                       pool_i, (int32_t*)pool_cnt, list_s, list_i, kp, cap, tau, overflow_flags);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }
@@ -247,8 +291,9 @@ int launch_select_pools(const float* pool_s, const int32_t* pool_i, const int32_
 int launch_select_lists(const float* cand_s, const int64_t* cand_l, int64_t part_stride, int nparts, int k_in,
                         int64_t nq, int k_out, float* out_s, int64_t* out_l, hipStream_t st) {
     if (nq <= 0) return LDOT_OK;
-    hipLaunchKernelGGL(select_lists_kernel, dim3((unsigned)nq), dim3(kSelThreads), 0, st, cand_s, cand_l,
-                       part_stride, nparts, k_in, k_out, out_s, out_l);
+    const int cap = select_cap(k_out, 1024);
+    hipLaunchKernelGGL(select_lists_kernel, dim3((unsigned)nq), dim3(kSelThreads), (size_t)cap * 8, st, cand_s, cand_l,
+                       part_stride, nparts, k_in, k_out, cap, out_s, out_l);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }
