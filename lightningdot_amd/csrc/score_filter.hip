@@ -152,8 +152,10 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_ring_kernel(
     auto issue = [&]() {
         char* st = smem + (int)(issued & 3) * kRStageBytes;
         if (!(VAR & 2) || issued < 4) {
-            ring_stage_operand_buf<(VAR & 32) ? 2 : 0>(c, sa, l_k * (kRBK * 2), st);
-            ring_stage_operand_buf<(VAR & 64) ? 2 : 0>(c, sb, l_k * (kRBK * 2), st + kROpBytes);
+            constexpr int kAuxX = ((VAR & 32) ? 2 : 0) | ((VAR & 512) ? 16 : 0) | ((VAR & 1024) ? 1 : 0);
+            constexpr int kAuxQ = ((VAR & 64) ? 2 : 0) | ((VAR & 512) ? 16 : 0) | ((VAR & 1024) ? 1 : 0);
+            ring_stage_operand_buf<kAuxX>(c, sa, l_k * (kRBK * 2), st);
+            ring_stage_operand_buf<kAuxQ>(c, sb, l_k * (kRBK * 2), st + kROpBytes);
         }
         ++issued;
         if (issued < S) {
@@ -262,6 +264,11 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
         if (variant == 3) rk = score_filter_ring_kernel<3>;
         if (variant == 5) rk = score_filter_ring_kernel<5>;
         if (variant == 131) rk = score_filter_ring_kernel<131>;
+        if (variant == 512) rk = score_filter_ring_kernel<512>;
+        if (variant == 1024) rk = score_filter_ring_kernel<1024>;
+        if (variant == 1536) rk = score_filter_ring_kernel<1536>;
+        if (variant == 517) rk = score_filter_ring_kernel<517>;
+        if (variant == 1029) rk = score_filter_ring_kernel<1029>;
         if (variant == 387) rk = score_filter_ring_kernel<387>;
         if (variant == 259) rk = score_filter_ring_kernel<259>;
         if (variant == 135) rk = score_filter_ring_kernel<135>;

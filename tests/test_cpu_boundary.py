@@ -79,3 +79,33 @@ def test_hard_negative_postprocess_matches_golden(golden_dir):
                                                 g['img2txt'], g['txt2img'], g['nh'], sample=fake_sample)
     assert hn_txt == g['out_txt'] and hn_img == g['out_img']
     assert dict(zip(g['hard_neg_txt'].keys(), pops[:len(g['hard_neg_txt'])])) == g['pops_txt_sorted']
+
+
+def test_config_surface_matches_reference_golden(golden_dir, tmp_path):
+    """G6: parse_with_config on the reference's flickr30k eval config -> same namespace as the reference."""
+    import json
+    import sys
+    from lightningdot_amd import options
+    g = json.load(open(os.path.join(golden_dir, 'g6_config.json')))
+    cfg = {k: v for k, v in g['plain'].items()}      # reconstruct the JSON the reference parsed
+    ref_json = {k: cfg[k] for k in ['txt_model_config', 'img_model_config', 'itm_global_file', 'seed', 'output_dir',
+                                    'max_txt_len', 'conf_th', 'max_bb', 'min_bb', 'num_bb', 'project_dim', 'val_txt_db',
+                                    'val_img_db', 'test_txt_db', 'test_img_db', 'project_name', 'n_workers', 'fp16']}
+    path = tmp_path / 'flickr30k_eval_config.json'
+    path.write_text(json.dumps(ref_json))
+    saved = sys.argv
+    try:
+        sys.argv = ['eval_itm.py', '--config', str(path)]
+        got = vars(options.parse_with_config(options.build_parser(), ['--config', str(path)]))
+        got['config'] = g['plain']['config']
+        assert got == g['plain']
+        sys.argv = ['eval_itm.py', '--config', str(path), '--max_txt_len', '32', '--project_dim=256']
+        got = vars(options.parse_with_config(options.build_parser()))
+        got['config'] = g['override']['config']
+        assert got == g['override']
+        # documented fix: overrides given through `cmds` are honoured too (the reference ignores them, 'cmds_only')
+        sys.argv = ['eval_itm.py']
+        got = vars(options.parse_with_config(options.build_parser(), ['--config', str(path), '--max_txt_len', '32']))
+        assert got['max_txt_len'] == 32 and g['cmds_only']['max_txt_len'] == 60
+    finally:
+        sys.argv = saved
