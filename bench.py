@@ -195,6 +195,25 @@ def main():
                      'kernel_ms_per_step': prof['kernel_ms'] / max(args.steps, 1),
                      'flops_per_step': prof['flops'] / max(args.steps, 1)},
     }
+    # measured-offline HBM traffic of the dominant kernel (rocprofv3 PMC passes, tools/pmc.sh; see profiles/)
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if os.path.exists(tpath) and world == 1 and N == 1_000_000 and Q == 10_000 and D == 768:
+        try:
+            t = json.load(open(tpath))
+            out['roofline']['traffic'] = t['hbm_bytes_per_launch']
+            out['roofline']['traffic_note'] = t['note']
+        except Exception:
+            pass
+    if world == 1:
+        # PCIe-inclusive variant: fp32 queries start on the HOST (numpy in / numpy out, the reference's calling
+        # convention) — reported beside `value`, never as `value`
+        q_host = q_all.cpu().numpy()
+        flat.search(q_host, K)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            flat.search(q_host, K)
+        out['pcie_inclusive'] = {'value': Q * 2 / (time.perf_counter() - t0), 'unit': 'queries/s',
+                                 'note': 'fp32 queries in pageable host memory -> scores+labels in host memory'}
     if not args.no_cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(x_local, q_all, K, args.cpu_sample_queries)
     print(json.dumps(out), flush=True)
