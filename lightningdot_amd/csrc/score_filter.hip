@@ -170,11 +170,16 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_ring_kernel(
             }
         }
     };
+    constexpr bool kEarly = (VAR & 2048) != 0;     // experiment: issue the loads BEFORE the slab-closing waits
+    constexpr bool kPrio = (VAR & 4096) != 0;      // experiment: raise wave priority around the MFMA groups
     issue();
     issue();
     issue();
-    issue();
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    if (!kEarly) issue();
+    if (kEarly)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     // ---- compute side --------------------------------------------------------------------------------------
@@ -192,9 +197,12 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_ring_kernel(
     auto slab = [&]() {
         if (!(VAR & 4)) {
             if (!(VAR & 256)) ring_read_frags(c, smem + (int)(s & 3) * kRStageBytes, 1, G);
+            if (kPrio) __builtin_amdgcn_s_setprio(1);
             ring_mfma(F, acc);
+            if (kPrio) __builtin_amdgcn_s_setprio(0);
         }
         __builtin_amdgcn_sched_barrier(0);                   // keep the 8 MFMAs ahead of the waits: they cover them
+        if (kEarly) issue();                                 // slab s+3 -> the stage slab s-1 vacated (barrier B_s passed)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of slab s are complete (WAR on its stage)
         if (VAR & 2)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -204,12 +212,14 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_ring_kernel(
         ++s;
         if (!(VAR & 4)) {
             if (!(VAR & 256)) ring_read_frags(c, smem + (int)(s & 3) * kRStageBytes, 0, F);
+            if (kPrio) __builtin_amdgcn_s_setprio(1);
             ring_mfma(G, acc);
+            if (kPrio) __builtin_amdgcn_s_setprio(0);
         }
         // the loads go out AFTER the 8 MFMAs are queued: a wave that is back-pressured on VMEM issue (TA FIFO full)
         // then still has matrix work in the pipe
         __builtin_amdgcn_sched_barrier(0);
-        issue();                                             // slab s+3 (or a dummy) -> the stage slab s-1 vacated
+        if (!kEarly) issue();                                // slab s+3 (or a dummy) -> the stage slab s-1 vacated
     };
 
 #pragma unroll 1
@@ -264,6 +274,13 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
         if (variant == 3) rk = score_filter_ring_kernel<3>;
         if (variant == 5) rk = score_filter_ring_kernel<5>;
         if (variant == 131) rk = score_filter_ring_kernel<131>;
+        if (variant == 257) rk = score_filter_ring_kernel<257>;
+        if (variant == 261) rk = score_filter_ring_kernel<261>;
+        if (variant == 2048) rk = score_filter_ring_kernel<2048>;
+        if (variant == 4096) rk = score_filter_ring_kernel<4096>;
+        if (variant == 6144) rk = score_filter_ring_kernel<6144>;
+        if (variant == 2049) rk = score_filter_ring_kernel<2049>;
+        if (variant == 4097) rk = score_filter_ring_kernel<4097>;
         if (variant == 512) rk = score_filter_ring_kernel<512>;
         if (variant == 1024) rk = score_filter_ring_kernel<1024>;
         if (variant == 1536) rk = score_filter_ring_kernel<1536>;
