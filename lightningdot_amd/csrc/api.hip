@@ -72,7 +72,8 @@ struct ldot_index {
 
 static int index_reserve(ldot_index* ix, int64_t rows, hipStream_t st) {
     // capacity is a multiple of 256 rows (the MFMA tile) and rows beyond ntotal are kept zero
-    int64_t need = round_up(rows > 0 ? rows : 1, 256);
+    // (+512 zero rows of slack: the fused kernel's 384-row tiles may read past the last 256-row boundary)
+    int64_t need = round_up(rows > 0 ? rows : 1, 256) + 512;
     if (need <= ix->cap_rows) return LDOT_OK;
     int64_t cap = std::max<int64_t>(need, ix->cap_rows + ix->cap_rows / 2);
     cap = round_up(cap, 256);
@@ -324,8 +325,9 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
     // spread over kPoolSubs lane-private sub-pools of kPoolCap entries.  Keeping the expectation <= 1024 per query
     // (8 per sub-pool, overflow probability ~1e-11 each) bounds len <= r*1024/kp; the smallest launch is one tile
     // per row slice, hence the warm-up covers at least 8*kp rows.
+    const int64_t bm = fused_tile_rows();
     const int64_t warm =
-        std::min(ix->ntotal, std::max<int64_t>(ix->warm_rows, round_up((int64_t)8 * kp, 256)));
+        std::min(ix->ntotal, std::max<int64_t>(ix->warm_rows, round_up(bm * kFusedSlices * (int64_t)kp / 1024, 256)));
     if ((rc = dense_scan_all(ix, nq, 0, warm, kp, tau, st))) return rc;
     if (warm >= ix->ntotal) return LDOT_OK;
     if ((rc = ix->w_pool_s.ensure((size_t)nq_pad * kPoolSubs * kPoolCap * 4))) return rc;
@@ -339,8 +341,8 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
     int64_t r = warm;
     while (r < ix->ntotal) {
         int64_t len = std::min<int64_t>(r * ix->growth_pct / 100, r * 1024 / kp);
-        len = std::max<int64_t>(len, kBM * kFusedSlices);
-        len = round_up(len, kBM);
+        len = std::max<int64_t>(len, bm * kFusedSlices);
+        len = round_up(len, bm);
         len = std::min(len, ix->ntotal - r);
         prof_begin(ix, st, 2.0 * nq * len * ix->d,
                    (double)len * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * kp * 8);

@@ -50,6 +50,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ring_make_rsrc(const char* pan
     return __builtin_amdgcn_make_buffer_rsrc((void*)panel_base, 0, (int)(kRBM * ld_bytes), 0x00020000);
 }
 
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ring_make_rsrc_n(const char* panel_base, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)panel_base, 0, (int)bytes, 0x00020000);
+}
+
 template <int AUX = 0>
 __device__ __forceinline__ void ring_stage_operand_buf(const RingCtx& c, const RingSrc& src, int k0b, char* lds_slab) {
 #pragma unroll
@@ -138,5 +142,53 @@ __device__ __forceinline__ void ring_wait_loads(int slabs_in_flight) {
     else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+
+
+// ---- third generation: (64*MR) x 256 tile, A fragments recycled in place -------------------------------------------
+// Wave tile (32*MR) x 64.  Per k-step the wave needs MR A fragments + 2 B fragments; only the B pair is double-buffered,
+// every A fragment register is reloaded with the NEXT k-step's data right after the two MFMAs that consume it were
+// issued (it then has (MR-1)*2 MFMA times to land).  MR = 6: 192 accumulator + 24 + 16 fragment VGPRs.
+template <int MR>
+struct RingGeom {
+    static constexpr int kBM = 64 * MR;                        // index rows per tile
+    static constexpr int kAOpBytes = kBM * kRBK * 2;           // A slab bytes
+    static constexpr int kStage = kAOpBytes + kROpBytes;       // + B slab (256 queries)
+    static constexpr int kLds = kRingStages * kStage;
+    static constexpr int kALoads = kAOpBytes / 1024 / 8;       // direct-to-LDS loads per thread per slab (A)
+    static constexpr int kLoads = kALoads + 2;
+};
+
+template <int MR>
+struct FragsR {
+    bf16x8_t a[MR];
+    bf16x8_t b[2][2];
+};
+
+template <int MR>
+__device__ __forceinline__ void ringr_read_b(const RingCtx& c, const char* stage, int ks, bf16x8_t (&b)[2]) {
+    const char* b_w = stage + RingGeom<MR>::kAOpBytes + c.wn * (64 * 64) + c.frag_off[ks];
+#pragma unroll
+    for (int nr = 0; nr < 2; ++nr) b[nr] = *(const bf16x8_t*)(b_w + nr * 2048);
+}
+
+// one k-step: MFMAs on (a[*], bcur) while a[*] is reloaded from (nstage, nks) and bnext is fetched
+template <int MR>
+__device__ __forceinline__ void ringr_step(const RingCtx& c, FragsR<MR>& f, const int cur, const char* nstage,
+                                           const int nks, f32x16 (&acc)[MR][2]) {
+    ringr_read_b<MR>(c, nstage, nks, f.b[cur ^ 1]);
+    const char* a_w = nstage + c.wm * (32 * MR * 64) + c.frag_off[nks];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+        acc[mr][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mr], f.b[cur][0], acc[mr][0], 0, 0, 0);
+        acc[mr][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mr], f.b[cur][1], acc[mr][1], 0, 0, 0);
+        f.a[mr] = *(const bf16x8_t*)(a_w + mr * 2048);
+    }
+}
+
+template <int MR>
+struct RingSrcR {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff[RingGeom<MR>::kALoads > 2 ? RingGeom<MR>::kALoads : 2];
+};
 
 }  // namespace ldot

@@ -39,6 +39,8 @@ int launch_rescore(const float* q32, int64_t ldq, const float* x32, int64_t ldx,
                    const float* list_s, const int32_t* list_i, int kp, int k, int do_rescore, float* out_s,
                    int64_t* out_l, hipStream_t st);
 
+int fused_tile_rows();
+
 // fused MFMA score + threshold filter over index rows [row0, row0 + nrows) (nrows_pad multiple of 256)
 int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_t nrows, const void* q16,
                         int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, float* pool_s,

@@ -253,18 +253,200 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_ring_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing dummy loads must land before the LDS is released
 }
 
+// ---- third generation: (64*MR) x 256 tile on the ring, A fragments recycled in place (gemm_ring.h) -------------
+template <int MR, bool NOSTORE>
+__device__ __forceinline__ void filter_epilogue_r(const f32x16 (&acc)[MR][2], const float (&tau)[2], int (&cur)[2],
+                                                  const uint32_t (&pbase)[2], float* __restrict__ pool_s,
+                                                  int32_t* __restrict__ pool_i, int32_t row_lane0, int32_t row_end) {
+#pragma unroll
+    for (int nr = 0; nr < 2; ++nr) {
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float a0 = acc[mr][nr][4 * g + 0], a1 = acc[mr][nr][4 * g + 1];
+                const float a2 = acc[mr][nr][4 * g + 2], a3 = acc[mr][nr][4 * g + 3];
+                const float m = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+                if (m >= tau[nr]) {
+                    const int32_t rb = row_lane0 + mr * 32 + 8 * g;
+                    filter_append<NOSTORE>(a0, tau[nr], rb + 0, row_end, cur[nr], pbase[nr], pool_s, pool_i);
+                    filter_append<NOSTORE>(a1, tau[nr], rb + 1, row_end, cur[nr], pbase[nr], pool_s, pool_i);
+                    filter_append<NOSTORE>(a2, tau[nr], rb + 2, row_end, cur[nr], pbase[nr], pool_s, pool_i);
+                    filter_append<NOSTORE>(a3, tau[nr], rb + 3, row_end, cur[nr], pbase[nr], pool_s, pool_i);
+                }
+            }
+        }
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int VAR>
+__global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
+    const char* __restrict__ X16, int64_t ldx_b, int64_t row0, int64_t nrows, const char* __restrict__ Q16,
+    int64_t ldq_b, int nqb, int nk, const float* __restrict__ tau_g, float* __restrict__ pool_s,
+    int32_t* __restrict__ pool_i, int32_t* __restrict__ pool_cnt) {
+    constexpr int MR = 6;
+    using Geo = RingGeom<MR>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    RingCtx c;
+    ring_ctx_init(c);
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int qsub = slot & 7, nsub = slot >> 3;
+    const int slice = xcd * 4 + nsub;
+    const int ntiles = (int)((nrows + Geo::kBM - 1) / Geo::kBM);
+    const int32_t row_end = (int32_t)(row0 + nrows);
+    const int sub = (slice * 2 + c.wm) * 2 + (c.lane >> 5);
+    const int nq_iter = (nqb > qsub) ? (nqb - qsub + 7) / 8 : 0;
+    const int nt_iter = (ntiles > slice) ? (ntiles - slice + kFusedSlices - 1) / kFusedSlices : 0;
+    const int ntile_total = nq_iter * nt_iter;
+    if (ntile_total == 0) return;
+    const int64_t S = (int64_t)ntile_total * nk;
+
+    // ---- load cursor (see the second-generation kernel) ---------------------------------------------------------
+    int va[Geo::kALoads], vb[2];
+#pragma unroll
+    for (int j = 0; j < Geo::kALoads; ++j) va[j] = ((j * 8 + c.wave) * 16 + (c.lane >> 2)) * (int)ldx_b + c.st_col;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) vb[j] = c.st_row[j] * (int)ldq_b + c.st_col;
+    int l_q = 0, l_t = 0, l_k = 0;
+    RingSrc sa, sb;   // (voff members unused here)
+    sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)slice * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
+    sb.rsrc = ring_make_rsrc_n(Q16 + (int64_t)qsub * kRBN * ldq_b, kRBN * ldq_b);
+    int64_t issued = 0;
+    auto issue = [&]() {
+        char* st = smem + (int)(issued & 3) * Geo::kStage;
+        const int k0b = l_k * (kRBK * 2);
+#pragma unroll
+        for (int j = 0; j < Geo::kALoads; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(sa.rsrc, (rg_lptr_t)(st + (j * 8 + c.wave) * 1024), 16, va[j], k0b, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(sb.rsrc, (rg_lptr_t)(st + Geo::kAOpBytes + (j * 8 + c.wave) * 1024),
+                                                     16, vb[j], k0b, 0, 0);
+        ++issued;
+        if (issued < S) {
+            if (++l_k == nk) {
+                l_k = 0;
+                if (++l_t == nt_iter) {
+                    l_t = 0;
+                    ++l_q;
+                    sb.rsrc = ring_make_rsrc_n(Q16 + (int64_t)(qsub + l_q * 8) * kRBN * ldq_b, kRBN * ldq_b);
+                }
+                sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)(slice + l_t * kFusedSlices) * Geo::kBM) * ldx_b,
+                                           Geo::kBM * ldx_b);
+            }
+        }
+    };
+    issue();
+    issue();
+    issue();
+    issue();
+    wait_vmcnt<3 * Geo::kLoads>();
+    __builtin_amdgcn_s_barrier();
+
+    // ---- compute side --------------------------------------------------------------------------------------
+    float tau[2];
+    int cur[2] = {0, 0};
+    uint32_t pbase[2];
+    int64_t qidx[2];
+    f32x16 acc[MR][2];
+    FragsR<MR> f;
+    {
+        const char* a_w = smem + c.wm * (32 * MR * 64) + c.frag_off[0];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) f.a[mr] = *(const bf16x8_t*)(a_w + mr * 2048);
+        ringr_read_b<MR>(c, smem, 0, f.b[0]);
+        f.b[1][0] = f.b[0][0];
+        f.b[1][1] = f.b[0][1];
+    }
+    int64_t s = 0;
+    auto slab = [&]() {
+        // k-step 0 of slab s (operands: a, b[0]); a <- k-step 1 of slab s, b[1] <- k-step 1 of slab s
+        ringr_step<MR>(c, f, 0, smem + (int)(s & 3) * Geo::kStage, 1, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of slab s are complete (WAR on its stage)
+        wait_vmcnt<2 * Geo::kLoads>();                       // slab s+1 has landed (this thread's part) ...
+        __builtin_amdgcn_s_barrier();                        // ... and everybody else's
+        ++s;
+        // k-step 1 of the old slab (operands: a, b[1]); a, b[0] <- k-step 0 of slab s (just opened)
+        ringr_step<MR>(c, f, 1, smem + (int)(s & 3) * Geo::kStage, 0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        issue();                                             // slab s+3 (or a dummy) -> the stage slab s-1 vacated
+    };
+
+#pragma unroll 1
+    for (int c_q = 0; c_q < nq_iter; ++c_q) {
+#pragma unroll
+        for (int nr = 0; nr < 2; ++nr) {
+            qidx[nr] = (int64_t)(qsub + c_q * 8) * kRBN + c.wn * 64 + nr * 32 + (c.lane & 31);
+            tau[nr] = (VAR & 16) ? INFINITY : ring_launder(tau_g[qidx[nr]]);
+            pbase[nr] = (uint32_t)((qidx[nr] * kPoolSubs + sub) * kPoolCap);
+            cur[nr] = 0;
+        }
+#pragma unroll 1
+        for (int c_t = 0; c_t < nt_iter; ++c_t) {
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < 2; ++nr)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.f;
+#pragma unroll 1
+            for (int kk = 0; kk < nk; ++kk) slab();
+            const int64_t trow = row0 + (int64_t)(slice + c_t * kFusedSlices) * Geo::kBM;
+            const int32_t row_lane0 = (int32_t)trow + c.wm * (32 * MR) + 4 * (c.lane >> 5);
+            if (!(VAR & 1)) {
+                filter_epilogue_r<MR, (VAR & 8) != 0>(acc, tau, cur, pbase, pool_s, pool_i, row_lane0, row_end);
+            } else {
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int nr = 0; nr < 2; ++nr) asm volatile("" ::"v"(acc[mr][nr]));
+            }
+        }
+#pragma unroll
+        for (int nr = 0; nr < 2; ++nr) pool_cnt[qidx[nr] * kPoolSubs + sub] = cur[nr];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing dummy loads must land before the LDS is released
+}
+
+static int g_filter_impl = -1;
+static int filter_impl() {
+    if (g_filter_impl < 0) {
+        const char* f = getenv("LDOT_FILTER_IMPL");
+        g_filter_impl = f ? atoi(f) : 3;
+    }
+    return g_filter_impl;
+}
+// index rows per fused tile (the host sizes launches and the row padding of the index with it)
+int fused_tile_rows() { return filter_impl() == 3 ? RingGeom<6>::kBM : kRBM; }
+
 int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_t nrows, const void* q16,
                         int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, float* pool_s,
                         int32_t* pool_i, int32_t* pool_cnt, hipStream_t st) {
     if (nrows <= 0 || nq_pad <= 0) return LDOT_OK;
     // LDOT_DEBUG_VARIANT selects an ablation build of the kernel (profiling only; results are then meaningless)
-    // LDOT_FILTER_IMPL: 2 (default) = ring kernel, 1 = first-generation two-stage kernel
-    static int variant = -1, impl = 2;
+    // LDOT_FILTER_IMPL: 3 (default) = 384x256 ring kernel, 2 = 256x256 ring kernel, 1 = first-generation two-stage kernel
+    static int variant = -1;
+    const int impl = filter_impl();
     if (variant < 0) {
         const char* e = getenv("LDOT_DEBUG_VARIANT");
         variant = e ? atoi(e) : 0;
-        const char* f = getenv("LDOT_FILTER_IMPL");
-        if (f) impl = atoi(f);
+    }
+    if (impl == 3) {
+        auto rk = score_filter_r6_kernel<0>;
+        if (variant == 16) rk = score_filter_r6_kernel<16>;
+        LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           RingGeom<6>::kLds));
+        hipLaunchKernelGGL(rk, dim3(256), dim3(kRingThreads), RingGeom<6>::kLds, st, (const char*)x16, ldx_elems * 2,
+                           row0, nrows, (const char*)q16, ldq_elems * 2, (int)(nq_pad / kRBN), dpad / kRBK, tau, pool_s,
+                           pool_i, pool_cnt);
+        LDOT_HIP_CHECK(hipGetLastError());
+        return LDOT_OK;
     }
     if (impl == 2) {
         auto rk = score_filter_ring_kernel<0>;
