@@ -67,6 +67,7 @@ struct ldot_index {
     double prof[4] = {0, 0, 0, 0};
     // workspaces
     DevBuf w_stage, w_q32, w_q16, w_ls, w_li, w_S, w_outs, w_outl, w_tau, w_pool_s, w_pool_i, w_pool_cnt, w_over;
+    DevBuf w_part_s, w_part_l, w_mrg_s, w_mrg_l;
     int64_t stats[4] = {0, 0, 0, 0};
 };
 
@@ -139,7 +140,8 @@ int ldot_index_destroy(ldot_index_t* ix) {
     if (ix->x32) (void)hipFree(ix->x32);
     if (ix->x16) (void)hipFree(ix->x16);
     DevBuf* bufs[] = {&ix->w_stage, &ix->w_q32, &ix->w_q16, &ix->w_ls, &ix->w_li, &ix->w_S, &ix->w_outs,
-                      &ix->w_outl, &ix->w_tau, &ix->w_pool_s, &ix->w_pool_i, &ix->w_pool_cnt, &ix->w_over};
+                      &ix->w_outl, &ix->w_tau, &ix->w_pool_s, &ix->w_pool_i, &ix->w_pool_cnt, &ix->w_over,
+                      &ix->w_part_s, &ix->w_part_l, &ix->w_mrg_s, &ix->w_mrg_l};
     for (DevBuf* b : bufs) b->release();
     delete ix;
     return LDOT_OK;
@@ -293,7 +295,7 @@ static int dense_scan(ldot_index* ix, int64_t q0, int64_t nqb, int64_t nqb_pad, 
         prof_begin(ix, st, 2.0 * nqb * nrows * ix->d,
                    (double)nrows * ix->d * 2 + (double)nqb * ix->d * 2 + (double)nqb * nrows * 4);
         rc = launch_score_dense(q16, ix->dpad, nqb_pad, ix->x16, ix->dpad, r, nrows_pad, ix->dpad, (float*)ix->w_S.p,
-                                chunk, st);
+                                chunk, nqb, st);
         prof_end(ix, st);
         if (rc) return rc;
         rc = launch_select_dense((const float*)ix->w_S.p, chunk, nqb, nrows, r, ls, li, kp, tau ? tau + q0 : nullptr,
@@ -304,7 +306,46 @@ static int dense_scan(ldot_index* ix, int64_t q0, int64_t nqb, int64_t nqb_pad, 
     return LDOT_OK;
 }
 
+// Few queries (one query tile) x many rows — the single-query serving shape (dvl/utils.py:204-211): one wide score
+// launch over up to 4M rows (only the valid query rows are stored), a segmented select with (query, segment)
+// parallelism and one merge.  HBM-bound: the index is streamed once.
+static int dense_scan_wide(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, int kp, hipStream_t st) {
+    const int64_t wide = (int64_t)1 << 22, seg_cols = 16384;
+    float* ls = (float*)ix->w_ls.p;
+    int32_t* li = (int32_t*)ix->w_li.p;
+    for (int64_t r = r0; r < r1; r += wide) {
+        const int64_t nrows = std::min(wide, r1 - r), nrows_pad = round_up(nrows, kBN);
+        const int64_t nseg = (nrows + seg_cols - 1) / seg_cols;
+        int rc;
+        if ((rc = ix->w_S.ensure((size_t)nq * nrows_pad * sizeof(float)))) return rc;
+        if ((rc = ix->w_part_s.ensure((size_t)(nseg + 1) * nq * kp * 4))) return rc;
+        if ((rc = ix->w_part_l.ensure((size_t)(nseg + 1) * nq * kp * 8))) return rc;
+        if ((rc = ix->w_mrg_s.ensure((size_t)nq * kp * 4))) return rc;
+        if ((rc = ix->w_mrg_l.ensure((size_t)nq * kp * 8))) return rc;
+        prof_begin(ix, st, 2.0 * nq * nrows * ix->d,
+                   (double)nrows * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * nrows * 4);
+        rc = launch_score_dense(ix->w_q16.p, ix->dpad, kBM, ix->x16, ix->dpad, r, nrows_pad, ix->dpad,
+                                (float*)ix->w_S.p, nrows_pad, nq, st);
+        prof_end(ix, st);
+        if (rc) return rc;
+        float* ps = (float*)ix->w_part_s.p;
+        int64_t* pl = (int64_t*)ix->w_part_l.p;
+        if ((rc = launch_select_dense_parts((const float*)ix->w_S.p, nrows_pad, nq, nrows, seg_cols, r, kp, ps, pl, st)))
+            return rc;
+        // the running list (earlier wide chunks) joins the merge as one more part
+        if ((rc = launch_lists_to_parts(ls, li, nq * kp, ps + nseg * nq * kp, pl + nseg * nq * kp, st))) return rc;
+        if ((rc = launch_select_lists(ps, pl, nq * kp, (int)nseg + 1, kp, nq, kp, (float*)ix->w_mrg_s.p,
+                                      (int64_t*)ix->w_mrg_l.p, st)))
+            return rc;
+        if ((rc = launch_parts_to_lists((const float*)ix->w_mrg_s.p, (const int64_t*)ix->w_mrg_l.p, nq * kp, ls, li, st)))
+            return rc;
+        ix->stats[2] += nrows * nq;
+    }
+    return LDOT_OK;
+}
+
 static int dense_scan_all(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, int kp, float* tau, hipStream_t st) {
+    if (nq <= kBM && tau == nullptr && r1 - r0 > 2 * ix->chunk_rows) return dense_scan_wide(ix, nq, r0, r1, kp, st);
     // query blocks bound the dense score workspace (<= ~2 GiB at the default chunk)
     const int64_t qb_max = std::max<int64_t>(kBM, ((int64_t)1 << 29) / ix->chunk_rows / kBM * kBM);
     for (int64_t q0 = 0; q0 < nq; q0 += qb_max) {

@@ -21,12 +21,22 @@ int launch_convert_rows(const void* src, int dtype, int64_t ld_src, int64_t n, i
                         float* dst32, uint16_t* dst16, hipStream_t st);
 
 int launch_score_dense(const void* q16, int64_t ldq_elems, int64_t nq_pad, const void* x16, int64_t ldx_elems,
-                       int64_t xrow0, int64_t nrows_pad, int dpad, float* S, int64_t lds_elems, hipStream_t st);
+                       int64_t xrow0, int64_t nrows_pad, int dpad, float* S, int64_t lds_elems, int64_t nq_valid,
+                       hipStream_t st);
 
 // lists: [nq][kp] fp32 scores + int32 rows, kept sorted (score desc, row asc); empty slots have row -1.
 int launch_init_lists(float* list_s, int32_t* list_i, int64_t n, hipStream_t st);
 int launch_select_dense(const float* S, int64_t lds_elems, int64_t nq, int64_t ncols, int64_t idx_base,
                         float* list_s, int32_t* list_i, int kp, float* tau, hipStream_t st);
+// segmented variant for few queries x many rows: grid (nq, nseg); every (query, segment) writes an independent partial
+// top-kp list part_[sl][seg][q][kp] (int64 labels) that launch_select_lists then merges
+int launch_select_dense_parts(const float* S, int64_t lds_elems, int64_t nq, int64_t ncols, int64_t seg_cols,
+                              int64_t idx_base, int kp, float* part_s, int64_t* part_l, hipStream_t st);
+// list bookkeeping for the segmented path
+int launch_lists_to_parts(const float* list_s, const int32_t* list_i, int64_t n, float* part_s, int64_t* part_l,
+                          hipStream_t st);
+int launch_parts_to_lists(const float* out_s, const int64_t* out_l, int64_t n, float* list_s, int32_t* list_i,
+                          hipStream_t st);
 int launch_select_pools(const float* pool_s, const int32_t* pool_i, const int32_t* pool_cnt, int64_t nq,
                         float* list_s, int32_t* list_i, int kp, float* tau, int32_t* overflow_flags,
                         hipStream_t st);

@@ -11,7 +11,7 @@ namespace ldot {
 // accumulator register stores a coalesced 128-byte run of S[q][n..n+32).
 __global__ __launch_bounds__(kGemmThreads, 2) void score_dense_kernel(
     const char* __restrict__ Q16, int64_t ldq_b, int tiles_m, const char* __restrict__ X16, int64_t ldx_b,
-    int64_t xrow0, int tiles_n, int nk, float* __restrict__ S, int64_t lds_elems) {
+    int64_t xrow0, int tiles_n, int nk, float* __restrict__ S, int64_t lds_elems, int64_t m_valid) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // supertile order: 8 query tiles x 4 row tiles per group of 32 consecutive logical ids
     const int sm = (tiles_m + 7) / 8;
@@ -36,12 +36,13 @@ __global__ __launch_bounds__(kGemmThreads, 2) void score_dense_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t m = m_base + mr * 32 + (r & 3) + 8 * (r >> 2);
-                S[m * lds_elems + n_base + nr * 32] = acc[mr][nr][r];
+                if (m < m_valid) S[m * lds_elems + n_base + nr * 32] = acc[mr][nr][r];   // pad queries are not stored
             }
 }
 
 int launch_score_dense(const void* q16, int64_t ldq_elems, int64_t nq_pad, const void* x16, int64_t ldx_elems,
-                       int64_t xrow0, int64_t nrows_pad, int dpad, float* S, int64_t lds_elems, hipStream_t st) {
+                       int64_t xrow0, int64_t nrows_pad, int dpad, float* S, int64_t lds_elems, int64_t nq_valid,
+                       hipStream_t st) {
     const int tiles_m = (int)(nq_pad / kBM), tiles_n = (int)(nrows_pad / kBN);
     const int sm = (tiles_m + 7) / 8, sn = (tiles_n + 3) / 4;
     const int nwg = sm * sn * 32;
@@ -53,7 +54,7 @@ int launch_score_dense(const void* q16, int64_t ldq_elems, int64_t nq_pad, const
     }
     hipLaunchKernelGGL(score_dense_kernel, dim3(nwg), dim3(kGemmThreads), kGemmLdsBytes, st, (const char*)q16,
                        ldq_elems * 2, tiles_m, (const char*)x16, ldx_elems * 2, xrow0, tiles_n, dpad / kBK, S,
-                       lds_elems);
+                       lds_elems, nq_valid);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

@@ -167,6 +167,66 @@ __global__ __launch_bounds__(kSelThreads) void select_dense_kernel(const float* 
     sel.finish(ls, li, tau ? tau + q : nullptr);
 }
 
+// segmented dense source (few queries x many rows): blockIdx.y = segment of `seg_cols` columns; no running list, the
+// partial top-kp of the segment goes to part_[sl][seg][q][kp] with int64 labels (merged by select_lists_kernel)
+__global__ __launch_bounds__(kSelThreads) void select_dense_parts_kernel(const float* __restrict__ S, int64_t lds_elems,
+                                                                         int64_t nq, int64_t ncols, int64_t seg_cols,
+                                                                         int64_t idx_base, int kp, int cap,
+                                                                         float* __restrict__ part_s,
+                                                                         int64_t* __restrict__ part_l) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
+    __shared__ int count;
+    const int64_t q = blockIdx.x, seg = blockIdx.y;
+    Selector sel;
+    sel.init(keys, &count, kp, cap);
+    const float* row = S + q * lds_elems;
+    const int64_t cbeg = seg * seg_cols, cend = (cbeg + seg_cols < ncols) ? cbeg + seg_cols : ncols;
+    for (int64_t c0 = cbeg; c0 < cend; c0 += 4 * kSelThreads) {
+        sel.reserve(4 * kSelThreads);
+        const int64_t c = c0 + threadIdx.x * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c + 3 < cend) {
+            v = *(const f32x4*)(row + c);
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (c + e < cend) v[e] = row[c + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sel.push(make_key(v[e], (uint32_t)(idx_base + c + e)), c + e < cend);
+    }
+    sel.compact();
+    const int n = count;
+    float* ps = part_s + (seg * nq + q) * kp;
+    int64_t* pl = part_l + (seg * nq + q) * kp;
+    for (int e = threadIdx.x; e < kp; e += kSelThreads) {
+        if (e < n) {
+            const uint64_t k = keys[e];
+            ps[e] = desc_key_to_float((uint32_t)(k >> 32));
+            pl[e] = (int64_t)(uint32_t)(k & 0xffffffffu);
+        } else {
+            ps[e] = LDOT_PAD_SCORE;
+            pl[e] = LDOT_PAD_LABEL;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void lists_to_parts_kernel(const float* __restrict__ ls, const int32_t* __restrict__ li,
+                                                             int64_t n, float* __restrict__ ps, int64_t* __restrict__ pl) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        ps[i] = ls[i];
+        pl[i] = (int64_t)li[i];
+    }
+}
+__global__ __launch_bounds__(256) void parts_to_lists_kernel(const float* __restrict__ os, const int64_t* __restrict__ ol,
+                                                             int64_t n, float* __restrict__ ls, int32_t* __restrict__ li) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        ls[i] = os[i];
+        li[i] = (int32_t)ol[i];
+    }
+}
+
 // pool source: the per-query sub-pools filled by the fused filter kernel; resets the counters afterwards.
 // One wave per query (no cross-wave barriers), small LDS footprint -> many queries resident per CU.
 constexpr int kPoolSelThreads = 64;
@@ -273,6 +333,35 @@ int launch_select_dense(const float* S, int64_t lds_elems, int64_t nq, int64_t n
     const int cap = select_cap(kp, 2048);   // 16 KiB of keys for kp <= 1024: segment of 1024 columns always fits
     hipLaunchKernelGGL(select_dense_kernel, dim3((unsigned)nq), dim3(kSelThreads), (size_t)cap * 8, st, S, lds_elems,
                        ncols, idx_base, list_s, list_i, kp, cap, tau);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+int launch_select_dense_parts(const float* S, int64_t lds_elems, int64_t nq, int64_t ncols, int64_t seg_cols,
+                              int64_t idx_base, int kp, float* part_s, int64_t* part_l, hipStream_t st) {
+    if (nq <= 0 || ncols <= 0) return LDOT_OK;
+    const int cap = select_cap(kp, 2048);
+    const unsigned nseg = (unsigned)((ncols + seg_cols - 1) / seg_cols);
+    hipLaunchKernelGGL(select_dense_parts_kernel, dim3((unsigned)nq, nseg), dim3(kSelThreads), (size_t)cap * 8, st, S,
+                       lds_elems, nq, ncols, seg_cols, idx_base, kp, cap, part_s, part_l);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+int launch_lists_to_parts(const float* list_s, const int32_t* list_i, int64_t n, float* part_s, int64_t* part_l,
+                          hipStream_t st) {
+    if (n <= 0) return LDOT_OK;
+    hipLaunchKernelGGL(lists_to_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, list_s, list_i, n,
+                       part_s, part_l);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+int launch_parts_to_lists(const float* out_s, const int64_t* out_l, int64_t n, float* list_s, int32_t* list_i,
+                          hipStream_t st) {
+    if (n <= 0) return LDOT_OK;
+    hipLaunchKernelGGL(parts_to_lists_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out_s, out_l, n,
+                       list_s, list_i);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

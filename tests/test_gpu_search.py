@@ -266,3 +266,22 @@ def test_s1_reduced_planted(L):
     assert (np.diff(s.astype(np.float64), axis=1) <= 0).all()
     sub = slice(0, 96)
     assert_topk_matches(q[sub], x, s[sub], l[sub], k)
+
+
+@pytest.mark.parametrize('nq,n,d,k', [(1, 150_000, 128, 100), (7, 70_001, 768, 10), (256, 200_000, 64, 100)])
+def test_few_queries_wide_path(L, nq, n, d, k):
+    """Single-query serving shape (dvl/utils.py:204-211): one query tile against many rows takes the wide dense path
+    (one score launch, segmented select, merge)."""
+    rng = np.random.default_rng(n + nq)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    q, g = planted_queries(x, nq)
+    ix = _index(x)
+    s, l = ix.search(q, k)
+    assert (l[:, 0] == g).all()
+    assert_topk_matches(q, x, s, l, k)
+    # incremental: rows added after a search are visible to the next one
+    x2 = rng.standard_normal((500, d)).astype(np.float32)
+    x2[7] = q[0] * 3.0
+    ix.add(x2)
+    s2, l2 = ix.search(q[:1], k)
+    assert l2[0, 0] == n + 7
