@@ -60,8 +60,8 @@ extern "C" {
 #define LDOT_OPT_CHUNK_ROWS 3   /* index rows per scoring chunk (multiple of 256) */
 #define LDOT_OPT_MARGIN 4       /* extra candidates kept beyond k before the fp32 re-score (default max(28,k/4)) */
 #define LDOT_OPT_PROFILE 5      /* 1: bracket every score-kernel launch with HIP events (see ldot_index_last_profile) */
-#define LDOT_OPT_WARM_ROWS 6    /* rows scored densely before the fused filter starts (default 2048, multiple of 256) */
-#define LDOT_OPT_GROWTH_PCT 7   /* fused launch i covers growth% of the rows already scanned (default 100 = doubling) */
+#define LDOT_OPT_WARM_ROWS 6    /* rows scored densely before the fused filter starts (default 4096, multiple of 256) */
+#define LDOT_OPT_GROWTH_PCT 7   /* fused launch i covers growth% of the rows already scanned (default 150) */
 
 typedef struct ldot_index ldot_index_t;
 

@@ -57,8 +57,8 @@ struct ldot_index {
     int64_t chunk_rows = 32768;
     int margin = -1;
     int profile = 0;
-    int64_t warm_rows = 2048;
-    int growth_pct = 100;
+    int64_t warm_rows = 4096;
+    int growth_pct = 150;
     struct ProfEv {
         hipEvent_t a, b;
         double flops, bytes;

@@ -254,10 +254,24 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_ring_kernel(
 }
 
 // ---- third generation: (64*MR) x 256 tile on the ring, A fragments recycled in place (gemm_ring.h) -------------
+// max of four accumulator registers in two instructions.  fmaxf() would add a canonicalising v_max per MFMA
+// output (hipcc cannot prove MFMA results are quiet); scores are never signalling NaNs, so v_max3 is applied
+// directly.  The operands are MFMA results: the caller guarantees >= 18 wait states since the last MFMA issue
+// (the s_nop block at the top of the epilogue) because hipcc does not pad hazards for inline asm.
+__device__ __forceinline__ float max4_raw(float a0, float a1, float a2, float a3) {
+    float m;
+    asm volatile("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4" : "=&v"(m) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+    return m;
+}
+
 template <int MR, bool NOSTORE>
 __device__ __forceinline__ void filter_epilogue_r(const f32x16 (&acc)[MR][2], const float (&tau)[2], int (&cur)[2],
                                                   const uint32_t (&pbase)[2], float* __restrict__ pool_s,
                                                   int32_t* __restrict__ pool_i, int32_t row_lane0, int32_t row_end) {
+    // MFMA -> VALU read hazard cover for the inline-asm reads below (32x32x16 bf16: 8 passes, <= 18 wait states)
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int nr = 0; nr < 2; ++nr) {
 #pragma unroll
@@ -266,7 +280,7 @@ __device__ __forceinline__ void filter_epilogue_r(const f32x16 (&acc)[MR][2], co
             for (int g = 0; g < 4; ++g) {
                 const float a0 = acc[mr][nr][4 * g + 0], a1 = acc[mr][nr][4 * g + 1];
                 const float a2 = acc[mr][nr][4 * g + 2], a3 = acc[mr][nr][4 * g + 3];
-                const float m = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+                const float m = max4_raw(a0, a1, a2, a3);
                 if (m >= tau[nr]) {
                     const int32_t rb = row_lane0 + mr * 32 + 8 * g;
                     filter_append<NOSTORE>(a0, tau[nr], rb + 0, row_end, cur[nr], pbase[nr], pool_s, pool_i);
@@ -320,9 +334,11 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     auto issue = [&]() {
         char* st = smem + (int)(issued & 3) * Geo::kStage;
         const int k0b = l_k * (kRBK * 2);
+        if (!(VAR & 2) || issued < 4)
 #pragma unroll
         for (int j = 0; j < Geo::kALoads; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(sa.rsrc, (rg_lptr_t)(st + (j * 8 + c.wave) * 1024), 16, va[j], k0b, 0, 0);
+        if (!(VAR & 2) || issued < 4)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(sb.rsrc, (rg_lptr_t)(st + Geo::kAOpBytes + (j * 8 + c.wave) * 1024),
@@ -366,14 +382,17 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     int64_t s = 0;
     auto slab = [&]() {
         // k-step 0 of slab s (operands: a, b[0]); a <- k-step 1 of slab s, b[1] <- k-step 1 of slab s
-        ringr_step<MR>(c, f, 0, smem + (int)(s & 3) * Geo::kStage, 1, acc);
+        if (!(VAR & 4)) ringr_step<MR>(c, f, 0, smem + (int)(s & 3) * Geo::kStage, 1, acc);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of slab s are complete (WAR on its stage)
-        wait_vmcnt<2 * Geo::kLoads>();                       // slab s+1 has landed (this thread's part) ...
+        if (VAR & 2)
+            wait_vmcnt<0>();
+        else
+            wait_vmcnt<2 * Geo::kLoads>();                   // slab s+1 has landed (this thread's part) ...
         __builtin_amdgcn_s_barrier();                        // ... and everybody else's
         ++s;
         // k-step 1 of the old slab (operands: a, b[1]); a, b[0] <- k-step 0 of slab s (just opened)
-        ringr_step<MR>(c, f, 1, smem + (int)(s & 3) * Geo::kStage, 0, acc);
+        if (!(VAR & 4)) ringr_step<MR>(c, f, 1, smem + (int)(s & 3) * Geo::kStage, 0, acc);
         __builtin_amdgcn_sched_barrier(0);
         issue();                                             // slab s+3 (or a dummy) -> the stage slab s-1 vacated
     };
@@ -440,6 +459,8 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     if (impl == 3) {
         auto rk = score_filter_r6_kernel<0>;
         if (variant == 16) rk = score_filter_r6_kernel<16>;
+        if (variant == 18) rk = score_filter_r6_kernel<18>;
+        if (variant == 20) rk = score_filter_r6_kernel<20>;
         LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            RingGeom<6>::kLds));
         hipLaunchKernelGGL(rk, dim3(256), dim3(kRingThreads), RingGeom<6>::kLds, st, (const char*)x16, ldx_elems * 2,
