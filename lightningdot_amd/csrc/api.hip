@@ -367,22 +367,24 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
     // (8 per sub-pool, overflow probability ~1e-11 each) bounds len <= r*1024/kp; the smallest launch is one tile
     // per row slice, hence the warm-up covers at least 8*kp rows.
     const int64_t bm = fused_tile_rows();
+    const int qg = fused_query_group(nq_pad);
+    const int64_t nslices = 256 / qg, nsubs = 4 * nslices;
     const int64_t warm =
-        std::min(ix->ntotal, std::max<int64_t>(ix->warm_rows, round_up(bm * kFusedSlices * (int64_t)kp / 1024, 256)));
+        std::min(ix->ntotal, std::max<int64_t>(ix->warm_rows, round_up(bm * nslices * (int64_t)kp / 1024, 256)));
     if ((rc = dense_scan_all(ix, nq, 0, warm, kp, tau, st))) return rc;
     if (warm >= ix->ntotal) return LDOT_OK;
-    if ((rc = ix->w_pool_s.ensure((size_t)nq_pad * kPoolSubs * kPoolCap * 4))) return rc;
-    if ((rc = ix->w_pool_i.ensure((size_t)nq_pad * kPoolSubs * kPoolCap * 4))) return rc;
-    if ((rc = ix->w_pool_cnt.ensure((size_t)nq_pad * kPoolSubs * 4))) return rc;
+    if ((rc = ix->w_pool_s.ensure((size_t)nq_pad * nsubs * kPoolCap * 4))) return rc;
+    if ((rc = ix->w_pool_i.ensure((size_t)nq_pad * nsubs * kPoolCap * 4))) return rc;
+    if ((rc = ix->w_pool_cnt.ensure((size_t)nq_pad * nsubs * 4))) return rc;
     if ((rc = ix->w_over.ensure((size_t)nq_pad * 4))) return rc;
     LDOT_HIP_CHECK(hipMemsetAsync(ix->w_over.p, 0, (size_t)nq_pad * 4, st));
-    LDOT_HIP_CHECK(hipMemsetAsync(ix->w_pool_cnt.p, 0, (size_t)nq_pad * kPoolSubs * 4, st));
+    LDOT_HIP_CHECK(hipMemsetAsync(ix->w_pool_cnt.p, 0, (size_t)nq_pad * nsubs * 4, st));
     if (nq_pad > nq)   // pad queries never produce candidates
         LDOT_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(tau + nq), 0x7f800000, (size_t)(nq_pad - nq), st));
     int64_t r = warm;
     while (r < ix->ntotal) {
         int64_t len = std::min<int64_t>(r * ix->growth_pct / 100, r * 1024 / kp);
-        len = std::max<int64_t>(len, bm * kFusedSlices);
+        len = std::max<int64_t>(len, bm * nslices);
         len = round_up(len, bm);
         len = std::min(len, ix->ntotal - r);
         prof_begin(ix, st, 2.0 * nq * len * ix->d,
@@ -392,7 +394,8 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
         prof_end(ix, st);
         if (rc) return rc;
         rc = launch_select_pools((const float*)ix->w_pool_s.p, (const int32_t*)ix->w_pool_i.p,
-                                 (const int32_t*)ix->w_pool_cnt.p, nq, (float*)ix->w_ls.p, (int32_t*)ix->w_li.p, kp, tau,
+                                 (const int32_t*)ix->w_pool_cnt.p, (int)nsubs, nq, (float*)ix->w_ls.p, (int32_t*)ix->w_li.p, kp,
+                                 tau,
                                  (int32_t*)ix->w_over.p, st);
         if (rc) return rc;
         ix->stats[3] += len * nq;
@@ -450,8 +453,7 @@ int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dty
     if ((rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, st))) return rc;
 
     if (ix->ntotal > 0) {
-        bool fused = ix->mode == LDOT_MODE_FUSED ||
-                     (ix->mode == LDOT_MODE_AUTO && ix->ntotal >= 131072 && nq_pad >= 4 * kBN);
+        bool fused = ix->mode == LDOT_MODE_FUSED || (ix->mode == LDOT_MODE_AUTO && ix->ntotal >= 131072);
         if (fused) {
             bool overflowed = false;
             if ((rc = fused_scan(ix, nq, nq_pad, kp, st, &overflowed))) return rc;

@@ -14,6 +14,7 @@ constexpr int kSelCap = 4096;      // LDS candidate buffer (64-bit keys)
 constexpr int kFusedSlices = 32;
 constexpr int kPoolSubs = kFusedSlices * 4;
 constexpr int kPoolCap = 32;
+constexpr int kPoolSubsMax = 1024;   // query-group width 1: 256 row slices x 4 lanes
 
 // rows: convert n rows of `dtype` (row stride ld_src elements, d valid columns) into the padded fp32 master copy
 // and/or its bf16 shadow (row stride dpad, zero padded); optional L2 normalisation.
@@ -37,7 +38,7 @@ int launch_lists_to_parts(const float* list_s, const int32_t* list_i, int64_t n,
                           hipStream_t st);
 int launch_parts_to_lists(const float* out_s, const int64_t* out_l, int64_t n, float* list_s, int32_t* list_i,
                           hipStream_t st);
-int launch_select_pools(const float* pool_s, const int32_t* pool_i, const int32_t* pool_cnt, int64_t nq,
+int launch_select_pools(const float* pool_s, const int32_t* pool_i, const int32_t* pool_cnt, int nsubs, int64_t nq,
                         float* list_s, int32_t* list_i, int kp, float* tau, int32_t* overflow_flags,
                         hipStream_t st);
 // generic merge of explicit candidate lists: cand_[sl] is [nq][ncand] (labels int64, -1 = empty) -> [nq][k_out]
@@ -50,6 +51,7 @@ int launch_rescore(const float* q32, int64_t ldq, const float* x32, int64_t ldx,
                    int64_t* out_l, hipStream_t st);
 
 int fused_tile_rows();
+int fused_query_group(int64_t nq_pad);   // 8 / 4 / 2 / 1 -> 1024 / qg sub-pools per query, 256 / qg row slices
 
 // fused MFMA score + threshold filter over index rows [row0, row0 + nrows) (nrows_pad multiple of 256)
 int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_t nrows, const void* q16,

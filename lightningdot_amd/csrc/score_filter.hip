@@ -298,24 +298,30 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// qg_log2: log2 of the number of query blocks an XCD works on concurrently (8 for large batches; 1/2/4 for few
+// query blocks, so that all 256 workgroups stream index rows even for a single query block — the serving shape).
 template <int VAR>
 __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     const char* __restrict__ X16, int64_t ldx_b, int64_t row0, int64_t nrows, const char* __restrict__ Q16,
     int64_t ldq_b, int nqb, int nk, const float* __restrict__ tau_g, float* __restrict__ pool_s,
-    int32_t* __restrict__ pool_i, int32_t* __restrict__ pool_cnt) {
+    int32_t* __restrict__ pool_i, int32_t* __restrict__ pool_cnt, int qg_log2) {
     constexpr int MR = 6;
     using Geo = RingGeom<MR>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     RingCtx c;
     ring_ctx_init(c);
+    const int qg = 1 << qg_log2;                       // query blocks in flight per XCD
+    const int nstream = 32 >> qg_log2;                 // row streams per XCD
+    const int nslices = 8 * nstream;                   // row slices of the launch
+    const int nsubs = nslices * 4;                     // lane-private sub-pools per query
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int qsub = slot & 7, nsub = slot >> 3;
-    const int slice = xcd * 4 + nsub;
+    const int qsub = slot & (qg - 1), nsub = slot >> qg_log2;
+    const int slice = xcd * nstream + nsub;
     const int ntiles = (int)((nrows + Geo::kBM - 1) / Geo::kBM);
     const int32_t row_end = (int32_t)(row0 + nrows);
     const int sub = (slice * 2 + c.wm) * 2 + (c.lane >> 5);
-    const int nq_iter = (nqb > qsub) ? (nqb - qsub + 7) / 8 : 0;
-    const int nt_iter = (ntiles > slice) ? (ntiles - slice + kFusedSlices - 1) / kFusedSlices : 0;
+    const int nq_iter = (nqb > qsub) ? (nqb - qsub + qg - 1) >> qg_log2 : 0;
+    const int nt_iter = (ntiles > slice) ? (ntiles - slice + nslices - 1) / nslices : 0;
     const int ntile_total = nq_iter * nt_iter;
     if (ntile_total == 0) return;
     const int64_t S = (int64_t)ntile_total * nk;
@@ -350,9 +356,9 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
                 if (++l_t == nt_iter) {
                     l_t = 0;
                     ++l_q;
-                    sb.rsrc = ring_make_rsrc_n(Q16 + (int64_t)(qsub + l_q * 8) * kRBN * ldq_b, kRBN * ldq_b);
+                    sb.rsrc = ring_make_rsrc_n(Q16 + (int64_t)(qsub + l_q * qg) * kRBN * ldq_b, kRBN * ldq_b);
                 }
-                sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)(slice + l_t * kFusedSlices) * Geo::kBM) * ldx_b,
+                sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)(slice + l_t * nslices) * Geo::kBM) * ldx_b,
                                            Geo::kBM * ldx_b);
             }
         }
@@ -401,9 +407,9 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     for (int c_q = 0; c_q < nq_iter; ++c_q) {
 #pragma unroll
         for (int nr = 0; nr < 2; ++nr) {
-            qidx[nr] = (int64_t)(qsub + c_q * 8) * kRBN + c.wn * 64 + nr * 32 + (c.lane & 31);
+            qidx[nr] = (int64_t)(qsub + c_q * qg) * kRBN + c.wn * 64 + nr * 32 + (c.lane & 31);
             tau[nr] = (VAR & 16) ? INFINITY : ring_launder(tau_g[qidx[nr]]);
-            pbase[nr] = (uint32_t)((qidx[nr] * kPoolSubs + sub) * kPoolCap);
+            pbase[nr] = (uint32_t)((qidx[nr] * nsubs + sub) * kPoolCap);
             cur[nr] = 0;
         }
 #pragma unroll 1
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
                     for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.f;
 #pragma unroll 1
             for (int kk = 0; kk < nk; ++kk) slab();
-            const int64_t trow = row0 + (int64_t)(slice + c_t * kFusedSlices) * Geo::kBM;
+            const int64_t trow = row0 + (int64_t)(slice + c_t * nslices) * Geo::kBM;
             const int32_t row_lane0 = (int32_t)trow + c.wm * (32 * MR) + 4 * (c.lane >> 5);
             if (!(VAR & 1)) {
                 filter_epilogue_r<MR, (VAR & 8) != 0>(acc, tau, cur, pbase, pool_s, pool_i, row_lane0, row_end);
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
             }
         }
 #pragma unroll
-        for (int nr = 0; nr < 2; ++nr) pool_cnt[qidx[nr] * kPoolSubs + sub] = cur[nr];
+        for (int nr = 0; nr < 2; ++nr) pool_cnt[qidx[nr] * nsubs + sub] = cur[nr];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing dummy loads must land before the LDS is released
 }
@@ -443,6 +449,14 @@ static int filter_impl() {
 }
 // index rows per fused tile (the host sizes launches and the row padding of the index with it)
 int fused_tile_rows() { return filter_impl() == 3 ? RingGeom<6>::kBM : kRBM; }
+
+// query blocks an XCD works on concurrently for a batch of nqb query blocks (power of two <= 8); the fused launch then
+// has 256 / qg row slices and 1024 / qg sub-pools per query
+int fused_query_group(int64_t nq_pad) {
+    if (filter_impl() != 3) return 8;
+    const int64_t nqb = nq_pad / kRBN;
+    return nqb >= 8 ? 8 : nqb >= 4 ? 4 : nqb >= 2 ? 2 : 1;
+}
 
 int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_t nrows, const void* q16,
                         int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, float* pool_s,
@@ -463,9 +477,11 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
         if (variant == 20) rk = score_filter_r6_kernel<20>;
         LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            RingGeom<6>::kLds));
+        const int qg = fused_query_group(nq_pad);
+        const int qg_log2 = qg == 8 ? 3 : qg == 4 ? 2 : qg == 2 ? 1 : 0;
         hipLaunchKernelGGL(rk, dim3(256), dim3(kRingThreads), RingGeom<6>::kLds, st, (const char*)x16, ldx_elems * 2,
                            row0, nrows, (const char*)q16, ldq_elems * 2, (int)(nq_pad / kRBN), dpad / kRBK, tau, pool_s,
-                           pool_i, pool_cnt);
+                           pool_i, pool_cnt, qg_log2);
         LDOT_HIP_CHECK(hipGetLastError());
         return LDOT_OK;
     }

@@ -232,31 +232,31 @@ __global__ __launch_bounds__(256) void parts_to_lists_kernel(const float* __rest
 constexpr int kPoolSelThreads = 64;
 __global__ __launch_bounds__(kPoolSelThreads) void select_pools_kernel(const float* __restrict__ pool_s,
                                                                        const int32_t* __restrict__ pool_i,
-                                                                       int32_t* __restrict__ pool_cnt,
+                                                                       int32_t* __restrict__ pool_cnt, int nsubs,
                                                                        float* __restrict__ list_s,
                                                                        int32_t* __restrict__ list_i, int kp, int cap,
                                                                        float* __restrict__ tau,
                                                                        int32_t* __restrict__ overflow) {
     extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
     __shared__ int count;
-    __shared__ int cnts[kPoolSubs];
+    __shared__ int cnts[kPoolSubsMax];
     const int64_t q = blockIdx.x;
     Selector sel;
     sel.init(keys, &count, kp, cap);
     float* ls = list_s + q * kp;
     int32_t* li = list_i + q * kp;
     bool over = false;
-    for (int s = threadIdx.x; s < kPoolSubs; s += kPoolSelThreads) {
-        const int c = pool_cnt[q * kPoolSubs + s];
+    for (int s = threadIdx.x; s < nsubs; s += kPoolSelThreads) {
+        const int c = pool_cnt[q * (int64_t)nsubs + s];
         cnts[s] = c < kPoolCap ? c : kPoolCap;
         over |= c > kPoolCap;
-        pool_cnt[q * kPoolSubs + s] = 0;
+        pool_cnt[q * (int64_t)nsubs + s] = 0;
     }
     const bool any_over = __any(over);
     sel.load_list(ls, li);
-    const int64_t base = q * (int64_t)(kPoolSubs * kPoolCap);
-    // each lane walks two sub-pools (kPoolSubs = 2 * 64); entries of a sub-pool are contiguous
-    for (int half = 0; half < kPoolSubs / kPoolSelThreads; ++half) {
+    const int64_t base = q * (int64_t)nsubs * kPoolCap;
+    // each lane walks nsubs / 64 sub-pools; entries of a sub-pool are contiguous
+    for (int half = 0; half < nsubs / kPoolSelThreads; ++half) {
         const int sub = half * kPoolSelThreads + threadIdx.x;
         const int n = cnts[sub];
         int nmax = n;
@@ -366,13 +366,13 @@ int launch_parts_to_lists(const float* out_s, const int64_t* out_l, int64_t n, f
     return LDOT_OK;
 }
 
-int launch_select_pools(const float* pool_s, const int32_t* pool_i, const int32_t* pool_cnt, int64_t nq,
+int launch_select_pools(const float* pool_s, const int32_t* pool_i, const int32_t* pool_cnt, int nsubs, int64_t nq,
                         float* list_s, int32_t* list_i, int kp, float* tau, int32_t* overflow_flags,
                         hipStream_t st) {
     if (nq <= 0) return LDOT_OK;
     const int cap = select_cap(kp, 1024);
     hipLaunchKernelGGL(select_pools_kernel, dim3((unsigned)nq), dim3(kPoolSelThreads), (size_t)cap * 8, st, pool_s,
-                       pool_i, (int32_t*)pool_cnt, list_s, list_i, kp, cap, tau, overflow_flags);
+                       pool_i, (int32_t*)pool_cnt, nsubs, list_s, list_i, kp, cap, tau, overflow_flags);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

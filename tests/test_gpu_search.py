@@ -118,7 +118,7 @@ def test_normalize_option(L):
     assert np.abs(s).max() <= 1.0 + 1e-5
 
 
-@pytest.mark.parametrize('nq,n,d,k', [(300, 20000, 768, 100), (1100, 70000, 128, 10), (257, 40000, 64, 1000)])
+@pytest.mark.parametrize('nq,n,d,k', [(300, 20000, 768, 100), (1100, 70000, 128, 10), (257, 150000, 64, 1000)])
 def test_fused_matches_oracle(L, nq, n, d, k):
     rng = np.random.default_rng(n + k)
     x = rng.standard_normal((n, d)).astype(np.float32)
@@ -140,7 +140,7 @@ def test_fused_adversarial_order_falls_back(L):
     """Rows sorted so that every later row beats all earlier ones for every query: the lane-private pools
     overflow, the library detects it and redoes the search densely — results stay exact."""
     rng = np.random.default_rng(11)
-    n, d, nq = 12000, 64, 256
+    n, d, nq = 12000, 64, 2048      # 8 query blocks -> 32 row slices, warm-up 4096 rows, one fused launch
     base = rng.standard_normal(d).astype(np.float32)
     base /= np.linalg.norm(base)
     x = (rng.standard_normal((n, d)) * 0.01).astype(np.float32) + np.outer(np.linspace(0.0, 50.0, n), base).astype(np.float32)
