@@ -51,7 +51,7 @@ extern "C" {
 #define LDOT_PAD_SCORE (-3.402823466e+38f)
 
 /* search-mode flags (ldot_index_set_option(LDOT_OPT_MODE, ...)) */
-#define LDOT_MODE_AUTO 0   /* dense for small indexes, fused filter for large ones */
+#define LDOT_MODE_AUTO 0   /* dense below 32768 rows, fused filter above */
 #define LDOT_MODE_DENSE 1  /* materialise score chunks + radix select */
 #define LDOT_MODE_FUSED 2  /* fused MFMA score + threshold filter (never materialises Q x N) */
 

@@ -453,7 +453,7 @@ int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dty
     if ((rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, st))) return rc;
 
     if (ix->ntotal > 0) {
-        bool fused = ix->mode == LDOT_MODE_FUSED || (ix->mode == LDOT_MODE_AUTO && ix->ntotal >= 131072);
+        bool fused = ix->mode == LDOT_MODE_FUSED || (ix->mode == LDOT_MODE_AUTO && ix->ntotal >= 32768);
         if (fused) {
             bool overflowed = false;
             if ((rc = fused_scan(ix, nq, nq_pad, kp, st, &overflowed))) return rc;

@@ -74,8 +74,11 @@ class ShardedFlatIndexer:
 
     # ---- search ------------------------------------------------------------------------------------------
     def _gather_queries(self, q: torch.Tensor) -> Tuple[torch.Tensor, List[int]]:
-        counts = [None] * self.world
-        dist.all_gather_object(counts, int(q.shape[0]), group=self.group)
+        # query counts travel as one small tensor (no pickling; one host sync)
+        mine = torch.tensor([q.shape[0]], dtype=torch.int64, device=q.device)
+        cbuf = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(cbuf, mine, group=self.group)
+        counts = [int(c) for c in torch.cat(cbuf).tolist()]
         mx = max(counts)
         pad = q if q.shape[0] == mx else torch.cat([q, q.new_zeros(mx - q.shape[0], q.shape[1])], 0)
         bufs = [torch.empty_like(pad) for _ in range(self.world)]
@@ -96,14 +99,17 @@ class ShardedFlatIndexer:
         mine = slice(starts[self.rank], starts[self.rank + 1])
         nq_mine = counts[self.rank]
         backend = dist.get_backend(self.group)
-        if backend == 'nccl' and self.world > 1:
+        if backend == 'nccl':
             # all-to-all by query slice: rank r receives, from every rank, the partial lists of ITS queries
             mx = max(counts)
-            send_s = s.new_full((self.world, mx, k), L.PAD_SCORE)
-            send_l = l.new_full((self.world, mx, k), -1)
-            for r in range(self.world):
-                send_s[r, :counts[r]] = s[starts[r]:starts[r + 1]]
-                send_l[r, :counts[r]] = l[starts[r]:starts[r + 1]]
+            if min(counts) == mx:                    # equal query slices: the send buffers are plain views
+                send_s, send_l = s.view(self.world, mx, k), l.view(self.world, mx, k)
+            else:
+                send_s = s.new_full((self.world, mx, k), L.PAD_SCORE)
+                send_l = l.new_full((self.world, mx, k), -1)
+                for r in range(self.world):
+                    send_s[r, :counts[r]] = s[starts[r]:starts[r + 1]]
+                    send_l[r, :counts[r]] = l[starts[r]:starts[r + 1]]
             recv_s, recv_l = torch.empty_like(send_s), torch.empty_like(send_l)
             dist.all_to_all_single(recv_s, send_s.contiguous(), group=self.group)
             dist.all_to_all_single(recv_l, send_l.contiguous(), group=self.group)
