@@ -293,6 +293,23 @@ def g5_pool_proj():
         w0=sd['encode_proj.0.weight'].numpy(), b0=sd['encode_proj.0.bias'].numpy(),
         ln_g=sd['encode_proj.2.weight'].numpy(), ln_b=sd['encode_proj.2.bias'].numpy(),
         w3=sd['encode_proj.3.weight'].numpy(), b3=sd['encode_proj.3.bias'].numpy())
+    # full small tower: every parameter + inputs + outputs of the image path AND of the text-only path (the reference's
+    # `txt_model_type == 'uniter-base'` option, bi_encoder.py:216-217 — same BERT math and key names as the text tower)
+    txt_ids = torch.randint(1, 120, (B, 9), generator=g)
+    txt_ids[:, 0] = 101 % 120
+    txt_pos = torch.arange(0, 9, dtype=torch.long).unsqueeze(0)
+    txt_attn = torch.ones(B, 9, dtype=torch.long)
+    txt_attn[2, 6:] = 0
+    with torch.no_grad():
+        tseq, tpooled, _ = enc(txt_ids, txt_attn, txt_pos, None, None, None, None)
+    small_sd = {('sd__' + k): v.numpy() for k, v in sd.items()}
+    np.savez_compressed(
+        os.path.join(OUT, 'g5_tower_small.npz'), cfg=json.dumps(small), project_dim=np.int64(32),
+        img_input_ids=input_ids.numpy(), img_position_ids=position_ids.numpy(), img_feat=img_feat.numpy(),
+        img_pos_feat=img_pos_feat.numpy(), img_attn=attn.numpy(), gather_index=gather_index.numpy(),
+        img_seq=seq.numpy(), img_pooled=pooled.numpy(),
+        txt_input_ids=txt_ids.numpy(), txt_position_ids=txt_pos.numpy(), txt_attn=txt_attn.numpy(),
+        txt_seq=tseq.numpy(), txt_pooled=tpooled.numpy(), **small_sd)
     # checkpoint surface: key/shape manifest of the REAL image tower config (config/img_base.json)
     real = ref_be.UniterEncoder(UniterConfig(os.path.join(_ref_stubs.REF_ROOT, 'config', 'img_base.json')),
                                 project_dim=768)

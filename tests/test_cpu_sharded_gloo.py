@@ -110,3 +110,39 @@ def test_allgather_autograd_two_ranks_gloo(tmp_path):
         g = torch.load(os.path.join(str(tmp_path), f'g{r}.pt'))
         start = sum(sizes[:r])
         assert torch.equal(g, total[start:start + sizes[r]])
+
+
+def _dp_worker(rank, world, port, out_dir):
+    """Config-5 data-parallel plumbing: rank-0 parameter broadcast + flat-bucket averaged gradient all-reduce."""
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from lightningdot_amd.train import allreduce_gradients, broadcast_parameters
+    torch.manual_seed(100 + rank)                      # ranks start DIFFERENT
+    m = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.LayerNorm(5), torch.nn.Linear(5, 3))
+    m[2].bias.requires_grad_(False)                    # a frozen parameter takes no part
+    broadcast_parameters(m, 0)
+    x = torch.full((4, 6), float(rank + 1))
+    m(x).sum().backward()
+    local = [p.grad.clone() if p.grad is not None else None for p in m.parameters()]
+    allreduce_gradients(m.parameters(), bucket_bytes=64)        # tiny buckets: several collectives
+    torch.save(dict(params=[p.data.clone() for p in m.parameters()], local=local,
+                    reduced=[p.grad.clone() if p.grad is not None else None for p in m.parameters()]),
+               os.path.join(out_dir, f'dp{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_broadcast_and_gradient_allreduce_gloo(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_dp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a = torch.load(os.path.join(str(tmp_path), 'dp0.pt'))
+    b = torch.load(os.path.join(str(tmp_path), 'dp1.pt'))
+    for pa, pb in zip(a['params'], b['params']):
+        assert torch.equal(pa, pb)                     # broadcast made the replicas identical
+    for la, lb, ra, rb in zip(a['local'], b['local'], a['reduced'], b['reduced']):
+        if la is None:
+            assert ra is None and rb is None
+            continue
+        assert torch.allclose(ra, (la + lb) / 2) and torch.equal(ra, rb)
