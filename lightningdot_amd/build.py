@@ -55,9 +55,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
-    # a device-side compile error can leave host stubs without their kernels: refuse a library that does not load
-    import ctypes
-    ctypes.CDLL(LIB, mode=os.RTLD_NOW | os.RTLD_LOCAL)
+    # a device-side compile error can leave host stubs without their kernels: refuse a library that does not load.
+    # (checked in a child process: loading it here would map the system HIP runtime before torch maps its own)
+    subprocess.check_call([sys.executable, '-c',
+                           'import ctypes, os, sys; ctypes.CDLL(sys.argv[1], mode=os.RTLD_NOW | os.RTLD_LOCAL)', LIB])
     return LIB
 
 
