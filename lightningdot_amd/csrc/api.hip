@@ -66,7 +66,7 @@ struct ldot_index {
     std::vector<ProfEv> prof_events;
     double prof[4] = {0, 0, 0, 0};
     // workspaces
-    DevBuf w_stage, w_q32, w_q16, w_ls, w_li, w_S, w_outs, w_outl, w_tau, w_pool_s, w_pool_i, w_pool_cnt, w_over;
+    DevBuf w_stage, w_q32, w_q16, w_ls, w_li, w_S, w_outs, w_outl, w_tau, w_pool, w_pool_cnt, w_over;
     DevBuf w_part_s, w_part_l, w_mrg_s, w_mrg_l;
     int64_t stats[4] = {0, 0, 0, 0};
 };
@@ -140,7 +140,7 @@ int ldot_index_destroy(ldot_index_t* ix) {
     if (ix->x32) (void)hipFree(ix->x32);
     if (ix->x16) (void)hipFree(ix->x16);
     DevBuf* bufs[] = {&ix->w_stage, &ix->w_q32, &ix->w_q16, &ix->w_ls, &ix->w_li, &ix->w_S, &ix->w_outs,
-                      &ix->w_outl, &ix->w_tau, &ix->w_pool_s, &ix->w_pool_i, &ix->w_pool_cnt, &ix->w_over,
+                      &ix->w_outl, &ix->w_tau, &ix->w_pool, &ix->w_pool_cnt, &ix->w_over,
                       &ix->w_part_s, &ix->w_part_l, &ix->w_mrg_s, &ix->w_mrg_l};
     for (DevBuf* b : bufs) b->release();
     delete ix;
@@ -363,7 +363,7 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
     float* tau = (float*)ix->w_tau.p;
     int rc;
     // Pool sizing rule: a launch over `len` rows after `r` scanned rows admits ~kp*len/r candidates per query,
-    // spread over kPoolSubs lane-private sub-pools of kPoolCap entries.  Keeping the expectation <= 1024 per query
+    // spread over lane-private sub-pools of kPoolCap entries.  Keeping the expectation <= 1024 per query
     // (8 per sub-pool, overflow probability ~1e-11 each) bounds len <= r*1024/kp; the smallest launch is one tile
     // per row slice, hence the warm-up covers at least 8*kp rows.
     const int64_t bm = fused_tile_rows();
@@ -373,8 +373,7 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
         std::min(ix->ntotal, std::max<int64_t>(ix->warm_rows, round_up(bm * nslices * (int64_t)kp / 1024, 256)));
     if ((rc = dense_scan_all(ix, nq, 0, warm, kp, tau, st))) return rc;
     if (warm >= ix->ntotal) return LDOT_OK;
-    if ((rc = ix->w_pool_s.ensure((size_t)nq_pad * nsubs * kPoolCap * 4))) return rc;
-    if ((rc = ix->w_pool_i.ensure((size_t)nq_pad * nsubs * kPoolCap * 4))) return rc;
+    if ((rc = ix->w_pool.ensure((size_t)nq_pad * nsubs * kPoolCap * 8))) return rc;
     if ((rc = ix->w_pool_cnt.ensure((size_t)nq_pad * nsubs * 4))) return rc;
     if ((rc = ix->w_over.ensure((size_t)nq_pad * 4))) return rc;
     LDOT_HIP_CHECK(hipMemsetAsync(ix->w_over.p, 0, (size_t)nq_pad * 4, st));
@@ -390,11 +389,10 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
         prof_begin(ix, st, 2.0 * nq * len * ix->d,
                    (double)len * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * kp * 8);
         rc = launch_score_filter(ix->x16, ix->dpad, r, len, ix->w_q16.p, ix->dpad, nq_pad, ix->dpad, tau,
-                                 (float*)ix->w_pool_s.p, (int32_t*)ix->w_pool_i.p, (int32_t*)ix->w_pool_cnt.p, st);
+                                 (uint2*)ix->w_pool.p, (int32_t*)ix->w_pool_cnt.p, st);
         prof_end(ix, st);
         if (rc) return rc;
-        rc = launch_select_pools((const float*)ix->w_pool_s.p, (const int32_t*)ix->w_pool_i.p,
-                                 (const int32_t*)ix->w_pool_cnt.p, (int)nsubs, nq, (float*)ix->w_ls.p, (int32_t*)ix->w_li.p, kp,
+        rc = launch_select_pools((const uint2*)ix->w_pool.p, (const int32_t*)ix->w_pool_cnt.p, (int)nsubs, nq, (float*)ix->w_ls.p, (int32_t*)ix->w_li.p, kp,
                                  tau,
                                  (int32_t*)ix->w_over.p, st);
         if (rc) return rc;

@@ -9,10 +9,9 @@ constexpr int kSelThreads = 256;
 constexpr int kSelSeg = 2048;      // candidates examined between two compaction checks
 constexpr int kSelCap = 4096;      // LDS candidate buffer (64-bit keys)
 
-// fused-filter candidate pools: per query, kPoolSubs private sub-pools of kPoolCap (score, row) pairs.
-// sub-pool id = ((slice * 2 + wm) * 2 + (lane >> 5)); slice = fused-kernel row slice 0..kFusedSlices-1
-constexpr int kFusedSlices = 32;
-constexpr int kPoolSubs = kFusedSlices * 4;
+// fused-filter candidate pools: per query, nsubs = 4 * (row slices) lane-private sub-pools of kPoolCap {score, row}
+// words, laid out entry-major: pool[(q * kPoolCap + e) * nsubs + sub].
+// sub-pool id = ((slice * 2 + wm) * 2 + (lane >> 5)); slices = 256 / (query blocks per XCD) = 32 .. 256
 constexpr int kPoolCap = 32;
 constexpr int kPoolSubsMax = 1024;   // query-group width 1: 256 row slices x 4 lanes
 
@@ -38,9 +37,8 @@ int launch_lists_to_parts(const float* list_s, const int32_t* list_i, int64_t n,
                           hipStream_t st);
 int launch_parts_to_lists(const float* out_s, const int64_t* out_l, int64_t n, float* list_s, int32_t* list_i,
                           hipStream_t st);
-int launch_select_pools(const float* pool_s, const int32_t* pool_i, const int32_t* pool_cnt, int nsubs, int64_t nq,
-                        float* list_s, int32_t* list_i, int kp, float* tau, int32_t* overflow_flags,
-                        hipStream_t st);
+int launch_select_pools(const uint2* pool, const int32_t* pool_cnt, int nsubs, int64_t nq, float* list_s,
+                        int32_t* list_i, int kp, float* tau, int32_t* overflow_flags, hipStream_t st);
 // generic merge of explicit candidate lists: cand_[sl] is [nq][ncand] (labels int64, -1 = empty) -> [nq][k_out]
 int launch_select_lists(const float* cand_s, const int64_t* cand_l, int64_t part_stride, int nparts, int k_in,
                         int64_t nq, int k_out, float* out_s, int64_t* out_l, hipStream_t st);
@@ -55,8 +53,8 @@ int fused_query_group(int64_t nq_pad);   // 8 / 4 / 2 / 1 -> 1024 / qg sub-pools
 
 // fused MFMA score + threshold filter over index rows [row0, row0 + nrows) (nrows_pad multiple of 256)
 int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_t nrows, const void* q16,
-                        int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, float* pool_s,
-                        int32_t* pool_i, int32_t* pool_cnt, hipStream_t st);
+                        int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, uint2* pool, int32_t* pool_cnt,
+                        hipStream_t st);
 
 // loss path (fp32-input MFMA)
 int launch_sgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* B2, float w, float* C,

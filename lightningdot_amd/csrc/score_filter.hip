@@ -3,254 +3,42 @@
 // Replaces the sgemm + heap inside faiss IndexFlatIP.search (dvl/indexer/faiss_indexers.py:83) for large
 // indexes.  Orientation is "swapped": A = index rows (M side), B = queries (N side), so in the MFMA C/D layout
 // a lane owns ONE query column (col = lane & 31) and its accumulator registers hold that query's scores
-// against 64 different index rows.  The per-query admission threshold tau (the current k'-th best score, a
-// valid lower bound of the final one) therefore lives in a lane register and the filter is one v_cmp per
-// score with an exec-masked, almost never taken, append.
+// against 96 different index rows.  The per-query admission threshold tau (the current k'-th best score, a
+// valid lower bound of the final one) therefore lives in a lane register and the filter is a v_max3 tree + one
+// v_cmp per 4 scores with an exec-masked, almost never taken, append.
 //
-// Appends go to lane-private sub-pools in HBM (cursor in a VGPR, no atomics, no LDS): for a query q the
-// 4 lanes x 32 row slices that can produce candidates each own pool[q][sub][0..kPoolCap).  The select kernel
-// (select.hip) folds the pools into the running top-k' list between launches and raises tau.
+// Appends go to lane-private sub-pools in HBM (cursor in a VGPR, no atomics, no LDS): for a query q each of the
+// 4 lanes x (row slices) that can produce candidates owns the entries pool[q][e][sub], e = 0..kPoolCap-1.  The layout
+// is entry-major ([q][e][sub], one 8-byte {score, row} word per entry) so that the select kernel, which folds the
+// pools into the running top-k' list between launches and raises tau, reads the few used entry levels of all
+// sub-pools as contiguous 8-byte words instead of one cache line per entry.
 //
-// Work decomposition (256 persistent workgroups, block b observed on XCD b % 8):
-//   XCD x, slot s in [0,32): qsub = s % 8, nsub = s / 8;  row slice = x*4 + nsub  -> tiles t = slice (mod 32)
-//   for each group of 8 query blocks: query block = g*8 + qsub.
-// At any time the 32 workgroups of an XCD work on 8 query panels x 4 adjacent row tiles, so the private L2
-// holds 8 Q panels (3 MiB) and streams each row panel once per query group.
+// Work decomposition (256 persistent workgroups, block b observed on XCD b % 8; qg = query blocks per XCD):
+//   XCD x, slot s in [0,32): qsub = s % qg, nsub = s / qg;  row slice = x*(32/qg) + nsub -> tiles t = slice (mod slices)
+//   for each group of qg query blocks: query block = g*qg + qsub.
+// With qg = 8 the 32 workgroups of an XCD work on 8 query panels x 4 adjacent row tiles, so the private L2 holds
+// 8 Q panels (3 MiB) and streams each row panel once per query group.
+//
+// Earlier generations of this kernel (256x256 two-stage, commit da2a5a4; 256x256 on the LDS ring, commit 62cbd68) are in
+// the history; their measurements are in DESIGN.md section 5.2.
 #include <math.h>
 #include <stdlib.h>
 
-#include <type_traits>
-
 #include "gemm_ring.h"
-#include "gemm_tile.h"
 #include "kernels.h"
 
 namespace ldot {
 
-// Filter epilogue.  Fast path per 4 accumulator registers (256 scores): one max tree + one compare + one
-// (almost never taken) branch.  The slow path re-tests the four registers and appends the hits to the
-// lane-private sub-pool (cursor `cur`, clamped at kPoolCap; the true count is kept so overflow is detectable).
+// Append one candidate to this lane's sub-pool (cursor `cur`, clamped at kPoolCap; the true count is kept so overflow
+// is detectable).  pbase = q * kPoolCap * nsubs + sub, entry e lives at pbase + e * nsubs.
 template <bool NOSTORE = false>
 __device__ __forceinline__ void filter_append(float v, float tau, int32_t row, int32_t row_end, int& cur, uint32_t pbase,
-                                     float* __restrict__ pool_s, int32_t* __restrict__ pool_i) {
+                                              uint32_t nsubs, uint2* __restrict__ pool) {
     if (v >= tau && row < row_end) {
         const int p = cur;
         cur = p + 1;
-        if (p < kPoolCap && !NOSTORE) {
-            pool_s[pbase + (uint32_t)p] = v;
-            pool_i[pbase + (uint32_t)p] = row;
-        }
+        if (p < kPoolCap && !NOSTORE) pool[pbase + (uint32_t)p * nsubs] = make_uint2(__float_as_uint(v), (uint32_t)row);
     }
-}
-
-template <bool NOSTORE = false>
-__device__ __forceinline__ void filter_epilogue(const f32x16 (&acc)[4][2], const float (&tau)[2], int (&cur)[2],
-                                       const uint32_t (&pbase)[2], float* __restrict__ pool_s,
-                                       int32_t* __restrict__ pool_i, int32_t row_lane0, int32_t row_end) {
-#pragma unroll
-    for (int nr = 0; nr < 2; ++nr) {
-#pragma unroll
-        for (int mr = 0; mr < 4; ++mr) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float a0 = acc[mr][nr][4 * g + 0], a1 = acc[mr][nr][4 * g + 1];
-                const float a2 = acc[mr][nr][4 * g + 2], a3 = acc[mr][nr][4 * g + 3];
-                const float m = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
-                if (m >= tau[nr]) {
-                    // rows of register r = 4g + e:  (r & 3) + 8 * (r >> 2) = e + 8g
-                    const int32_t rb = row_lane0 + mr * 32 + 8 * g;
-                    filter_append<NOSTORE>(a0, tau[nr], rb + 0, row_end, cur[nr], pbase[nr], pool_s, pool_i);
-                    filter_append<NOSTORE>(a1, tau[nr], rb + 1, row_end, cur[nr], pbase[nr], pool_s, pool_i);
-                    filter_append<NOSTORE>(a2, tau[nr], rb + 2, row_end, cur[nr], pbase[nr], pool_s, pool_i);
-                    filter_append<NOSTORE>(a3, tau[nr], rb + 3, row_end, cur[nr], pbase[nr], pool_s, pool_i);
-                }
-            }
-        }
-    }
-}
-
-template <int VAR>
-__global__ __launch_bounds__(kGemmThreads, 2) void score_filter_kernel(
-    const char* __restrict__ X16, int64_t ldx_b, int64_t row0, int64_t nrows, const char* __restrict__ Q16,
-    int64_t ldq_b, int nqb, int nk, const float* __restrict__ tau_g, float* __restrict__ pool_s,
-    int32_t* __restrict__ pool_i, int32_t* __restrict__ pool_cnt) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    TileCtx c;
-    tile_ctx_init(c);
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int qsub = slot & 7, nsub = slot >> 3;
-    const int slice = xcd * 4 + nsub;
-    const int ntiles = (int)((nrows + kBM - 1) / kBM);
-    const int32_t row_end = (int32_t)(row0 + nrows);
-    const int sub = (slice * 2 + c.wm) * 2 + (c.lane >> 5);
-    f32x16 acc[4][2];
-
-    for (int qb = qsub; qb < nqb; qb += 8) {
-        float tau[2];
-        int cur[2] = {0, 0};
-        uint32_t pbase[2];
-        int64_t qidx[2];
-#pragma unroll
-        for (int nr = 0; nr < 2; ++nr) {
-            qidx[nr] = (int64_t)qb * kBN + c.wn * 64 + nr * 32 + (c.lane & 31);
-            tau[nr] = tau_g[qidx[nr]];
-            pbase[nr] = (uint32_t)((qidx[nr] * kPoolSubs + sub) * kPoolCap);
-        }
-        for (int t = slice; t < ntiles; t += kFusedSlices) {
-            const int64_t trow = row0 + (int64_t)t * kBM;
-            gemm_tile<VAR>(c, X16, ldx_b, trow, Q16, ldq_b, (int64_t)qb * kBN, nk, smem, acc);
-            const int32_t row_lane0 = (int32_t)trow + c.wm * 128 + 4 * (c.lane >> 5);
-            if (!(VAR & 1)) {
-                filter_epilogue(acc, tau, cur, pbase, pool_s, pool_i, row_lane0, row_end);
-            } else {   // ablation: keep the accumulators live without the filter
-#pragma unroll
-                for (int mr = 0; mr < 4; ++mr)
-#pragma unroll
-                    for (int nr = 0; nr < 2; ++nr) asm volatile("" ::"v"(acc[mr][nr]));
-            }
-        }
-#pragma unroll
-        for (int nr = 0; nr < 2; ++nr) pool_cnt[qidx[nr] * kPoolSubs + sub] = cur[nr];
-    }
-}
-
-// ---- second generation: continuous slab stream through the 4-stage LDS ring (gemm_ring.h) ---------------------
-// VAR bit 0: skip the filter epilogue, bit 3: count hits but do not store them, bit 4: tau = +inf  (ablations)
-template <int VAR>
-__global__ __launch_bounds__(kRingThreads, 2) void score_filter_ring_kernel(
-    const char* __restrict__ X16, int64_t ldx_b, int64_t row0, int64_t nrows, const char* __restrict__ Q16,
-    int64_t ldq_b, int nqb, int nk, const float* __restrict__ tau_g, float* __restrict__ pool_s,
-    int32_t* __restrict__ pool_i, int32_t* __restrict__ pool_cnt) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    RingCtx c;
-    ring_ctx_init(c);
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int qsub = slot & 7, nsub = slot >> 3;
-    const int slice = xcd * 4 + nsub;
-    const int ntiles = (int)((nrows + kRBM - 1) / kRBM);
-    const int32_t row_end = (int32_t)(row0 + nrows);
-    const int sub = (slice * 2 + c.wm) * 2 + (c.lane >> 5);
-    const int nq_iter = (nqb > qsub) ? (nqb - qsub + 7) / 8 : 0;
-    const int nt_iter = (ntiles > slice) ? (ntiles - slice + kFusedSlices - 1) / kFusedSlices : 0;
-    const int ntile_total = nq_iter * nt_iter;
-    if (ntile_total == 0) return;
-    const int64_t S = (int64_t)ntile_total * nk;
-
-    // ---- load cursor: slab `issued` goes to ring stage issued % 4.  Past the last slab the cursor stops and the
-    // same slab is re-loaded into stages nobody reads again: the number of loads in flight stays uniform, so one
-    // counted wait serves every iteration.
-    RingSrc sa, sb;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        sa.voff[j] = c.st_row[j] * (int)ldx_b + c.st_col;
-        sb.voff[j] = c.st_row[j] * (int)ldq_b + c.st_col;
-    }
-    int l_q = 0, l_t = 0, l_k = 0;
-    sa.rsrc = ring_make_rsrc(X16 + (row0 + (int64_t)slice * kRBM) * ldx_b, ldx_b);
-    sb.rsrc = ring_make_rsrc(Q16 + (int64_t)qsub * kRBN * ldq_b, ldq_b);
-    int64_t issued = 0;
-    auto issue = [&]() {
-        char* st = smem + (int)(issued & 3) * kRStageBytes;
-        if (!(VAR & 2) || issued < 4) {
-            constexpr int kAuxX = ((VAR & 32) ? 2 : 0) | ((VAR & 512) ? 16 : 0) | ((VAR & 1024) ? 1 : 0);
-            constexpr int kAuxQ = ((VAR & 64) ? 2 : 0) | ((VAR & 512) ? 16 : 0) | ((VAR & 1024) ? 1 : 0);
-            ring_stage_operand_buf<kAuxX>(c, sa, l_k * (kRBK * 2), st);
-            ring_stage_operand_buf<kAuxQ>(c, sb, l_k * (kRBK * 2), st + kROpBytes);
-        }
-        ++issued;
-        if (issued < S) {
-            if (++l_k == nk) {
-                l_k = 0;
-                if (++l_t == nt_iter) {
-                    l_t = 0;
-                    ++l_q;
-                    sb.rsrc = ring_make_rsrc(Q16 + (int64_t)(qsub + l_q * 8) * kRBN * ldq_b, ldq_b);
-                }
-                sa.rsrc = ring_make_rsrc(X16 + (row0 + (int64_t)(slice + l_t * kFusedSlices) * kRBM) * ldx_b, ldx_b);
-            }
-        }
-    };
-    constexpr bool kEarly = (VAR & 2048) != 0;     // experiment: issue the loads BEFORE the slab-closing waits
-    constexpr bool kPrio = (VAR & 4096) != 0;      // experiment: raise wave priority around the MFMA groups
-    issue();
-    issue();
-    issue();
-    if (!kEarly) issue();
-    if (kEarly)
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    // ---- compute side --------------------------------------------------------------------------------------
-    float tau[2];
-    int cur[2] = {0, 0};
-    uint32_t pbase[2];
-    int64_t qidx[2];
-    f32x16 acc[4][2];
-    Frags F, G;
-    ring_read_frags(c, smem, 0, F);
-    G = F;
-    int64_t s = 0;
-
-    // one slab: G <- k-step 1 of slab s; MFMA(F = k-step 0); open slab s+1; F <- k-step 0 of slab s+1; MFMA(G)
-    auto slab = [&]() {
-        if (!(VAR & 4)) {
-            if (!(VAR & 256)) ring_read_frags(c, smem + (int)(s & 3) * kRStageBytes, 1, G);
-            if (kPrio) __builtin_amdgcn_s_setprio(1);
-            ring_mfma(F, acc);
-            if (kPrio) __builtin_amdgcn_s_setprio(0);
-        }
-        __builtin_amdgcn_sched_barrier(0);                   // keep the 8 MFMAs ahead of the waits: they cover them
-        if (kEarly) issue();                                 // slab s+3 -> the stage slab s-1 vacated (barrier B_s passed)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of slab s are complete (WAR on its stage)
-        if (VAR & 2)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // slab s+1 has landed (this thread's part) ...
-        if (!(VAR & 128)) __builtin_amdgcn_s_barrier();      // ... and everybody else's
-        ++s;
-        if (!(VAR & 4)) {
-            if (!(VAR & 256)) ring_read_frags(c, smem + (int)(s & 3) * kRStageBytes, 0, F);
-            if (kPrio) __builtin_amdgcn_s_setprio(1);
-            ring_mfma(G, acc);
-            if (kPrio) __builtin_amdgcn_s_setprio(0);
-        }
-        // the loads go out AFTER the 8 MFMAs are queued: a wave that is back-pressured on VMEM issue (TA FIFO full)
-        // then still has matrix work in the pipe
-        __builtin_amdgcn_sched_barrier(0);
-        if (!kEarly) issue();                                // slab s+3 (or a dummy) -> the stage slab s-1 vacated
-    };
-
-#pragma unroll 1
-    for (int c_q = 0; c_q < nq_iter; ++c_q) {
-#pragma unroll
-        for (int nr = 0; nr < 2; ++nr) {
-            qidx[nr] = (int64_t)(qsub + c_q * 8) * kRBN + c.wn * 64 + nr * 32 + (c.lane & 31);
-            tau[nr] = (VAR & 16) ? INFINITY : ring_launder(tau_g[qidx[nr]]);
-            pbase[nr] = (uint32_t)((qidx[nr] * kPoolSubs + sub) * kPoolCap);
-            cur[nr] = 0;
-        }
-#pragma unroll 1
-        for (int c_t = 0; c_t < nt_iter; ++c_t) {
-            ring_zero(acc);
-#pragma unroll 1
-            for (int kk = 0; kk < nk; ++kk) slab();
-            const int64_t trow = row0 + (int64_t)(slice + c_t * kFusedSlices) * kRBM;
-            const int32_t row_lane0 = (int32_t)trow + c.wm * 128 + 4 * (c.lane >> 5);
-            if (!(VAR & 1)) {
-                filter_epilogue<(VAR & 8) != 0>(acc, tau, cur, pbase, pool_s, pool_i, row_lane0, row_end);
-            } else {
-#pragma unroll
-                for (int mr = 0; mr < 4; ++mr)
-#pragma unroll
-                    for (int nr = 0; nr < 2; ++nr) asm volatile("" ::"v"(acc[mr][nr]));
-            }
-        }
-#pragma unroll
-        for (int nr = 0; nr < 2; ++nr) pool_cnt[qidx[nr] * kPoolSubs + sub] = cur[nr];
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing dummy loads must land before the LDS is released
 }
 
 // ---- third generation: (64*MR) x 256 tile on the ring, A fragments recycled in place (gemm_ring.h) -------------
@@ -266,8 +54,8 @@ __device__ __forceinline__ float max4_raw(float a0, float a1, float a2, float a3
 
 template <int MR, bool NOSTORE>
 __device__ __forceinline__ void filter_epilogue_r(const f32x16 (&acc)[MR][2], const float (&tau)[2], int (&cur)[2],
-                                                  const uint32_t (&pbase)[2], float* __restrict__ pool_s,
-                                                  int32_t* __restrict__ pool_i, int32_t row_lane0, int32_t row_end) {
+                                                  const uint32_t (&pbase)[2], uint32_t nsubs, uint2* __restrict__ pool,
+                                                  int32_t row_lane0, int32_t row_end) {
     // MFMA -> VALU read hazard cover for the inline-asm reads below (32x32x16 bf16: 8 passes, <= 18 wait states)
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
@@ -283,10 +71,10 @@ __device__ __forceinline__ void filter_epilogue_r(const f32x16 (&acc)[MR][2], co
                 const float m = max4_raw(a0, a1, a2, a3);
                 if (m >= tau[nr]) {
                     const int32_t rb = row_lane0 + mr * 32 + 8 * g;
-                    filter_append<NOSTORE>(a0, tau[nr], rb + 0, row_end, cur[nr], pbase[nr], pool_s, pool_i);
-                    filter_append<NOSTORE>(a1, tau[nr], rb + 1, row_end, cur[nr], pbase[nr], pool_s, pool_i);
-                    filter_append<NOSTORE>(a2, tau[nr], rb + 2, row_end, cur[nr], pbase[nr], pool_s, pool_i);
-                    filter_append<NOSTORE>(a3, tau[nr], rb + 3, row_end, cur[nr], pbase[nr], pool_s, pool_i);
+                    filter_append<NOSTORE>(a0, tau[nr], rb + 0, row_end, cur[nr], pbase[nr], nsubs, pool);
+                    filter_append<NOSTORE>(a1, tau[nr], rb + 1, row_end, cur[nr], pbase[nr], nsubs, pool);
+                    filter_append<NOSTORE>(a2, tau[nr], rb + 2, row_end, cur[nr], pbase[nr], nsubs, pool);
+                    filter_append<NOSTORE>(a3, tau[nr], rb + 3, row_end, cur[nr], pbase[nr], nsubs, pool);
                 }
             }
         }
@@ -303,8 +91,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int VAR>
 __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     const char* __restrict__ X16, int64_t ldx_b, int64_t row0, int64_t nrows, const char* __restrict__ Q16,
-    int64_t ldq_b, int nqb, int nk, const float* __restrict__ tau_g, float* __restrict__ pool_s,
-    int32_t* __restrict__ pool_i, int32_t* __restrict__ pool_cnt, int qg_log2) {
+    int64_t ldq_b, int nqb, int nk, const float* __restrict__ tau_g, uint2* __restrict__ pool,
+    int32_t* __restrict__ pool_cnt, int qg_log2) {
     constexpr int MR = 6;
     using Geo = RingGeom<MR>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -409,7 +197,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
         for (int nr = 0; nr < 2; ++nr) {
             qidx[nr] = (int64_t)(qsub + c_q * qg) * kRBN + c.wn * 64 + nr * 32 + (c.lane & 31);
             tau[nr] = (VAR & 16) ? INFINITY : ring_launder(tau_g[qidx[nr]]);
-            pbase[nr] = (uint32_t)((qidx[nr] * nsubs + sub) * kPoolCap);
+            pbase[nr] = (uint32_t)(qidx[nr] * kPoolCap * nsubs + sub);
             cur[nr] = 0;
         }
 #pragma unroll 1
@@ -425,7 +213,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
             const int64_t trow = row0 + (int64_t)(slice + c_t * nslices) * Geo::kBM;
             const int32_t row_lane0 = (int32_t)trow + c.wm * (32 * MR) + 4 * (c.lane >> 5);
             if (!(VAR & 1)) {
-                filter_epilogue_r<MR, (VAR & 8) != 0>(acc, tau, cur, pbase, pool_s, pool_i, row_lane0, row_end);
+                filter_epilogue_r<MR, (VAR & 8) != 0>(acc, tau, cur, pbase, (uint32_t)nsubs, pool, row_lane0, row_end);
             } else {
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr)
@@ -439,100 +227,37 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing dummy loads must land before the LDS is released
 }
 
-static int g_filter_impl = -1;
-static int filter_impl() {
-    if (g_filter_impl < 0) {
-        const char* f = getenv("LDOT_FILTER_IMPL");
-        g_filter_impl = f ? atoi(f) : 3;
-    }
-    return g_filter_impl;
-}
 // index rows per fused tile (the host sizes launches and the row padding of the index with it)
-int fused_tile_rows() { return filter_impl() == 3 ? RingGeom<6>::kBM : kRBM; }
+int fused_tile_rows() { return RingGeom<6>::kBM; }
 
 // query blocks an XCD works on concurrently for a batch of nqb query blocks (power of two <= 8); the fused launch then
 // has 256 / qg row slices and 1024 / qg sub-pools per query
 int fused_query_group(int64_t nq_pad) {
-    if (filter_impl() != 3) return 8;
     const int64_t nqb = nq_pad / kRBN;
     return nqb >= 8 ? 8 : nqb >= 4 ? 4 : nqb >= 2 ? 2 : 1;
 }
 
 int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_t nrows, const void* q16,
-                        int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, float* pool_s,
-                        int32_t* pool_i, int32_t* pool_cnt, hipStream_t st) {
+                        int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, uint2* pool, int32_t* pool_cnt,
+                        hipStream_t st) {
     if (nrows <= 0 || nq_pad <= 0) return LDOT_OK;
-    // LDOT_DEBUG_VARIANT selects an ablation build of the kernel (profiling only; results are then meaningless)
-    // LDOT_FILTER_IMPL: 3 (default) = 384x256 ring kernel, 2 = 256x256 ring kernel, 1 = first-generation two-stage kernel
+    // LDOT_DEBUG_VARIANT selects an ablation build of the kernel (profiling only; results are then meaningless):
+    //   16 tau = +inf (epilogue fast path only), 18 = 16 + no global loads after the prologue, 20 = 16 + no MFMA/ds_read
     static int variant = -1;
-    const int impl = filter_impl();
     if (variant < 0) {
         const char* e = getenv("LDOT_DEBUG_VARIANT");
         variant = e ? atoi(e) : 0;
     }
-    if (impl == 3) {
-        auto rk = score_filter_r6_kernel<0>;
-        if (variant == 16) rk = score_filter_r6_kernel<16>;
-        if (variant == 18) rk = score_filter_r6_kernel<18>;
-        if (variant == 20) rk = score_filter_r6_kernel<20>;
-        LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           RingGeom<6>::kLds));
-        const int qg = fused_query_group(nq_pad);
-        const int qg_log2 = qg == 8 ? 3 : qg == 4 ? 2 : qg == 2 ? 1 : 0;
-        hipLaunchKernelGGL(rk, dim3(256), dim3(kRingThreads), RingGeom<6>::kLds, st, (const char*)x16, ldx_elems * 2,
-                           row0, nrows, (const char*)q16, ldq_elems * 2, (int)(nq_pad / kRBN), dpad / kRBK, tau, pool_s,
-                           pool_i, pool_cnt, qg_log2);
-        LDOT_HIP_CHECK(hipGetLastError());
-        return LDOT_OK;
-    }
-    if (impl == 2) {
-        auto rk = score_filter_ring_kernel<0>;
-        if (variant == 1) rk = score_filter_ring_kernel<1>;
-        if (variant == 16) rk = score_filter_ring_kernel<16>;
-        if (variant == 8) rk = score_filter_ring_kernel<8>;
-        if (variant == 3) rk = score_filter_ring_kernel<3>;
-        if (variant == 5) rk = score_filter_ring_kernel<5>;
-        if (variant == 131) rk = score_filter_ring_kernel<131>;
-        if (variant == 257) rk = score_filter_ring_kernel<257>;
-        if (variant == 261) rk = score_filter_ring_kernel<261>;
-        if (variant == 2048) rk = score_filter_ring_kernel<2048>;
-        if (variant == 4096) rk = score_filter_ring_kernel<4096>;
-        if (variant == 6144) rk = score_filter_ring_kernel<6144>;
-        if (variant == 2049) rk = score_filter_ring_kernel<2049>;
-        if (variant == 4097) rk = score_filter_ring_kernel<4097>;
-        if (variant == 512) rk = score_filter_ring_kernel<512>;
-        if (variant == 1024) rk = score_filter_ring_kernel<1024>;
-        if (variant == 1536) rk = score_filter_ring_kernel<1536>;
-        if (variant == 517) rk = score_filter_ring_kernel<517>;
-        if (variant == 1029) rk = score_filter_ring_kernel<1029>;
-        if (variant == 387) rk = score_filter_ring_kernel<387>;
-        if (variant == 259) rk = score_filter_ring_kernel<259>;
-        if (variant == 135) rk = score_filter_ring_kernel<135>;
-        if (variant == 32) rk = score_filter_ring_kernel<32>;
-        if (variant == 96) rk = score_filter_ring_kernel<96>;
-        if (variant == 37) rk = score_filter_ring_kernel<37>;
-        if (variant == 101) rk = score_filter_ring_kernel<101>;
-        LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, kRingLdsBytes));
-        hipLaunchKernelGGL(rk, dim3(256), dim3(kRingThreads), kRingLdsBytes, st, (const char*)x16, ldx_elems * 2, row0,
-                           nrows, (const char*)q16, ldq_elems * 2, (int)(nq_pad / kRBN), dpad / kRBK, tau, pool_s,
-                           pool_i, pool_cnt);
-        LDOT_HIP_CHECK(hipGetLastError());
-        return LDOT_OK;
-    }
-    auto kern = score_filter_kernel<0>;
-    switch (variant) {
-        case 1: kern = score_filter_kernel<1>; break;
-        case 2: kern = score_filter_kernel<2>; break;
-        case 3: kern = score_filter_kernel<3>; break;
-        case 4: kern = score_filter_kernel<4>; break;
-        case 5: kern = score_filter_kernel<5>; break;
-        case 7: kern = score_filter_kernel<7>; break;
-        default: break;
-    }
-    LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLdsBytes));
-    hipLaunchKernelGGL(kern, dim3(256), dim3(kGemmThreads), kGemmLdsBytes, st, (const char*)x16, ldx_elems * 2, row0,
-                       nrows, (const char*)q16, ldq_elems * 2, (int)(nq_pad / kBN), dpad / kBK, tau, pool_s, pool_i,
-                       pool_cnt);
+    auto rk = score_filter_r6_kernel<0>;
+    if (variant == 16) rk = score_filter_r6_kernel<16>;
+    if (variant == 18) rk = score_filter_r6_kernel<18>;
+    if (variant == 20) rk = score_filter_r6_kernel<20>;
+    LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<6>::kLds));
+    const int qg = fused_query_group(nq_pad);
+    const int qg_log2 = qg == 8 ? 3 : qg == 4 ? 2 : qg == 2 ? 1 : 0;
+    hipLaunchKernelGGL(rk, dim3(256), dim3(kRingThreads), RingGeom<6>::kLds, st, (const char*)x16, ldx_elems * 2, row0,
+                       nrows, (const char*)q16, ldq_elems * 2, (int)(nq_pad / kRBN), dpad / kRBK, tau, pool, pool_cnt,
+                       qg_log2);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

@@ -230,8 +230,7 @@ __global__ __launch_bounds__(256) void parts_to_lists_kernel(const float* __rest
 // pool source: the per-query sub-pools filled by the fused filter kernel; resets the counters afterwards.
 // One wave per query (no cross-wave barriers), small LDS footprint -> many queries resident per CU.
 constexpr int kPoolSelThreads = 64;
-__global__ __launch_bounds__(kPoolSelThreads) void select_pools_kernel(const float* __restrict__ pool_s,
-                                                                       const int32_t* __restrict__ pool_i,
+__global__ __launch_bounds__(kPoolSelThreads) void select_pools_kernel(const uint2* __restrict__ pool,
                                                                        int32_t* __restrict__ pool_cnt, int nsubs,
                                                                        float* __restrict__ list_s,
                                                                        int32_t* __restrict__ list_i, int kp, int cap,
@@ -254,26 +253,26 @@ __global__ __launch_bounds__(kPoolSelThreads) void select_pools_kernel(const flo
     }
     const bool any_over = __any(over);
     sel.load_list(ls, li);
-    const int64_t base = q * (int64_t)nsubs * kPoolCap;
-    // each lane walks nsubs / 64 sub-pools; entries of a sub-pool are contiguous
-    for (int half = 0; half < nsubs / kPoolSelThreads; ++half) {
-        const int sub = half * kPoolSelThreads + threadIdx.x;
-        const int n = cnts[sub];
-        int nmax = n;
+    // entry-major pools: level e of all sub-pools is one contiguous run of 8-byte words -> coalesced reads of the few
+    // levels that are in use (most sub-pools hold 0..3 candidates)
+    int cmax = 0;
+    for (int s = threadIdx.x; s < nsubs; s += kPoolSelThreads) cmax = max(cmax, cnts[s]);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
-        for (int e0 = 0; e0 < nmax; e0 += 4) {
-            sel.reserve(4 * kPoolSelThreads);   // wave-uniform loop (nmax is wave-uniform); compacts only when needed
-            float vs[4];
-            int32_t vi[4];
+    for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o));
+    const uint2* base = pool + q * (int64_t)kPoolCap * nsubs;
+    for (int e = 0; e < cmax; ++e) {
+        for (int s0 = 0; s0 < nsubs; s0 += 4 * kPoolSelThreads) {
+            sel.reserve(4 * kPoolSelThreads);
+            uint2 v[4];
+            bool ok[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const bool ok = e0 + u < n;
-                vs[u] = ok ? pool_s[base + sub * kPoolCap + e0 + u] : 0.f;
-                vi[u] = ok ? pool_i[base + sub * kPoolCap + e0 + u] : 0;
+                const int sidx = s0 + u * kPoolSelThreads + threadIdx.x;
+                ok[u] = sidx < nsubs && e < cnts[sidx];
+                v[u] = ok[u] ? base[(int64_t)e * nsubs + sidx] : make_uint2(0u, 0u);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) sel.push(make_key(vs[u], (uint32_t)vi[u]), e0 + u < n);
+            for (int u = 0; u < 4; ++u) sel.push(make_key(__uint_as_float(v[u].x), v[u].y), ok[u]);
         }
     }
     sel.finish(ls, li, tau ? tau + q : nullptr);
@@ -366,13 +365,12 @@ int launch_parts_to_lists(const float* out_s, const int64_t* out_l, int64_t n, f
     return LDOT_OK;
 }
 
-int launch_select_pools(const float* pool_s, const int32_t* pool_i, const int32_t* pool_cnt, int nsubs, int64_t nq,
-                        float* list_s, int32_t* list_i, int kp, float* tau, int32_t* overflow_flags,
-                        hipStream_t st) {
+int launch_select_pools(const uint2* pool, const int32_t* pool_cnt, int nsubs, int64_t nq, float* list_s,
+                        int32_t* list_i, int kp, float* tau, int32_t* overflow_flags, hipStream_t st) {
     if (nq <= 0) return LDOT_OK;
     const int cap = select_cap(kp, 1024);
-    hipLaunchKernelGGL(select_pools_kernel, dim3((unsigned)nq), dim3(kPoolSelThreads), (size_t)cap * 8, st, pool_s,
-                       pool_i, (int32_t*)pool_cnt, nsubs, list_s, list_i, kp, cap, tau, overflow_flags);
+    hipLaunchKernelGGL(select_pools_kernel, dim3((unsigned)nq), dim3(kPoolSelThreads), (size_t)cap * 8, st, pool,
+                       (int32_t*)pool_cnt, nsubs, list_s, list_i, kp, cap, tau, overflow_flags);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }
