@@ -7,6 +7,7 @@
 // appends those that beat the current k'-th key to an LDS buffer and, only when the buffer could overflow,
 // compacts it with a bitonic sort (LDS, 64-bit compare-exchange) and tightens the threshold.
 #include <float.h>
+#include <stdlib.h>
 
 #include "kernels.h"
 
@@ -15,6 +16,16 @@ namespace ldot {
 constexpr uint64_t kEmptyKey = ~0ull;
 
 __device__ inline uint64_t make_key(float s, uint32_t row) { return ((uint64_t)desc_key(s) << 32) | row; }
+
+// Workgroup-wide sync for the select kernels.  A single-wave workgroup (the pool select) needs no hardware barrier:
+// the LDS executes one wave's operations in issue order, so draining the LDS counter is enough — and an s_barrier per
+// bitonic stage is what dominated that kernel.
+__device__ __forceinline__ void sel_sync() {
+    if (blockDim.x <= 64)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else
+        __syncthreads();
+}
 
 __device__ inline void bitonic_sort_lds(uint64_t* keys, int P) {
     for (int k = 2; k <= P; k <<= 1) {
@@ -29,7 +40,7 @@ __device__ inline void bitonic_sort_lds(uint64_t* keys, int P) {
                     keys[p] = a;
                 }
             }
-            __syncthreads();
+            sel_sync();
         }
     }
 }
@@ -48,7 +59,7 @@ struct Selector {
         cap = cap_;
         tau = kEmptyKey;
         if (threadIdx.x == 0) *count = 0;
-        __syncthreads();
+        sel_sync();
     }
     // Wave-aggregated append: must be called by ALL lanes of a wave together (valid = false for lanes without a
     // candidate).  One LDS atomic per wave per call instead of one per hit.
@@ -66,25 +77,25 @@ struct Selector {
     }
     // sort, truncate to kp, refresh tau.  Must be called by all threads.
     __device__ inline void compact() {
-        __syncthreads();
+        sel_sync();
         const int n = *count;
         int P = 2;
         while (P < n) P <<= 1;
         for (int i = n + threadIdx.x; i < P; i += blockDim.x) keys[i] = kEmptyKey;
-        __syncthreads();
+        sel_sync();
         bitonic_sort_lds(keys, P);
         const int m = n < kp ? n : kp;
         const uint64_t t = (m >= kp) ? keys[kp - 1] : kEmptyKey;
-        __syncthreads();
+        sel_sync();
         if (threadIdx.x == 0) *count = m;
         tau = t;
-        __syncthreads();
+        sel_sync();
     }
     // call (all threads) before streaming up to `upcoming` more candidates (upcoming <= cap - kp)
     __device__ inline void reserve(int upcoming) {
-        __syncthreads();
+        sel_sync();
         const int n = *count;
-        __syncthreads();                              // everyone has read count before anyone pushes again
+        sel_sync();                              // everyone has read count before anyone pushes again
         if (n + upcoming > cap) compact();            // uniform branch
     }
     // The running list is kept sorted (best first, empty slots last): adopt it as keys[0..n) without sorting and
@@ -97,15 +108,76 @@ struct Selector {
             const unsigned long long mask = __ballot(valid);
             if ((threadIdx.x & 63) == 0 && mask) atomicAdd(count, __popcll(mask));
         }
-        __syncthreads();
+        sel_sync();
         const int n = *count;
         tau = (n >= kp) ? keys[kp - 1] : kEmptyKey;
-        __syncthreads();
+        sel_sync();
     }
     __device__ inline void finish(float* ls, int32_t* li, float* tau_out) {
         compact();
         const int n = *count;
         for (int e = threadIdx.x; e < kp; e += blockDim.x) {
+            if (e < n) {
+                const uint64_t k = keys[e];
+                ls[e] = desc_key_to_float((uint32_t)(k >> 32));
+                li[e] = (int32_t)(uint32_t)(k & 0xffffffffu);
+            } else {
+                ls[e] = LDOT_PAD_SCORE;
+                li[e] = -1;
+            }
+        }
+        if (tau_out && threadIdx.x == 0)
+            *tau_out = (n >= kp) ? desc_key_to_float((uint32_t)(keys[kp - 1] >> 32)) : -INFINITY;
+    }
+};
+
+// Single-wave variant of the selector (pool select: one wave per query).  The append counter is a wave-uniform
+// register, appends are ballot/popcount compactions — no LDS atomics, no barriers.
+struct WaveSelector {
+    uint64_t* keys;   // LDS [cap]
+    uint64_t tau;
+    int n, kp, cap;
+
+    __device__ inline void init(uint64_t* k, int kp_, int cap_) {
+        keys = k;
+        kp = kp_;
+        cap = cap_;
+        n = 0;
+        tau = kEmptyKey;
+    }
+    __device__ inline void push(uint64_t key, bool valid) {
+        const bool hit = valid && key < tau;
+        const unsigned long long mask = __ballot(hit);
+        const int lane = threadIdx.x & 63;
+        if (hit) keys[n + __popcll(mask & ((1ull << lane) - 1ull))] = key;
+        n += __popcll(mask);
+    }
+    __device__ inline void compact() {
+        int P = 2;
+        while (P < n) P <<= 1;
+        for (int i = n + threadIdx.x; i < P; i += 64) keys[i] = kEmptyKey;
+        sel_sync();
+        bitonic_sort_lds(keys, P);
+        n = n < kp ? n : kp;
+        tau = (n >= kp) ? keys[kp - 1] : kEmptyKey;
+    }
+    __device__ inline void reserve(int upcoming) {
+        if (n + upcoming > cap) compact();
+    }
+    // the running list is sorted (best first, empty slots last)
+    __device__ inline void load_list(const float* ls, const int32_t* li) {
+        for (int e0 = 0; e0 < kp; e0 += 64) {
+            const int e = e0 + (threadIdx.x & 63);
+            const bool valid = e < kp && li[e] >= 0;
+            if (valid) keys[e] = make_key(ls[e], (uint32_t)li[e]);
+            n += __popcll(__ballot(valid));
+        }
+        sel_sync();
+        tau = (n >= kp) ? keys[kp - 1] : kEmptyKey;
+    }
+    __device__ inline void finish(float* ls, int32_t* li, float* tau_out) {
+        compact();
+        for (int e = threadIdx.x; e < kp; e += 64) {
             if (e < n) {
                 const uint64_t k = keys[e];
                 ls[e] = desc_key_to_float((uint32_t)(k >> 32));
@@ -237,11 +309,10 @@ __global__ __launch_bounds__(kPoolSelThreads) void select_pools_kernel(const uin
                                                                        float* __restrict__ tau,
                                                                        int32_t* __restrict__ overflow) {
     extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
-    __shared__ int count;
     __shared__ int cnts[kPoolSubsMax];
     const int64_t q = blockIdx.x;
-    Selector sel;
-    sel.init(keys, &count, kp, cap);
+    WaveSelector sel;
+    sel.init(keys, kp, cap);
     float* ls = list_s + q * kp;
     int32_t* li = list_i + q * kp;
     bool over = false;
@@ -254,25 +325,32 @@ __global__ __launch_bounds__(kPoolSelThreads) void select_pools_kernel(const uin
     const bool any_over = __any(over);
     sel.load_list(ls, li);
     // entry-major pools: level e of all sub-pools is one contiguous run of 8-byte words -> coalesced reads of the few
-    // levels that are in use (most sub-pools hold 0..3 candidates)
-    int cmax = 0;
-    for (int s = threadIdx.x; s < nsubs; s += kPoolSelThreads) cmax = max(cmax, cnts[s]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o));
+    // levels in use.  Two groups of 64 sub-pools x 4 entry levels per step: 8 independent loads in flight per lane.
     const uint2* base = pool + q * (int64_t)kPoolCap * nsubs;
-    for (int e = 0; e < cmax; ++e) {
-        for (int s0 = 0; s0 < nsubs; s0 += 4 * kPoolSelThreads) {
-            sel.reserve(4 * kPoolSelThreads);
-            uint2 v[4];
-            bool ok[4];
+    for (int s0 = 0; s0 < nsubs; s0 += 2 * kPoolSelThreads) {
+        int c[2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int sidx = s0 + u * kPoolSelThreads + threadIdx.x;
-                ok[u] = sidx < nsubs && e < cnts[sidx];
-                v[u] = ok[u] ? base[(int64_t)e * nsubs + sidx] : make_uint2(0u, 0u);
-            }
+        for (int g = 0; g < 2; ++g) {
+            const int sidx = s0 + g * kPoolSelThreads + threadIdx.x;
+            c[g] = sidx < nsubs ? cnts[sidx] : 0;
+        }
+        int cm = max(c[0], c[1]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) sel.push(make_key(__uint_as_float(v[u].x), v[u].y), ok[u]);
+        for (int o = 32; o > 0; o >>= 1) cm = max(cm, __shfl_xor(cm, o));
+        for (int e0 = 0; e0 < cm; e0 += 4) {
+            sel.reserve(8 * kPoolSelThreads);
+            uint2 v[2][4];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    v[g][u] = (e0 + u < c[g])
+                                  ? base[(int64_t)(e0 + u) * nsubs + s0 + g * kPoolSelThreads + threadIdx.x]
+                                  : make_uint2(0u, 0u);
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sel.push(make_key(__uint_as_float(v[g][u].x), v[g][u].y), e0 + u < c[g]);
         }
     }
     sel.finish(ls, li, tau ? tau + q : nullptr);
@@ -368,7 +446,7 @@ int launch_parts_to_lists(const float* out_s, const int64_t* out_l, int64_t n, f
 int launch_select_pools(const uint2* pool, const int32_t* pool_cnt, int nsubs, int64_t nq, float* list_s,
                         int32_t* list_i, int kp, float* tau, int32_t* overflow_flags, hipStream_t st) {
     if (nq <= 0) return LDOT_OK;
-    const int cap = select_cap(kp, 1024);
+    const int cap = select_cap(kp, 1024);   // a step appends up to 8 x 64 candidates on top of a full list
     hipLaunchKernelGGL(select_pools_kernel, dim3((unsigned)nq), dim3(kPoolSelThreads), (size_t)cap * 8, st, pool,
                        (int32_t*)pool_cnt, nsubs, list_s, list_i, kp, cap, tau, overflow_flags);
     LDOT_HIP_CHECK(hipGetLastError());
