@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round evidence: GPU tests, bench JSON, rocprofv3 kernel stats, PMC passes (no TA_* counters), vendor GEMM reference.
+# usage (GPU box): tools/evidence.sh <tag>   -> gpurun_out/ev_<tag>/
+T=${1:-ev}; O=$GRAFT_REPO_ROOT/gpurun_out/ev_$T; mkdir -p $O
+cd $GRAFT_REPO_ROOT
+timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+timeout 300 python -c 'import __graft_entry__ as g; g.smoke(); print("smoke ok")' > $O/smoke.log 2>&1
+timeout 600 python bench.py --steps 5 --warmup 2 > $O/bench.json 2> $O/bench.err
+timeout 300 python tools/gemm_ref.py > $O/vendor_gemm.txt 2>&1
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/kt
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt -o k --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_profiled.json 2> $O/rocprof.err
+cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
+cd $GRAFT_REPO_ROOT
+for g in "FETCH_SIZE WRITE_SIZE" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES" "TCC_HIT TCC_MISS TCC_REQ"; do
+  bash tools/pmc2.sh "$g" >> $O/pmc.txt 2>&1
+done
+tail -3 $O/pytest_gpu.log; cat $O/smoke.log | tail -1; cat $O/bench.json; cat $O/pmc.txt
