@@ -96,7 +96,9 @@ struct Selector {
         sel_sync();
         const int n = *count;
         sel_sync();                              // everyone has read count before anyone pushes again
-        if (n + upcoming > cap) compact();            // uniform branch
+        // also compact as soon as a first threshold can be had (list not full yet, >= kp keys buffered): sorting 1024
+        // keys now and filtering the rest is cheaper than sorting a full buffer of unfiltered keys later
+        if (n + upcoming > cap || (tau == kEmptyKey && n >= kp)) compact();            // uniform branch
     }
     // The running list is kept sorted (best first, empty slots last): adopt it as keys[0..n) without sorting and
     // take the threshold from its last element.
