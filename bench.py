@@ -58,7 +58,9 @@ def main():
     ap.add_argument('--warm', type=int, default=0, help='dense warm-up rows (0 = library default)')
     ap.add_argument('--force-sharded', action='store_true', help='run the sharded code path even with one rank')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-queries', type=int, default=256)
+    ap.add_argument('--cpu-sample-queries', type=int, default=2048)
+    ap.add_argument('--normalised', action='store_true',
+                    help='second series (SURVEY 8d): rows and queries scaled to unit L2 norm (cosine scores)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -93,6 +95,9 @@ def main():
     if sharded:
         dist.all_reduce(q_all)
     q_all += 0.5 * eps
+    if args.normalised:
+        x_local = torch.nn.functional.normalize(x_local, dim=1)
+        q_all = torch.nn.functional.normalize(q_all, dim=1)
     mode = {'auto': L.MODE_AUTO, 'dense': L.MODE_DENSE, 'fused': L.MODE_FUSED}[args.mode]
 
     if not sharded:
@@ -186,7 +191,9 @@ def main():
         'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
         'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': f'synthetic {N} x {D} bf16 index (fp32 master for exact re-score), {Q} queries, '
-                               f'top-{K}, un-normalised inner product (BASELINE.json configs[3] / SURVEY S1)',
+                               f'top-{K}, ' + ('unit-L2-normalised rows and queries (cosine; SURVEY S1 second series)'
+                                               if args.normalised else
+                                               'un-normalised inner product (BASELINE.json configs[3] / SURVEY S1)'),
                    'index_rows': N, 'queries': Q, 'dim': D, 'k': K, 'search_mode': args.mode,
                    'parallelism': f'row-sharded index x{world}' if world > 1 else 'single GPU'},
         **recall, 'results_sorted': sorted_ok,
@@ -218,31 +225,47 @@ def main():
         out['pcie_inclusive'] = {'value': Q * 2 / (time.perf_counter() - t0), 'unit': 'queries/s',
                                  'note': 'fp32 queries in pageable host memory -> scores+labels in host memory'}
     if not args.no_cpu_baseline and not sharded:
-        out['cpu_baseline'] = cpu_baseline(x_local, q_all, K, args.cpu_sample_queries)
+        out['cpu_baseline'], out['parity_vs_cpu_fp32'] = cpu_baseline(x_local, q_all, K, args.cpu_sample_queries,
+                                                                      s_np, l_np)
     print(json.dumps(out), flush=True)
     if sharded:
         dist.destroy_process_group()
 
 
-def cpu_baseline(x_dev, q_dev, k, nsample):
+def cpu_baseline(x_dev, q_dev, k, nsample, gpu_scores, gpu_labels):
     """The reference's CPU scorer is faiss IndexFlatIP (fp32 sgemm + heap); faiss is not installable here, so the
     timed leg is the oracle's restatement of the same structure (oracle.search_fast: blocked fp32 sgemm +
-    selection) on a bounded sample: the first `nsample` queries against the FULL index, all host cores."""
+    selection) on a bounded sample: the first `nsample` queries against the FULL index, all host cores, plus a
+    one-thread figure on a smaller sample.  The same sample is the parity check of the GPU results (SURVEY 8d:
+    rank-1 mismatches and max |delta score| against the fp32 CPU path)."""
     from oracle import oracle_np as O      # checker / baseline only — never on the product path
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
-    except Exception:
-        cores = os.cpu_count() or 1
+    from threadpoolctl import threadpool_info, threadpool_limits
+    cores = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
     x = x_dev.cpu().numpy()
     q = q_dev[:nsample].cpu().numpy()
     O.search_fast(q[:8], x[:4096], k)                      # warm the BLAS threads
     t0 = time.perf_counter()
-    O.search_fast(q, x, k)
+    cs, cl = O.search_fast(q, x, k)
     dt = time.perf_counter() - t0
-    return {'value': len(q) / dt, 'unit': 'queries/s', 'cores': int(cores), 'kind': 'port',
+    n1 = min(32, len(q))
+    with threadpool_limits(limits=1):
+        t1 = time.perf_counter()
+        O.search_fast(q[:n1], x, k)
+        dt1 = time.perf_counter() - t1
+    base = {'value': len(q) / dt, 'unit': 'queries/s', 'cores': int(cores), 'kind': 'port',
             'sample': f'first {len(q)} queries x full {x.shape[0]} x {x.shape[1]} fp32 index, top-{k}, '
-                      f'oracle.search_fast (blocked numpy sgemm + argpartition), 1 run after warm-up, {dt:.2f} s'}
+                      f'oracle.search_fast (blocked numpy sgemm + argpartition), 1 run after warm-up, {dt:.2f} s',
+            'value_1thread': n1 / dt1, 'sample_1thread': f'first {n1} queries, 1 BLAS thread, {dt1:.2f} s'}
+    gs, gl = gpu_scores[:len(q)], gpu_labels[:len(q)]
+    scale = float(np.abs(cs).max()) or 1.0
+    # positions where the label differs but the two fp32 scores agree to 1e-4 relative are summation-order ties
+    diff = gl != cl
+    tie = np.abs(gs.astype(np.float64) - cs.astype(np.float64)) <= 1e-4 * scale
+    parity = {'queries': int(len(q)), 'rank1_mismatches': int((gl[:, 0] != cl[:, 0]).sum()),
+              'topk_label_mismatches': int(diff.sum()), 'topk_label_mismatches_not_ties': int((diff & ~tie).sum()),
+              'max_abs_dscore': float(np.abs(gs.astype(np.float64) - cs.astype(np.float64)).max()),
+              'score_scale': scale, 'tolerance': '1e-3 on scores, exact rank-1 (BASELINE.json north_star)'}
+    return base, parity
 
 
 if __name__ == '__main__':

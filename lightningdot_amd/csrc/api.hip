@@ -69,6 +69,9 @@ struct ldot_index {
     DevBuf w_stage, w_q32, w_q16, w_ls, w_li, w_S, w_outs, w_outl, w_tau, w_pool, w_pool_cnt, w_over;
     DevBuf w_part_s, w_part_l, w_mrg_s, w_mrg_l;
     int64_t stats[4] = {0, 0, 0, 0};
+    // the sub-pool counters and overflow flags are all-zero between searches (the pool select resets the counters it
+    // reads); they are cleared only after a (re)allocation or an aborted / overflowed search
+    bool pools_clean = false;
 };
 
 static int index_reserve(ldot_index* ix, int64_t rows, hipStream_t st) {
@@ -215,7 +218,7 @@ int ldot_index_add(ldot_index_t* ix, const void* rows, int64_t n, int dtype, int
         LDOT_HIP_CHECK(hipMemcpyAsync(ix->w_stage.p, rows, bytes, hipMemcpyHostToDevice, st));
         src = ix->w_stage.p;
     }
-    rc = launch_convert_rows(src, dtype, ix->d, n, ix->d, ix->dpad, normalize, ix->x32 + ix->ntotal * ix->dpad,
+    rc = launch_convert_rows(src, dtype, ix->d, n, n, ix->d, ix->dpad, normalize, ix->x32 + ix->ntotal * ix->dpad,
                              ix->x16 + ix->ntotal * ix->dpad, st);
     if (rc) return rc;
     if (mem == LDOT_HOST) LDOT_HIP_CHECK(hipStreamSynchronize(st));   // staging buffer is reused by the next call
@@ -374,15 +377,21 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
     if ((rc = dense_scan_all(ix, nq, 0, warm, kp, tau, st))) return rc;
     if (warm >= ix->ntotal) return LDOT_OK;
     if ((rc = ix->w_pool.ensure((size_t)nq_pad * nsubs * kPoolCap * 8))) return rc;
-    if ((rc = ix->w_pool_cnt.ensure((size_t)nq_pad * nsubs * 4))) return rc;
-    if ((rc = ix->w_over.ensure((size_t)nq_pad * 4))) return rc;
-    LDOT_HIP_CHECK(hipMemsetAsync(ix->w_over.p, 0, (size_t)nq_pad * 4, st));
-    LDOT_HIP_CHECK(hipMemsetAsync(ix->w_pool_cnt.p, 0, (size_t)nq_pad * nsubs * 4, st));
-    if (nq_pad > nq)   // pad queries never produce candidates
-        LDOT_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(tau + nq), 0x7f800000, (size_t)(nq_pad - nq), st));
+    const size_t cnt_bytes = (size_t)nq_pad * nsubs * 4, over_bytes = (size_t)nq_pad * 4;
+    if (cnt_bytes > ix->w_pool_cnt.bytes || over_bytes > ix->w_over.bytes) ix->pools_clean = false;
+    if ((rc = ix->w_pool_cnt.ensure(cnt_bytes))) return rc;
+    if ((rc = ix->w_over.ensure(over_bytes))) return rc;
+    if (!ix->pools_clean) {
+        LDOT_HIP_CHECK(hipMemsetAsync(ix->w_over.p, 0, ix->w_over.bytes, st));
+        LDOT_HIP_CHECK(hipMemsetAsync(ix->w_pool_cnt.p, 0, ix->w_pool_cnt.bytes, st));
+    }
+    ix->pools_clean = false;   // until this scan has completed
+    // (the pad queries' thresholds are +inf since init_lists: they never produce candidates)
+    // few query blocks: admissions are cheap, launches are not -> let the launch length grow up to the pool bound
+    const int64_t growth = nq_pad <= kBM ? std::max<int64_t>(ix->growth_pct, 1600) : ix->growth_pct;
     int64_t r = warm;
     while (r < ix->ntotal) {
-        int64_t len = std::min<int64_t>(r * ix->growth_pct / 100, r * 1024 / kp);
+        int64_t len = std::min<int64_t>(r * growth / 100, r * 1024 / kp);
         len = std::max<int64_t>(len, bm * nslices);
         len = round_up(len, bm);
         len = std::min(len, ix->ntotal - r);
@@ -407,6 +416,7 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
     for (int32_t v : over) n_over += (v != 0);
     ix->stats[1] = n_over;
     *overflowed = n_over > 0;
+    ix->pools_clean = n_over == 0;   // the counters were reset by the pool selects; flags are zero unless set
     return LDOT_OK;
 }
 
@@ -430,8 +440,10 @@ int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dty
     if ((rc = ix->w_ls.ensure((size_t)nq_pad * kp * 4))) return rc;
     if ((rc = ix->w_li.ensure((size_t)nq_pad * kp * 4))) return rc;
     if ((rc = ix->w_tau.ensure((size_t)nq_pad * 4))) return rc;
-    if ((rc = ix->w_outs.ensure((size_t)nq * k * 4))) return rc;
-    if ((rc = ix->w_outl.ensure((size_t)nq * k * 8))) return rc;
+    if (out_mem == LDOT_HOST) {
+        if ((rc = ix->w_outs.ensure((size_t)nq * k * 4))) return rc;
+        if ((rc = ix->w_outl.ensure((size_t)nq * k * 8))) return rc;
+    }
 
     // ingest queries -> fp32 (exact re-score operand) + bf16 (MFMA operand); pad rows of the last tile are zero
     const void* src = queries;
@@ -441,14 +453,11 @@ int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dty
         LDOT_HIP_CHECK(hipMemcpyAsync(ix->w_stage.p, queries, bytes, hipMemcpyHostToDevice, st));
         src = ix->w_stage.p;
     }
-    if (nq_pad > nq) {
-        LDOT_HIP_CHECK(hipMemsetAsync((float*)ix->w_q32.p + nq * ix->dpad, 0, (size_t)(nq_pad - nq) * ix->dpad * 4, st));
-        LDOT_HIP_CHECK(hipMemsetAsync((uint16_t*)ix->w_q16.p + nq * ix->dpad, 0, (size_t)(nq_pad - nq) * ix->dpad * 2, st));
-    }
-    if ((rc = launch_convert_rows(src, dtype, ix->d, nq, ix->d, ix->dpad, normalize, (float*)ix->w_q32.p,
+    if ((rc = launch_convert_rows(src, dtype, ix->d, nq, nq_pad, ix->d, ix->dpad, normalize, (float*)ix->w_q32.p,
                                   (uint16_t*)ix->w_q16.p, st)))
         return rc;
-    if ((rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, st))) return rc;
+    if ((rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, (float*)ix->w_tau.p, nq, nq_pad, st)))
+        return rc;
 
     if (ix->ntotal > 0) {
         bool fused = ix->mode == LDOT_MODE_FUSED || (ix->mode == LDOT_MODE_AUTO && ix->ntotal >= 32768);
@@ -456,19 +465,23 @@ int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dty
             bool overflowed = false;
             if ((rc = fused_scan(ix, nq, nq_pad, kp, st, &overflowed))) return rc;
             if (overflowed) {   // adversarial row order: redo everything with the always-correct dense path
-                if ((rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, st))) return rc;
+                if ((rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, nullptr, 0, 0, st)))
+                    return rc;
                 fused = false;
             }
         }
         if (!fused && (rc = dense_scan_all(ix, nq, 0, ix->ntotal, kp, nullptr, st))) return rc;
     }
+    // device outputs are written by the re-score kernel directly; host outputs go through the workspace
+    float* dst_s = out_mem == LDOT_DEVICE ? out_scores : (float*)ix->w_outs.p;
+    int64_t* dst_l = out_mem == LDOT_DEVICE ? out_labels : (int64_t*)ix->w_outl.p;
     if ((rc = launch_rescore((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, nq,
-                             (const float*)ix->w_ls.p, (const int32_t*)ix->w_li.p, kp, k, ix->rescore,
-                             (float*)ix->w_outs.p, (int64_t*)ix->w_outl.p, st)))
+                             (const float*)ix->w_ls.p, (const int32_t*)ix->w_li.p, kp, k, ix->rescore, dst_s, dst_l, st)))
         return rc;
-    const hipMemcpyKind kind = out_mem == LDOT_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-    LDOT_HIP_CHECK(hipMemcpyAsync(out_scores, ix->w_outs.p, (size_t)nq * k * 4, kind, st));
-    LDOT_HIP_CHECK(hipMemcpyAsync(out_labels, ix->w_outl.p, (size_t)nq * k * 8, kind, st));
+    if (out_mem == LDOT_HOST) {
+        LDOT_HIP_CHECK(hipMemcpyAsync(out_scores, dst_s, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
+        LDOT_HIP_CHECK(hipMemcpyAsync(out_labels, dst_l, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
+    }
     if (out_mem == LDOT_HOST || mem == LDOT_HOST) LDOT_HIP_CHECK(hipStreamSynchronize(st));
     prof_collect(ix, st);
     return LDOT_OK;
@@ -572,7 +585,7 @@ int ldot_cls_pool(const void* seq, int dtype, int64_t B, int64_t stride_b, int64
                   void* out_bf16, void* stream) {
     LDOT_REQUIRE(seq != nullptr && (out_f32 || out_bf16), LDOT_EINVAL, "NULL buffer");
     LDOT_REQUIRE(B >= 0 && D > 0 && D <= 65536 && stride_b >= D, LDOT_EINVAL, "bad shape");
-    return launch_convert_rows(seq, dtype, stride_b, B, (int)D, (int)D, normalize, out_f32, (uint16_t*)out_bf16,
+    return launch_convert_rows(seq, dtype, stride_b, B, B, (int)D, (int)D, normalize, out_f32, (uint16_t*)out_bf16,
                                (hipStream_t)stream);
 }
 

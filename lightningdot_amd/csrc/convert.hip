@@ -15,12 +15,19 @@ __device__ inline float load_elem(const void* p, int64_t i) {
 
 template <int DT>
 __global__ __launch_bounds__(256) void convert_rows_kernel(const void* __restrict__ src, int64_t ld_src, int64_t n,
-                                                           int d, int dpad, int normalize,
+                                                           int64_t n_pad, int d, int dpad, int normalize,
                                                            float* __restrict__ dst32,
                                                            uint16_t* __restrict__ dst16) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n) return;
+    if (row >= n_pad) return;
+    if (row >= n) {   // pad rows of the last query tile: zeros
+        for (int c = lane; c < dpad; c += 64) {
+            if (dst32) dst32[row * dpad + c] = 0.f;
+            if (dst16) dst16[row * dpad + c] = 0;
+        }
+        return;
+    }
     const int64_t so = row * ld_src;
     float scale = 1.f;
     if (normalize) {
@@ -46,21 +53,22 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(const void* __restric
     }
 }
 
-int launch_convert_rows(const void* src, int dtype, int64_t ld_src, int64_t n, int d, int dpad, int normalize,
-                        float* dst32, uint16_t* dst16, hipStream_t st) {
-    if (n <= 0) return LDOT_OK;
-    const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+int launch_convert_rows(const void* src, int dtype, int64_t ld_src, int64_t n, int64_t n_pad, int d, int dpad,
+                        int normalize, float* dst32, uint16_t* dst16, hipStream_t st) {
+    if (n_pad < n) n_pad = n;
+    if (n_pad <= 0) return LDOT_OK;
+    const dim3 grid((unsigned)((n_pad + 3) / 4)), block(256);
     switch (dtype) {
         case LDOT_F32:
-            hipLaunchKernelGGL(convert_rows_kernel<LDOT_F32>, grid, block, 0, st, src, ld_src, n, d, dpad, normalize,
+            hipLaunchKernelGGL(convert_rows_kernel<LDOT_F32>, grid, block, 0, st, src, ld_src, n, n_pad, d, dpad, normalize,
                                dst32, dst16);
             break;
         case LDOT_BF16:
-            hipLaunchKernelGGL(convert_rows_kernel<LDOT_BF16>, grid, block, 0, st, src, ld_src, n, d, dpad, normalize,
+            hipLaunchKernelGGL(convert_rows_kernel<LDOT_BF16>, grid, block, 0, st, src, ld_src, n, n_pad, d, dpad, normalize,
                                dst32, dst16);
             break;
         case LDOT_F16:
-            hipLaunchKernelGGL(convert_rows_kernel<LDOT_F16>, grid, block, 0, st, src, ld_src, n, d, dpad, normalize,
+            hipLaunchKernelGGL(convert_rows_kernel<LDOT_F16>, grid, block, 0, st, src, ld_src, n, n_pad, d, dpad, normalize,
                                dst32, dst16);
             break;
         default:

@@ -16,16 +16,17 @@ constexpr int kPoolCap = 32;
 constexpr int kPoolSubsMax = 1024;   // query-group width 1: 256 row slices x 4 lanes
 
 // rows: convert n rows of `dtype` (row stride ld_src elements, d valid columns) into the padded fp32 master copy
-// and/or its bf16 shadow (row stride dpad, zero padded); optional L2 normalisation.
-int launch_convert_rows(const void* src, int dtype, int64_t ld_src, int64_t n, int d, int dpad, int normalize,
-                        float* dst32, uint16_t* dst16, hipStream_t st);
+// and/or its bf16 shadow (row stride dpad, zero padded); optional L2 normalisation.  Rows [n, n_pad) are zero-filled.
+int launch_convert_rows(const void* src, int dtype, int64_t ld_src, int64_t n, int64_t n_pad, int d, int dpad,
+                        int normalize, float* dst32, uint16_t* dst16, hipStream_t st);
 
 int launch_score_dense(const void* q16, int64_t ldq_elems, int64_t nq_pad, const void* x16, int64_t ldx_elems,
                        int64_t xrow0, int64_t nrows_pad, int dpad, float* S, int64_t lds_elems, int64_t nq_valid,
                        hipStream_t st);
 
 // lists: [nq][kp] fp32 scores + int32 rows, kept sorted (score desc, row asc); empty slots have row -1.
-int launch_init_lists(float* list_s, int32_t* list_i, int64_t n, hipStream_t st);
+// also initialises the admission thresholds when tau != nullptr: -inf for queries < nq, +inf for the pad queries
+int launch_init_lists(float* list_s, int32_t* list_i, int64_t n, float* tau, int64_t nq, int64_t nq_pad, hipStream_t st);
 int launch_select_dense(const float* S, int64_t lds_elems, int64_t nq, int64_t ncols, int64_t idx_base,
                         float* list_s, int32_t* list_i, int kp, float* tau, hipStream_t st);
 // segmented variant for few queries x many rows: grid (nq, nseg); every (query, segment) writes an independent partial

@@ -39,31 +39,50 @@ __global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __rest
     int P = 2;
     while (P < kp) P <<= 1;
     for (int e = kp + threadIdx.x; e < P; e += kRsThreads) keys[e] = ~0ull;
-    for (int e = wave; e < kp; e += kRsThreads / 64) {
-        const int32_t r = list_i[q * kp + e];
-        uint64_t key = ~0ull;
-        if (r >= 0) {
-            float s;
-            if (do_rescore) {
-                const float* xr = x32 + (int64_t)r * ldx;
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-                for (int c = lane * 4; c < dpad; c += 256) {
-                    const f32x4 xv = *(const f32x4*)(xr + c);
-                    const f32x4 qv = *(const f32x4*)(qrow + c);
-                    a0 = fmaf(xv[0], qv[0], a0);
-                    a1 = fmaf(xv[1], qv[1], a1);
-                    a2 = fmaf(xv[2], qv[2], a2);
-                    a3 = fmaf(xv[3], qv[3], a3);
-                }
-                s = (a0 + a1) + (a2 + a3);
+    // four candidates per wave iteration: their row gathers are independent, so 4x the loads are in flight; the
+    // arithmetic of one candidate (4 fmaf chains over the columns lane*4 + 256*i, pairwise sum, xor-shuffle tree) does
+    // not depend on the grouping
+    constexpr int U = 4;
+    for (int e0 = wave * U; e0 < kp; e0 += (kRsThreads / 64) * U) {
+        int32_t r[U];
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            } else {
-                s = list_s[q * kp + e];
+        for (int u = 0; u < U; ++u) r[u] = (e0 + u < kp) ? list_i[q * kp + e0 + u] : -1;
+        float s[U];
+        if (do_rescore) {
+            float acc[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u][0] = acc[u][1] = acc[u][2] = acc[u][3] = 0.f;
+            for (int c = lane * 4; c < dpad; c += 256) {
+                const f32x4 qv = *(const f32x4*)(qrow + c);
+                f32x4 xv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {   // r[u] is wave-uniform; empty slots (and an empty index) load nothing
+                    xv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (r[u] >= 0) xv[u] = *(const f32x4*)(x32 + (int64_t)r[u] * ldx + c);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    acc[u][0] = fmaf(xv[u][0], qv[0], acc[u][0]);
+                    acc[u][1] = fmaf(xv[u][1], qv[1], acc[u][1]);
+                    acc[u][2] = fmaf(xv[u][2], qv[2], acc[u][2]);
+                    acc[u][3] = fmaf(xv[u][3], qv[3], acc[u][3]);
+                }
             }
-            key = ((uint64_t)desc_key(s) << 32) | (uint32_t)r;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                s[u] = (acc[u][0] + acc[u][1]) + (acc[u][2] + acc[u][3]);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) s[u] += __shfl_xor(s[u], o);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) s[u] = (r[u] >= 0) ? list_s[q * kp + e0 + u] : 0.f;
         }
-        if (lane == 0) keys[e] = key;
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (e0 + u < kp) keys[e0 + u] = (r[u] >= 0) ? (((uint64_t)desc_key(s[u]) << 32) | (uint32_t)r[u]) : ~0ull;
+        }
     }
     __syncthreads();
     bitonic_sort_lds_rs(keys, P);

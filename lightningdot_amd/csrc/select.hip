@@ -9,6 +9,8 @@
 #include <float.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace ldot {
@@ -194,12 +196,14 @@ struct WaveSelector {
     }
 };
 
-__global__ __launch_bounds__(kSelThreads) void init_lists_kernel(float* ls, int32_t* li, int64_t n) {
+__global__ __launch_bounds__(kSelThreads) void init_lists_kernel(float* ls, int32_t* li, int64_t n, float* tau,
+                                                                 int64_t nq, int64_t nq_pad) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         ls[i] = LDOT_PAD_SCORE;
         li[i] = -1;
     }
+    if (tau && i < nq_pad) tau[i] = i < nq ? -INFINITY : INFINITY;
 }
 
 // LDS budget of a select launch: cap 64-bit keys (power of two, >= 2 * kp so a full list plus a segment fits)
@@ -224,9 +228,9 @@ __global__ __launch_bounds__(kSelThreads) void select_dense_kernel(const float* 
     int32_t* li = list_i + q * kp;
     sel.load_list(ls, li);
     const float* row = S + q * lds_elems;
-    // a segment = 1024 columns (4 per thread) <= cap - kp
-    for (int64_t c0 = 0; c0 < ncols; c0 += 4 * kSelThreads) {
-        sel.reserve(4 * kSelThreads);
+    // a segment = 1024 columns (4 per thread) <= cap - kp; the next segment's scores are fetched before the current
+    // one is filtered (one WG per query: the load latency would otherwise be exposed once per segment)
+    auto fetch = [&](int64_t c0) {
         const int64_t c = c0 + threadIdx.x * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (c + 3 < ncols) {
@@ -235,6 +239,14 @@ __global__ __launch_bounds__(kSelThreads) void select_dense_kernel(const float* 
             for (int e = 0; e < 4; ++e)
                 if (c + e < ncols) v[e] = row[c + e];
         }
+        return v;
+    };
+    f32x4 vn = fetch(0);
+    for (int64_t c0 = 0; c0 < ncols; c0 += 4 * kSelThreads) {
+        const f32x4 v = vn;
+        if (c0 + 4 * kSelThreads < ncols) vn = fetch(c0 + 4 * kSelThreads);
+        sel.reserve(4 * kSelThreads);
+        const int64_t c = c0 + threadIdx.x * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) sel.push(make_key(v[e], (uint32_t)(idx_base + c + e)), c + e < ncols);
     }
@@ -359,6 +371,58 @@ __global__ __launch_bounds__(kPoolSelThreads) void select_pools_kernel(const uin
     if (threadIdx.x == 0 && any_over) overflow[q] = 1;
 }
 
+// Few queries (<= one query block, the serving shape): one 256-thread workgroup per query instead of one wave, so that
+// the counters and entry levels of 512 sub-pools are in flight per step (the one-wave walk is a chain of dependent
+// global round trips when there is nothing else on the chip to hide them).
+__global__ __launch_bounds__(kSelThreads) void select_pools_block_kernel(const uint2* __restrict__ pool,
+                                                                         int32_t* __restrict__ pool_cnt, int nsubs,
+                                                                         float* __restrict__ list_s,
+                                                                         int32_t* __restrict__ list_i, int kp, int cap,
+                                                                         float* __restrict__ tau,
+                                                                         int32_t* __restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
+    __shared__ int count;
+    const int64_t q = blockIdx.x;
+    Selector sel;
+    sel.init(keys, &count, kp, cap);
+    float* ls = list_s + q * kp;
+    int32_t* li = list_i + q * kp;
+    sel.load_list(ls, li);
+    const uint2* base = pool + q * (int64_t)kPoolCap * nsubs;
+    bool over = false;
+    for (int s0 = 0; s0 < nsubs; s0 += 2 * kSelThreads) {
+        int c[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int sidx = s0 + g * kSelThreads + threadIdx.x;
+            int v = 0;
+            if (sidx < nsubs) {
+                v = pool_cnt[q * (int64_t)nsubs + sidx];
+                pool_cnt[q * (int64_t)nsubs + sidx] = 0;
+            }
+            over |= v > kPoolCap;
+            c[g] = v < kPoolCap ? v : kPoolCap;
+        }
+        const int cm = max(c[0], c[1]);
+        for (int e0 = 0; __syncthreads_or(cm > e0); e0 += 2) {
+            sel.reserve(4 * kSelThreads);
+            uint2 v[2][2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    v[g][u] = (e0 + u < c[g]) ? base[(int64_t)(e0 + u) * nsubs + s0 + g * kSelThreads + threadIdx.x]
+                                              : make_uint2(0u, 0u);
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) sel.push(make_key(__uint_as_float(v[g][u].x), v[g][u].y), e0 + u < c[g]);
+        }
+    }
+    sel.finish(ls, li, tau ? tau + q : nullptr);
+    if (__syncthreads_or(over) && threadIdx.x == 0) overflow[q] = 1;
+}
+
 // explicit lists source (sharded merge): parts laid out [nparts][nq][k_in], int64 labels (< 2^32-1), -1 = empty
 __global__ __launch_bounds__(kSelThreads) void select_lists_kernel(const float* __restrict__ cand_s,
                                                                    const int64_t* __restrict__ cand_l,
@@ -399,9 +463,11 @@ __global__ __launch_bounds__(kSelThreads) void select_lists_kernel(const float* 
     }
 }
 
-int launch_init_lists(float* list_s, int32_t* list_i, int64_t n, hipStream_t st) {
-    if (n <= 0) return LDOT_OK;
-    hipLaunchKernelGGL(init_lists_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, list_s, list_i, n);
+int launch_init_lists(float* list_s, int32_t* list_i, int64_t n, float* tau, int64_t nq, int64_t nq_pad, hipStream_t st) {
+    const int64_t m = std::max(n, tau ? nq_pad : (int64_t)0);
+    if (m <= 0) return LDOT_OK;
+    hipLaunchKernelGGL(init_lists_kernel, dim3((unsigned)((m + kSelThreads - 1) / kSelThreads)), dim3(kSelThreads), 0, st,
+                       list_s, list_i, n, tau, nq, nq_pad);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }
@@ -448,6 +514,13 @@ int launch_parts_to_lists(const float* out_s, const int64_t* out_l, int64_t n, f
 int launch_select_pools(const uint2* pool, const int32_t* pool_cnt, int nsubs, int64_t nq, float* list_s,
                         int32_t* list_i, int kp, float* tau, int32_t* overflow_flags, hipStream_t st) {
     if (nq <= 0) return LDOT_OK;
+    if (nq <= 256) {   // few queries: block-per-query walk
+        const int bcap = select_cap(kp, 2048);   // a step appends up to 4 x 256 candidates on top of a full list
+        hipLaunchKernelGGL(select_pools_block_kernel, dim3((unsigned)nq), dim3(kSelThreads), (size_t)bcap * 8, st, pool,
+                           (int32_t*)pool_cnt, nsubs, list_s, list_i, kp, bcap, tau, overflow_flags);
+        LDOT_HIP_CHECK(hipGetLastError());
+        return LDOT_OK;
+    }
     const int cap = select_cap(kp, 1024);   // a step appends up to 8 x 64 candidates on top of a full list
     hipLaunchKernelGGL(select_pools_kernel, dim3((unsigned)nq), dim3(kPoolSelThreads), (size_t)cap * 8, st, pool,
                        (int32_t*)pool_cnt, nsubs, list_s, list_i, kp, cap, tau, overflow_flags);
