@@ -395,6 +395,7 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
         len = std::max<int64_t>(len, bm * nslices);
         len = round_up(len, bm);
         len = std::min(len, ix->ntotal - r);
+        if (ix->ntotal - r - len < len / 4) len = ix->ntotal - r;   // no short tail launch (the pool bound has that slack)
         prof_begin(ix, st, 2.0 * nq * len * ix->d,
                    (double)len * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * kp * 8);
         rc = launch_score_filter(ix->x16, ix->dpad, r, len, ix->w_q16.p, ix->dpad, nq_pad, ix->dpad, tau,

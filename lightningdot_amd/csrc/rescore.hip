@@ -2,29 +2,12 @@
 // The reference's scorer is fp32 end to end (faiss IndexFlatIP, dvl/indexer/faiss_indexers.py:83); candidates
 // come from the bf16 MFMA pass with a safety margin (k' > k) and every reported score is recomputed here from
 // the fp32 master copy of the rows, which is what makes rank order and scores match the fp32 reference.
+#include "bitonic.h"
 #include "kernels.h"
 
 namespace ldot {
 
 constexpr int kRsThreads = 256;
-
-__device__ inline void bitonic_sort_lds_rs(uint64_t* keys, int P) {
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < (P >> 1); t += kRsThreads) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int p = i | j;
-                const bool asc = ((i & k) == 0);
-                const uint64_t a = keys[i], b = keys[p];
-                if ((a > b) == asc) {
-                    keys[i] = b;
-                    keys[p] = a;
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
 
 __global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __restrict__ q32, int64_t ldq,
                                                              const float* __restrict__ x32, int64_t ldx, int dpad,
@@ -85,7 +68,7 @@ __global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __rest
         }
     }
     __syncthreads();
-    bitonic_sort_lds_rs(keys, P);
+    bitonic_sort_lds(keys, P);
     for (int e = threadIdx.x; e < k; e += kRsThreads) {
         const uint64_t key = (e < P) ? keys[e] : ~0ull;
         if (key != ~0ull) {

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 
+#include "bitonic.h"
 #include "kernels.h"
 
 namespace ldot {
@@ -27,24 +28,6 @@ __device__ __forceinline__ void sel_sync() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     else
         __syncthreads();
-}
-
-__device__ inline void bitonic_sort_lds(uint64_t* keys, int P) {
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int p = i | j;
-                const bool asc = ((i & k) == 0);
-                const uint64_t a = keys[i], b = keys[p];
-                if ((a > b) == asc) {
-                    keys[i] = b;
-                    keys[p] = a;
-                }
-            }
-            sel_sync();
-        }
-    }
 }
 
 struct Selector {
@@ -228,27 +211,31 @@ __global__ __launch_bounds__(kSelThreads) void select_dense_kernel(const float* 
     int32_t* li = list_i + q * kp;
     sel.load_list(ls, li);
     const float* row = S + q * lds_elems;
-    // a segment = 1024 columns (4 per thread) <= cap - kp; the next segment's scores are fetched before the current
-    // one is filtered (one WG per query: the load latency would otherwise be exposed once per segment)
-    auto fetch = [&](int64_t c0) {
-        const int64_t c = c0 + threadIdx.x * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (c + 3 < ncols) {
-            v = *(const f32x4*)(row + c);
-        } else {
-            for (int e = 0; e < 4; ++e)
-                if (c + e < ncols) v[e] = row[c + e];
-        }
-        return v;
-    };
-    f32x4 vn = fetch(0);
-    for (int64_t c0 = 0; c0 < ncols; c0 += 4 * kSelThreads) {
-        const f32x4 v = vn;
-        if (c0 + 4 * kSelThreads < ncols) vn = fetch(c0 + 4 * kSelThreads);
-        sel.reserve(4 * kSelThreads);
-        const int64_t c = c0 + threadIdx.x * 4;
+    // a segment = 1024 columns (4 per thread) <= cap - kp.  Four segments are fetched per round trip: with one WG per
+    // query the load latency is exposed once per fetch (every barrier in the selector drains vmcnt), so fewer, wider
+    // fetches are what matters for small batches.
+    constexpr int SEG = 4 * kSelThreads;
+    for (int64_t c0 = 0; c0 < ncols; c0 += 4 * SEG) {
+        f32x4 v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sel.push(make_key(v[e], (uint32_t)(idx_base + c + e)), c + e < ncols);
+        for (int j = 0; j < 4; ++j) {
+            const int64_t c = c0 + j * SEG + threadIdx.x * 4;
+            v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c + 3 < ncols) {
+                v[j] = *(const f32x4*)(row + c);
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < ncols) v[j][e] = row[c + e];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (c0 + j * SEG >= ncols) break;   // uniform
+            sel.reserve(SEG);
+            const int64_t c = c0 + j * SEG + threadIdx.x * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sel.push(make_key(v[j][e], (uint32_t)(idx_base + c + e)), c + e < ncols);
+        }
     }
     sel.finish(ls, li, tau ? tau + q : nullptr);
 }
