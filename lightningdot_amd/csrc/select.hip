@@ -121,6 +121,8 @@ struct Selector {
 // Single-wave variant of the selector (pool select: one wave per query).  The append counter is a wave-uniform
 // register, appends are ballot/popcount compactions — no LDS atomics, no barriers.
 struct WaveSelector {
+    static __device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
     uint64_t* keys;   // LDS [cap]
     uint64_t tau;
     int n, kp, cap;
@@ -139,32 +141,112 @@ struct WaveSelector {
         if (hit) keys[n + __popcll(mask & ((1ull << lane) - 1ull))] = key;
         n += __popcll(mask);
     }
+    // Keep the kp best (smallest) of keys[0..n): the list is a SET here — nothing downstream of the pool select needs it
+    // ordered (the next pool select takes its threshold from tau[], the re-score kernel sorts by exact score) — so
+    // instead of an LDS bitonic sort (LDS-bandwidth bound: ~370 KB of LDS traffic per query) the kp-th smallest key is
+    // found by a bitwise binary search on register-resident keys (ballot + popcount, no LDS traffic) and the survivors
+    // are compacted in place.  Buffers larger than 16 keys per lane (kp > 512) take the sort path.
+    static constexpr int kRegKeys = 16;
     __device__ inline void compact() {
-        int P = 2;
-        while (P < n) P <<= 1;
-        for (int i = n + threadIdx.x; i < P; i += 64) keys[i] = kEmptyKey;
-        sel_sync();
-        bitonic_sort_lds(keys, P);
-        n = n < kp ? n : kp;
-        tau = (n >= kp) ? keys[kp - 1] : kEmptyKey;
+        if (n <= kp) {   // nothing to drop; the threshold is known only once the list is full
+            if (n < kp) {
+                tau = kEmptyKey;
+                return;
+            }
+        }
+        if (cap > kRegKeys * 64) {
+            int P = 2;
+            while (P < n) P <<= 1;
+            for (int i = n + (threadIdx.x & 63); i < P; i += 64) keys[i] = kEmptyKey;
+            wave_sync();
+            bitonic_sort_lds(keys, P);   // (sort path: launched with one wave per workgroup)
+            n = n < kp ? n : kp;
+            tau = (n >= kp) ? keys[kp - 1] : kEmptyKey;
+            return;
+        }
+        // the scalar unit is shared by the CU's waves: keep the per-iteration scalar work minimal (register count
+        // specialised, 32-bit search on the score word; the row word is searched only to split exact score ties)
+        if (n <= 128)
+            select_regs<2>();
+        else if (n <= 256)
+            select_regs<4>();
+        else if (n <= 512)
+            select_regs<8>();
+        else
+            select_regs<16>();
+    }
+    template <int R>
+    __device__ __forceinline__ void select_regs() {
+        const int lane = threadIdx.x & 63;
+        wave_sync();
+        uint32_t hi[R], lo[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint64_t k = (r * 64 + lane < n) ? keys[r * 64 + lane] : kEmptyKey;
+            hi[r] = (uint32_t)(k >> 32);
+            lo[r] = (uint32_t)k;
+        }
+        wave_sync();
+        // Th = kp-th smallest score word (with multiplicity).  Empty slots are all ones in BOTH words and are never
+        // counted (a valid key's row word is < 2^31).
+        uint32_t Th = 0;
+        for (int b = 31; b >= 0; --b) {
+            const uint32_t trial = Th | ((1u << b) - 1u);
+            int c = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) c += __popcll(__ballot(hi[r] <= trial && lo[r] != 0xffffffffu));
+            if (c < kp) Th |= (1u << b);
+        }
+        int c_lt = 0, c_eq = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            c_lt += __popcll(__ballot(hi[r] < Th && lo[r] != 0xffffffffu));
+            c_eq += __popcll(__ballot(hi[r] == Th && lo[r] != 0xffffffffu));
+        }
+        uint32_t Tl = 0xfffffffeu;   // every tie fits
+        if (c_lt + c_eq > kp) {      // exact score ties straddle the cut: keep the kp - c_lt lowest rows among them
+            const int need = kp - c_lt;
+            Tl = 0;
+            for (int b = 31; b >= 0; --b) {
+                const uint32_t trial = Tl | ((1u << b) - 1u);
+                int c = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) c += __popcll(__ballot(hi[r] == Th && lo[r] <= trial));
+                if (c < need) Tl |= (1u << b);
+            }
+        }
+        int base = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool hit = lo[r] != 0xffffffffu && (hi[r] < Th || (hi[r] == Th && lo[r] <= Tl));
+            const unsigned long long mask = __ballot(hit);
+            const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+            if (hit && pos < kp) keys[pos] = ((uint64_t)hi[r] << 32) | lo[r];
+            base += __popcll(mask);
+        }
+        wave_sync();
+        n = kp;
+        tau = ((uint64_t)Th << 32) | Tl;
     }
     __device__ inline void reserve(int upcoming) {
         if (n + upcoming > cap) compact();
     }
-    // the running list is sorted (best first, empty slots last)
-    __device__ inline void load_list(const float* ls, const int32_t* li) {
+    // the running list is a set (valid entries first, empty slots last); its threshold comes from tau[]
+    __device__ inline void load_list(const float* ls, const int32_t* li, float tau_in) {
         for (int e0 = 0; e0 < kp; e0 += 64) {
             const int e = e0 + (threadIdx.x & 63);
             const bool valid = e < kp && li[e] >= 0;
-            if (valid) keys[e] = make_key(ls[e], (uint32_t)li[e]);
-            n += __popcll(__ballot(valid));
+            const unsigned long long mask = __ballot(valid);
+            if (valid) keys[n + __popcll(mask & ((1ull << (threadIdx.x & 63)) - 1ull))] = make_key(ls[e], (uint32_t)li[e]);
+            n += __popcll(mask);
         }
-        sel_sync();
-        tau = (n >= kp) ? keys[kp - 1] : kEmptyKey;
+        wave_sync();
+        // score-only threshold: admits every key whose score ties the kp-th best (rows then break the tie)
+        tau = (n >= kp && tau_in > -INFINITY) ? (((uint64_t)desc_key(tau_in) << 32) | 0xffffffffull) : kEmptyKey;
     }
     __device__ inline void finish(float* ls, int32_t* li, float* tau_out) {
         compact();
-        for (int e = threadIdx.x; e < kp; e += 64) {
+        for (int e = (threadIdx.x & 63); e < kp; e += 64) {
             if (e < n) {
                 const uint64_t k = keys[e];
                 ls[e] = desc_key_to_float((uint32_t)(k >> 32));
@@ -174,8 +256,7 @@ struct WaveSelector {
                 li[e] = -1;
             }
         }
-        if (tau_out && threadIdx.x == 0)
-            *tau_out = (n >= kp) ? desc_key_to_float((uint32_t)(keys[kp - 1] >> 32)) : -INFINITY;
+        if (tau_out && (threadIdx.x & 63) == 0) *tau_out = (n >= kp) ? desc_key_to_float((uint32_t)(tau >> 32)) : -INFINITY;
     }
 };
 
@@ -303,59 +384,73 @@ __global__ __launch_bounds__(256) void parts_to_lists_kernel(const float* __rest
 // pool source: the per-query sub-pools filled by the fused filter kernel; resets the counters afterwards.
 // One wave per query (no cross-wave barriers), small LDS footprint -> many queries resident per CU.
 constexpr int kPoolSelThreads = 64;
-__global__ __launch_bounds__(kPoolSelThreads) void select_pools_kernel(const uint2* __restrict__ pool,
-                                                                       int32_t* __restrict__ pool_cnt, int nsubs,
+// LV = entry levels fetched per step (x 2 groups of 64 sub-pools): a step appends at most 2 * LV * 64 candidates on top of
+// a full list, which sizes the LDS key buffer (cap >= kp + 2 * LV * 64) and with it the workgroups per CU.
+template <int LV, int QPW>
+__global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(const uint2* __restrict__ pool,
+                                                                       int32_t* __restrict__ pool_cnt, int nsubs, int64_t nq,
                                                                        float* __restrict__ list_s,
                                                                        int32_t* __restrict__ list_i, int kp, int cap,
                                                                        float* __restrict__ tau,
-                                                                       int32_t* __restrict__ overflow) {
+                                                                       int32_t* __restrict__ overflow, int dbg) {
     extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
-    __shared__ int cnts[kPoolSubsMax];
-    const int64_t q = blockIdx.x;
+    // QPW independent waves per workgroup, one query each (no workgroup-level synchronisation anywhere): the grid of
+    // one-wave workgroups was bound by the workgroup dispatch rate, not by the work
+    const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * QPW + wq;
+    if (q >= nq) return;
     WaveSelector sel;
-    sel.init(keys, kp, cap);
+    sel.init(keys + (size_t)wq * cap, kp, cap);
     float* ls = list_s + q * kp;
     int32_t* li = list_i + q * kp;
-    bool over = false;
-    for (int s = threadIdx.x; s < nsubs; s += kPoolSelThreads) {
-        const int c = pool_cnt[q * (int64_t)nsubs + s];
-        cnts[s] = c < kPoolCap ? c : kPoolCap;
-        over |= c > kPoolCap;
-        pool_cnt[q * (int64_t)nsubs + s] = 0;
+    int32_t* cnt = pool_cnt + q * (int64_t)nsubs;
+    // counters of the first 128 sub-pools are requested before the list so that both round trips overlap
+    int cn[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int sidx = g * kPoolSelThreads + lane;
+        cn[g] = sidx < nsubs ? cnt[sidx] : 0;
     }
-    const bool any_over = __any(over);
-    sel.load_list(ls, li);
+    if (!(dbg & 4)) sel.load_list(ls, li, tau ? tau[q] : -INFINITY);
+    bool over = false;
     // entry-major pools: level e of all sub-pools is one contiguous run of 8-byte words -> coalesced reads of the few
-    // levels in use.  Two groups of 64 sub-pools x 4 entry levels per step: 8 independent loads in flight per lane.
+    // levels in use.  Two groups of 64 sub-pools x LV entry levels per step.
     const uint2* base = pool + q * (int64_t)kPoolCap * nsubs;
     for (int s0 = 0; s0 < nsubs; s0 += 2 * kPoolSelThreads) {
         int c[2];
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            const int sidx = s0 + g * kPoolSelThreads + threadIdx.x;
-            c[g] = sidx < nsubs ? cnts[sidx] : 0;
+            const int sidx = s0 + g * kPoolSelThreads + lane;
+            over |= cn[g] > kPoolCap;
+            c[g] = cn[g] < kPoolCap ? cn[g] : kPoolCap;
+            if (sidx < nsubs) cnt[sidx] = 0;
+            const int nidx = sidx + 2 * kPoolSelThreads;       // next step's counters
+            cn[g] = nidx < nsubs ? cnt[nidx] : 0;
         }
         int cm = max(c[0], c[1]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cm = max(cm, __shfl_xor(cm, o));
-        for (int e0 = 0; e0 < cm; e0 += 4) {
-            sel.reserve(8 * kPoolSelThreads);
-            uint2 v[2][4];
+        if (dbg & 1) cm = 0;
+        for (int e0 = 0; e0 < cm; e0 += LV) {
+            sel.reserve(2 * LV * kPoolSelThreads);
+            uint2 v[2][LV];
 #pragma unroll
             for (int g = 0; g < 2; ++g)
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < LV; ++u)
                     v[g][u] = (e0 + u < c[g])
-                                  ? base[(int64_t)(e0 + u) * nsubs + s0 + g * kPoolSelThreads + threadIdx.x]
+                                  ? base[(int64_t)(e0 + u) * nsubs + s0 + g * kPoolSelThreads + lane]
                                   : make_uint2(0u, 0u);
 #pragma unroll
             for (int g = 0; g < 2; ++g)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) sel.push(make_key(__uint_as_float(v[g][u].x), v[g][u].y), e0 + u < c[g]);
+                for (int u = 0; u < LV; ++u) sel.push(make_key(__uint_as_float(v[g][u].x), v[g][u].y), e0 + u < c[g]);
         }
     }
+    const bool any_over = __any(over);
+    if (dbg & 2) return;
     sel.finish(ls, li, tau ? tau + q : nullptr);
-    if (threadIdx.x == 0 && any_over) overflow[q] = 1;
+    if (lane == 0 && any_over) overflow[q] = 1;
 }
 
 // Few queries (<= one query block, the serving shape): one 256-thread workgroup per query instead of one wave, so that
@@ -509,8 +604,20 @@ int launch_select_pools(const uint2* pool, const int32_t* pool_cnt, int nsubs, i
         return LDOT_OK;
     }
     const int cap = select_cap(kp, 1024);   // a step appends up to 8 x 64 candidates on top of a full list
-    hipLaunchKernelGGL(select_pools_kernel, dim3((unsigned)nq), dim3(kPoolSelThreads), (size_t)cap * 8, st, pool,
-                       (int32_t*)pool_cnt, nsubs, list_s, list_i, kp, cap, tau, overflow_flags);
+    static int dbg = -1;   // LDOT_DEBUG_SEL: ablation bits (profiling only; results are then meaningless)
+    if (dbg < 0) {
+        const char* e = getenv("LDOT_DEBUG_SEL");
+        dbg = e ? atoi(e) : 0;
+    }
+    if (cap <= WaveSelector::kRegKeys * 64) {   // register selection path: 4 independent query-waves per workgroup
+        constexpr int QPW = 4;
+        hipLaunchKernelGGL((select_pools_kernel<4, QPW>), dim3((unsigned)((nq + QPW - 1) / QPW)),
+                           dim3(kPoolSelThreads * QPW), (size_t)cap * 8 * QPW, st, pool, (int32_t*)pool_cnt, nsubs, nq,
+                           list_s, list_i, kp, cap, tau, overflow_flags, dbg);
+    } else {   // kp > 512: LDS sort path, one wave per workgroup
+        hipLaunchKernelGGL((select_pools_kernel<4, 1>), dim3((unsigned)nq), dim3(kPoolSelThreads), (size_t)cap * 8, st,
+                           pool, (int32_t*)pool_cnt, nsubs, nq, list_s, list_i, kp, cap, tau, overflow_flags, dbg);
+    }
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

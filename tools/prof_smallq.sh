@@ -6,5 +6,5 @@ python - <<PY
 import csv,glob
 f=glob.glob("/tmp/sq/**/*kernel_stats.csv",recursive=True)[0]
 for r in csv.DictReader(open(f)):
-    if "ldot" in r["Name"] or "rocclr" in r["Name"]: print(r["Name"][:50], r["Calls"], "avg_us=%.1f"%(float(r["AverageNs"])/1e3), "tot_ms=%.3f"%(float(r["TotalDurationNs"])/1e6))
+    if "ldot" in r["Name"] or "rocclr" in r["Name"]: print(r["Name"][:50], r["Calls"], "avg_us=%.1f"%(float(r["AverageNs"])/1e3), "min=%.1f max=%.1f"%(float(r["MinNs"])/1e3, float(r["MaxNs"])/1e3), "tot_ms=%.3f"%(float(r["TotalDurationNs"])/1e6))
 PY
