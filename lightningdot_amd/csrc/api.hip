@@ -179,7 +179,7 @@ int ldot_index_set_option(ldot_index_t* ix, int option, int64_t value) {
             ix->chunk_rows = value;
             return LDOT_OK;
         case LDOT_OPT_MARGIN:
-            LDOT_REQUIRE(value >= -1 && value <= kMaxKp, LDOT_EINVAL, "bad margin");
+            LDOT_REQUIRE(value >= -1 && value <= kMaxKp - kMaxK, LDOT_EINVAL, "bad margin (max %d)", kMaxKp - kMaxK);
             ix->margin = (int)value;
             return LDOT_OK;
         case LDOT_OPT_PROFILE:
@@ -425,7 +425,7 @@ int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dty
                       float* out_scores, int64_t* out_labels, int out_mem, void* stream) {
     LDOT_REQUIRE(ix != nullptr, LDOT_EINVAL, "index is NULL");
     LDOT_REQUIRE(nq >= 0, LDOT_EINVAL, "negative query count");
-    LDOT_REQUIRE(k >= 1 && k <= kMaxKp, LDOT_EINVAL, "k must be in [1, %d] (got %d)", kMaxKp, k);
+    LDOT_REQUIRE(k >= 1 && k <= kMaxK, LDOT_EINVAL, "k must be in [1, %d] (got %d)", kMaxK, k);
     LDOT_REQUIRE(dtype >= 0 && dtype <= 2, LDOT_EINVAL, "bad dtype %d", dtype);
     LDOT_REQUIRE((mem == LDOT_HOST || mem == LDOT_DEVICE) && (out_mem == LDOT_HOST || out_mem == LDOT_DEVICE),
                  LDOT_EINVAL, "bad memory space");

@@ -4,10 +4,9 @@
 
 namespace ldot {
 
-constexpr int kMaxKp = 2048;       // largest candidate-list length (k + margin) supported by the select kernels
+constexpr int kMaxK = 2048;        // largest k of a search
+constexpr int kMaxKp = 3072;       // largest candidate-list length k' = k + margin: k' + 1024 keys fit a 32 KiB LDS buffer
 constexpr int kSelThreads = 256;
-constexpr int kSelSeg = 2048;      // candidates examined between two compaction checks
-constexpr int kSelCap = 4096;      // LDS candidate buffer (64-bit keys)
 
 // fused-filter candidate pools: per query, nsubs = 4 * (row slices) lane-private sub-pools of kPoolCap {score, row}
 // words, laid out entry-major: pool[(q * kPoolCap + e) * nsubs + sub].

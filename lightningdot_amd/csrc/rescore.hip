@@ -15,7 +15,8 @@ __global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __rest
                                                              const int32_t* __restrict__ list_i, int kp, int k,
                                                              int do_rescore, float* __restrict__ out_s,
                                                              int64_t* __restrict__ out_l) {
-    __shared__ __attribute__((aligned(16))) uint64_t keys[kMaxKp];
+    __shared__ __attribute__((aligned(16))) uint64_t keys[4096];   // next power of two >= kMaxKp
+    static_assert(kMaxKp <= 4096, "re-score key buffer");
     const int64_t q = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* qrow = q32 + q * ldq;

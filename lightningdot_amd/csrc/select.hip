@@ -270,10 +270,11 @@ __global__ __launch_bounds__(kSelThreads) void init_lists_kernel(float* ls, int3
     if (tau && i < nq_pad) tau[i] = i < nq ? -INFINITY : INFINITY;
 }
 
-// LDS budget of a select launch: cap 64-bit keys (power of two, >= 2 * kp so a full list plus a segment fits)
-static inline int select_cap(int kp, int want) {
+// LDS budget of a select launch: cap 64-bit keys, a power of two >= `want` that holds a full list (kp) plus the
+// `upcoming` keys a step may append before the next compaction check
+static inline int select_cap(int kp, int want, int upcoming) {
     int c = want;
-    while (c < 2 * kp) c <<= 1;
+    while (c < kp + upcoming) c <<= 1;
     return c;
 }
 
@@ -557,7 +558,7 @@ int launch_init_lists(float* list_s, int32_t* list_i, int64_t n, float* tau, int
 int launch_select_dense(const float* S, int64_t lds_elems, int64_t nq, int64_t ncols, int64_t idx_base,
                         float* list_s, int32_t* list_i, int kp, float* tau, hipStream_t st) {
     if (nq <= 0) return LDOT_OK;
-    const int cap = select_cap(kp, 2048);   // 16 KiB of keys for kp <= 1024: segment of 1024 columns always fits
+    const int cap = select_cap(kp, 2048, 4 * kSelThreads);   // 16 KiB of keys for kp <= 1024
     hipLaunchKernelGGL(select_dense_kernel, dim3((unsigned)nq), dim3(kSelThreads), (size_t)cap * 8, st, S, lds_elems,
                        ncols, idx_base, list_s, list_i, kp, cap, tau);
     LDOT_HIP_CHECK(hipGetLastError());
@@ -567,7 +568,7 @@ int launch_select_dense(const float* S, int64_t lds_elems, int64_t nq, int64_t n
 int launch_select_dense_parts(const float* S, int64_t lds_elems, int64_t nq, int64_t ncols, int64_t seg_cols,
                               int64_t idx_base, int kp, float* part_s, int64_t* part_l, hipStream_t st) {
     if (nq <= 0 || ncols <= 0) return LDOT_OK;
-    const int cap = select_cap(kp, 2048);
+    const int cap = select_cap(kp, 2048, 4 * kSelThreads);
     const unsigned nseg = (unsigned)((ncols + seg_cols - 1) / seg_cols);
     hipLaunchKernelGGL(select_dense_parts_kernel, dim3((unsigned)nq, nseg), dim3(kSelThreads), (size_t)cap * 8, st, S,
                        lds_elems, nq, ncols, seg_cols, idx_base, kp, cap, part_s, part_l);
@@ -597,13 +598,13 @@ int launch_select_pools(const uint2* pool, const int32_t* pool_cnt, int nsubs, i
                         int32_t* list_i, int kp, float* tau, int32_t* overflow_flags, hipStream_t st) {
     if (nq <= 0) return LDOT_OK;
     if (nq <= 256) {   // few queries: block-per-query walk
-        const int bcap = select_cap(kp, 2048);   // a step appends up to 4 x 256 candidates on top of a full list
+        const int bcap = select_cap(kp, 2048, 4 * kSelThreads);   // a step appends up to 4 x 256 candidates on top of a full list
         hipLaunchKernelGGL(select_pools_block_kernel, dim3((unsigned)nq), dim3(kSelThreads), (size_t)bcap * 8, st, pool,
                            (int32_t*)pool_cnt, nsubs, list_s, list_i, kp, bcap, tau, overflow_flags);
         LDOT_HIP_CHECK(hipGetLastError());
         return LDOT_OK;
     }
-    const int cap = select_cap(kp, 1024);   // a step appends up to 8 x 64 candidates on top of a full list
+    const int cap = select_cap(kp, 1024, 8 * kPoolSelThreads);   // a step appends up to 8 x 64 candidates on top of a full list
     static int dbg = -1;   // LDOT_DEBUG_SEL: ablation bits (profiling only; results are then meaningless)
     if (dbg < 0) {
         const char* e = getenv("LDOT_DEBUG_SEL");
@@ -625,7 +626,7 @@ int launch_select_pools(const uint2* pool, const int32_t* pool_cnt, int nsubs, i
 int launch_select_lists(const float* cand_s, const int64_t* cand_l, int64_t part_stride, int nparts, int k_in,
                         int64_t nq, int k_out, float* out_s, int64_t* out_l, hipStream_t st) {
     if (nq <= 0) return LDOT_OK;
-    const int cap = select_cap(k_out, 1024);
+    const int cap = select_cap(k_out, 1024, kSelThreads);
     hipLaunchKernelGGL(select_lists_kernel, dim3((unsigned)nq), dim3(kSelThreads), (size_t)cap * 8, st, cand_s, cand_l,
                        part_stride, nparts, k_in, k_out, cap, out_s, out_l);
     LDOT_HIP_CHECK(hipGetLastError());

@@ -36,6 +36,7 @@ def _index(x, **opts):
     (1, 257, 100, 1),          # single query, k = 1, ragged rows
     (513, 70, 64, 100),        # k > ntotal -> padding
     (260, 33000, 128, 50),     # more than one dense chunk (32768) and more than one query tile
+    (70, 5000, 64, 2048),      # largest k: the margin is kept (k' = 2560)
 ])
 def test_dense_matches_oracle(L, nq, n, d, k):
     rng = np.random.default_rng(nq * 7 + n)
@@ -118,7 +119,8 @@ def test_normalize_option(L):
     assert np.abs(s).max() <= 1.0 + 1e-5
 
 
-@pytest.mark.parametrize('nq,n,d,k', [(300, 20000, 768, 100), (1100, 70000, 128, 10), (257, 150000, 64, 1000)])
+@pytest.mark.parametrize('nq,n,d,k', [(300, 20000, 768, 100), (1100, 70000, 128, 10), (257, 150000, 64, 1000),
+                                      (770, 150000, 128, 2048)])   # largest k keeps its margin (k' = 2560)
 def test_fused_matches_oracle(L, nq, n, d, k):
     rng = np.random.default_rng(n + k)
     x = rng.standard_normal((n, d)).astype(np.float32)
