@@ -75,12 +75,24 @@ class ShardedFlatIndexer:
     # ---- search ------------------------------------------------------------------------------------------
     def _gather_queries(self, q: torch.Tensor) -> Tuple[torch.Tensor, List[int]]:
         # query counts travel as one small tensor (no pickling; one host sync)
+        nccl = dist.get_backend(self.group) == 'nccl'
         mine = torch.tensor([q.shape[0]], dtype=torch.int64, device=q.device)
-        cbuf = [torch.empty_like(mine) for _ in range(self.world)]
-        dist.all_gather(cbuf, mine, group=self.group)
-        counts = [int(c) for c in torch.cat(cbuf).tolist()]
+        if nccl:
+            call = torch.empty(self.world, dtype=torch.int64, device=q.device)
+            dist.all_gather_into_tensor(call, mine, group=self.group)
+            counts = [int(c) for c in call.tolist()]
+        else:
+            cbuf = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(cbuf, mine, group=self.group)
+            counts = [int(c) for c in torch.cat(cbuf).tolist()]
         mx = max(counts)
         pad = q if q.shape[0] == mx else torch.cat([q, q.new_zeros(mx - q.shape[0], q.shape[1])], 0)
+        if nccl:   # one flat receive buffer; with equal slices it IS the gathered query matrix
+            out = torch.empty((self.world * mx, q.shape[1]), dtype=pad.dtype, device=pad.device)
+            dist.all_gather_into_tensor(out, pad.contiguous(), group=self.group)
+            if min(counts) == mx:
+                return out, counts
+            return torch.cat([out[r * mx:r * mx + c] for r, c in enumerate(counts)], 0), counts
         bufs = [torch.empty_like(pad) for _ in range(self.world)]
         dist.all_gather(bufs, pad.contiguous(), group=self.group)
         return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0), counts
