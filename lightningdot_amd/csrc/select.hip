@@ -85,8 +85,8 @@ struct Selector {
         // keys now and filtering the rest is cheaper than sorting a full buffer of unfiltered keys later
         if (n + upcoming > cap || (tau == kEmptyKey && n >= kp)) compact();            // uniform branch
     }
-    // The running list is kept sorted (best first, empty slots last): adopt it as keys[0..n) without sorting and
-    // take the threshold from its last element.
+    // Adopt the running list (valid entries first, empty slots last; sorted or not — the wave-level selectors keep
+    // sets) and take the threshold from it once it is full.
     __device__ inline void load_list(const float* ls, const int32_t* li) {
         for (int e0 = 0; e0 < kp; e0 += blockDim.x) {
             const int e = e0 + threadIdx.x;
@@ -97,8 +97,8 @@ struct Selector {
         }
         sel_sync();
         const int n = *count;
-        tau = (n >= kp) ? keys[kp - 1] : kEmptyKey;
         sel_sync();
+        if (n >= kp) compact();   // sorts the kp keys (cheap) and sets tau = the kp-th best
     }
     __device__ inline void finish(float* ls, int32_t* li, float* tau_out) {
         compact();
@@ -229,20 +229,32 @@ struct WaveSelector {
         tau = ((uint64_t)Th << 32) | Tl;
     }
     __device__ inline void reserve(int upcoming) {
-        if (n + upcoming > cap) compact();
+        // also compact as soon as a first threshold can be had (no threshold yet, >= kp keys buffered)
+        if (n + upcoming > cap || (tau == kEmptyKey && n >= kp)) compact();
     }
-    // the running list is a set (valid entries first, empty slots last); its threshold comes from tau[]
-    __device__ inline void load_list(const float* ls, const int32_t* li, float tau_in) {
+    // the running list is a set (valid entries first, empty slots last); once full, its threshold is its worst key
+    __device__ inline void load_list(const float* ls, const int32_t* li) {
+        const int lane = threadIdx.x & 63;
+        uint64_t worst = 0;
         for (int e0 = 0; e0 < kp; e0 += 64) {
-            const int e = e0 + (threadIdx.x & 63);
+            const int e = e0 + lane;
             const bool valid = e < kp && li[e] >= 0;
             const unsigned long long mask = __ballot(valid);
-            if (valid) keys[n + __popcll(mask & ((1ull << (threadIdx.x & 63)) - 1ull))] = make_key(ls[e], (uint32_t)li[e]);
+            if (valid) {
+                const uint64_t key = make_key(ls[e], (uint32_t)li[e]);
+                keys[n + __popcll(mask & ((1ull << lane) - 1ull))] = key;
+                worst = key > worst ? key : worst;
+            }
             n += __popcll(mask);
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t hi = __shfl_xor((uint32_t)(worst >> 32), o), lo = __shfl_xor((uint32_t)worst, o);
+            const uint64_t other = ((uint64_t)hi << 32) | lo;
+            worst = other > worst ? other : worst;
+        }
         wave_sync();
-        // score-only threshold: admits every key whose score ties the kp-th best (rows then break the tie)
-        tau = (n >= kp && tau_in > -INFINITY) ? (((uint64_t)desc_key(tau_in) << 32) | 0xffffffffull) : kEmptyKey;
+        tau = (n >= kp) ? worst : kEmptyKey;
     }
     __device__ inline void finish(float* ls, int32_t* li, float* tau_out) {
         compact();
@@ -317,6 +329,59 @@ __global__ __launch_bounds__(kSelThreads) void select_dense_kernel(const float* 
             const int64_t c = c0 + j * SEG + threadIdx.x * 4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) sel.push(make_key(v[j][e], (uint32_t)(idx_base + c + e)), c + e < ncols);
+        }
+    }
+    sel.finish(ls, li, tau ? tau + q : nullptr);
+}
+
+// dense source, wave-per-query variant (k' <= 512): the same register selection as the pool select instead of LDS bitonic
+// compactions (which are LDS-bandwidth bound at ~1.3 MB of LDS traffic per query).  QPW independent query-waves per WG.
+template <int QPW>
+__global__ __launch_bounds__(64 * QPW) void select_dense_wave_kernel(const float* __restrict__ S, int64_t lds_elems,
+                                                                     int64_t nq, int64_t ncols, int64_t idx_base,
+                                                                     float* __restrict__ list_s,
+                                                                     int32_t* __restrict__ list_i, int kp, int cap,
+                                                                     float* __restrict__ tau) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
+    const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * QPW + wq;
+    if (q >= nq) return;
+    WaveSelector sel;
+    sel.init(keys + (size_t)wq * cap, kp, cap);
+    float* ls = list_s + q * kp;
+    int32_t* li = list_i + q * kp;
+    const float* row = S + q * lds_elems;
+    // a step = 256 columns (4 per lane); four steps are fetched per round trip
+    constexpr int STEP = 256;
+    auto fetch = [&](int64_t c) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c + 3 < ncols) {
+            v = *(const f32x4*)(row + c);
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (c + e < ncols) v[e] = row[c + e];
+        }
+        return v;
+    };
+    f32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = fetch(j * STEP + lane * 4);
+    sel.load_list(ls, li);
+    for (int64_t c0 = 0; c0 < ncols; c0 += 4 * STEP) {
+        f32x4 w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = v[j];
+        if (c0 + 4 * STEP < ncols) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fetch(c0 + 4 * STEP + j * STEP + lane * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (c0 + j * STEP >= ncols) break;   // uniform
+            sel.reserve(STEP);
+            const int64_t c = c0 + j * STEP + lane * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sel.push(make_key(w[j][e], (uint32_t)(idx_base + c + e)), c + e < ncols);
         }
     }
     sel.finish(ls, li, tau ? tau + q : nullptr);
@@ -412,7 +477,7 @@ __global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(con
         const int sidx = g * kPoolSelThreads + lane;
         cn[g] = sidx < nsubs ? cnt[sidx] : 0;
     }
-    if (!(dbg & 4)) sel.load_list(ls, li, tau ? tau[q] : -INFINITY);
+    if (!(dbg & 4)) sel.load_list(ls, li);
     bool over = false;
     // entry-major pools: level e of all sub-pools is one contiguous run of 8-byte words -> coalesced reads of the few
     // levels in use.  Two groups of 64 sub-pools x LV entry levels per step.
@@ -558,6 +623,14 @@ int launch_init_lists(float* list_s, int32_t* list_i, int64_t n, float* tau, int
 int launch_select_dense(const float* S, int64_t lds_elems, int64_t nq, int64_t ncols, int64_t idx_base,
                         float* list_s, int32_t* list_i, int kp, float* tau, hipStream_t st) {
     if (nq <= 0) return LDOT_OK;
+    if (kp + 256 <= WaveSelector::kRegKeys * 64 && nq > 64) {   // wave-per-query register selection (k' <= 512)
+        constexpr int QPW = 4;
+        const int wcap = WaveSelector::kRegKeys * 64;
+        hipLaunchKernelGGL((select_dense_wave_kernel<QPW>), dim3((unsigned)((nq + QPW - 1) / QPW)), dim3(64 * QPW),
+                           (size_t)wcap * 8 * QPW, st, S, lds_elems, nq, ncols, idx_base, list_s, list_i, kp, wcap, tau);
+        LDOT_HIP_CHECK(hipGetLastError());
+        return LDOT_OK;
+    }
     const int cap = select_cap(kp, 2048, 4 * kSelThreads);   // 16 KiB of keys for kp <= 1024
     hipLaunchKernelGGL(select_dense_kernel, dim3((unsigned)nq), dim3(kSelThreads), (size_t)cap * 8, st, S, lds_elems,
                        ncols, idx_base, list_s, list_i, kp, cap, tau);
