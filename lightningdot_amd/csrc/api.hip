@@ -393,7 +393,8 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
     while (r < ix->ntotal) {
         int64_t len = std::min<int64_t>(r * growth / 100, r * 1024 / kp);
         len = std::max<int64_t>(len, bm * nslices);
-        len = round_up(len, bm);
+        // whole tiles for every row slice (a launch is as slow as its busiest slice); rounding DOWN keeps the pool bound
+        len = len / (bm * nslices) * (bm * nslices);
         len = std::min(len, ix->ntotal - r);
         if (ix->ntotal - r - len < len / 4) len = ix->ntotal - r;   // no short tail launch (the pool bound has that slack)
         prof_begin(ix, st, 2.0 * nq * len * ix->d,

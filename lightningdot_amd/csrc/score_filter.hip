@@ -14,8 +14,10 @@
 // sub-pools as contiguous 8-byte words instead of one cache line per entry.
 //
 // Work decomposition (256 persistent workgroups, block b observed on XCD b % 8; qg = query blocks per XCD):
-//   XCD x, slot s in [0,32): qsub = s % qg, nsub = s / qg;  row slice = x*(32/qg) + nsub -> tiles t = slice (mod slices)
-//   for each group of qg query blocks: query block = g*qg + qsub.
+//   XCD x, slot s in [0,32): qsub = s % qg, nsub = s / qg;  row stream = x*(32/qg) + nsub (nstreams = 256 / qg).
+//   Work units u = g * ntiles + t (g = group of qg query blocks, t = row tile) are dealt round-robin to the streams
+//   (u = stream (mod nstreams)), so streams differ by at most ONE tile per launch, not one per query group; the qg
+//   workgroups of a stream multiply the same row tile with their own query block g*qg + qsub.
 // With qg = 8 the 32 workgroups of an XCD work on 8 query panels x 4 adjacent row tiles, so the private L2 holds
 // 8 Q panels (3 MiB) and streams each row panel once per query group.
 //
@@ -108,11 +110,12 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     const int ntiles = (int)((nrows + Geo::kBM - 1) / Geo::kBM);
     const int32_t row_end = (int32_t)(row0 + nrows);
     const int sub = (slice * 2 + c.wm) * 2 + (c.lane >> 5);
-    const int nq_iter = (nqb > qsub) ? (nqb - qsub + qg - 1) >> qg_log2 : 0;
-    const int nt_iter = (ntiles > slice) ? (ntiles - slice + nslices - 1) / nslices : 0;
-    const int ntile_total = nq_iter * nt_iter;
+    const int nq_iter = (nqb > qsub) ? (nqb - qsub + qg - 1) >> qg_log2 : 0;   // query groups in which this qsub is valid
+    const int64_t nunits = (int64_t)nq_iter * ntiles;                            // (group, tile) units of this qsub
+    const int ntile_total = (nunits > slice) ? (int)((nunits - slice + nslices - 1) / nslices) : 0;
     if (ntile_total == 0) return;
     const int64_t S = (int64_t)ntile_total * nk;
+    const int g0 = slice / ntiles, t0 = slice % ntiles;                          // first unit of this stream
 
     // ---- load cursor (see the second-generation kernel) ---------------------------------------------------------
     int va[Geo::kALoads], vb[2];
@@ -120,10 +123,10 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     for (int j = 0; j < Geo::kALoads; ++j) va[j] = ((j * 8 + c.wave) * 16 + (c.lane >> 2)) * (int)ldx_b + c.st_col;
 #pragma unroll
     for (int j = 0; j < 2; ++j) vb[j] = c.st_row[j] * (int)ldq_b + c.st_col;
-    int l_q = 0, l_t = 0, l_k = 0;
+    int l_q = g0, l_t = t0, l_k = 0;
     RingSrc sa, sb;   // (voff members unused here)
-    sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)slice * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
-    sb.rsrc = ring_make_rsrc_n(Q16 + (int64_t)qsub * kRBN * ldq_b, kRBN * ldq_b);
+    sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)l_t * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
+    sb.rsrc = ring_make_rsrc_n(Q16 + (int64_t)(qsub + l_q * qg) * kRBN * ldq_b, kRBN * ldq_b);
     int64_t issued = 0;
     auto issue = [&]() {
         char* st = smem + (int)(issued & 3) * Geo::kStage;
@@ -139,15 +142,17 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
                                                      16, vb[j], k0b, 0, 0);
         ++issued;
         if (issued < S) {
-            if (++l_k == nk) {
+            if (++l_k == nk) {   // next unit of this stream
                 l_k = 0;
-                if (++l_t == nt_iter) {
-                    l_t = 0;
-                    ++l_q;
+                l_t += nslices;
+                if (l_t >= ntiles) {
+                    do {
+                        l_t -= ntiles;
+                        ++l_q;
+                    } while (l_t >= ntiles);
                     sb.rsrc = ring_make_rsrc_n(Q16 + (int64_t)(qsub + l_q * qg) * kRBN * ldq_b, kRBN * ldq_b);
                 }
-                sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)(slice + l_t * nslices) * Geo::kBM) * ldx_b,
-                                           Geo::kBM * ldx_b);
+                sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)l_t * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
             }
         }
     };
@@ -162,7 +167,6 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     float tau[2];
     int cur[2] = {0, 0};
     uint32_t pbase[2];
-    int64_t qidx[2];
     f32x16 acc[MR][2];
     FragsR<MR> f;
     {
@@ -191,39 +195,53 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
         issue();                                             // slab s+3 (or a dummy) -> the stage slab s-1 vacated
     };
 
-#pragma unroll 1
-    for (int c_q = 0; c_q < nq_iter; ++c_q) {
+    // the counters' query index is recomputed at store time (two VGPR pairs less live across the tile loop)
+    auto store_counts = [&](int g) {
 #pragma unroll
         for (int nr = 0; nr < 2; ++nr) {
-            qidx[nr] = (int64_t)(qsub + c_q * qg) * kRBN + c.wn * 64 + nr * 32 + (c.lane & 31);
-            tau[nr] = (VAR & 16) ? INFINITY : ring_launder(tau_g[qidx[nr]]);
-            pbase[nr] = (uint32_t)(qidx[nr] * kPoolCap * nsubs + sub);
-            cur[nr] = 0;
+            const int64_t qi = (int64_t)(qsub + g * qg) * kRBN + c.wn * 64 + nr * 32 + (c.lane & 31);
+            pool_cnt[qi * nsubs + sub] = cur[nr];
         }
+    };
+    int c_q = g0, c_t = t0, cur_q = -1;
 #pragma unroll 1
-        for (int c_t = 0; c_t < nt_iter; ++c_t) {
+    for (int j = 0; j < ntile_total; ++j) {
+        if (c_q != cur_q) {   // (uniform) the stream moves on to the next query group
+            if (cur_q >= 0) store_counts(cur_q);
+            cur_q = c_q;
 #pragma unroll
-            for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-                for (int nr = 0; nr < 2; ++nr)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.f;
-#pragma unroll 1
-            for (int kk = 0; kk < nk; ++kk) slab();
-            const int64_t trow = row0 + (int64_t)(slice + c_t * nslices) * Geo::kBM;
-            const int32_t row_lane0 = (int32_t)trow + c.wm * (32 * MR) + 4 * (c.lane >> 5);
-            if (!(VAR & 1)) {
-                filter_epilogue_r<MR, (VAR & 8) != 0>(acc, tau, cur, pbase, (uint32_t)nsubs, pool, row_lane0, row_end);
-            } else {
-#pragma unroll
-                for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-                    for (int nr = 0; nr < 2; ++nr) asm volatile("" ::"v"(acc[mr][nr]));
+            for (int nr = 0; nr < 2; ++nr) {
+                const int64_t qi = (int64_t)(qsub + c_q * qg) * kRBN + c.wn * 64 + nr * 32 + (c.lane & 31);
+                tau[nr] = (VAR & 16) ? INFINITY : ring_launder(tau_g[qi]);
+                pbase[nr] = (uint32_t)(qi * kPoolCap * nsubs + sub);
+                cur[nr] = 0;
             }
         }
 #pragma unroll
-        for (int nr = 0; nr < 2; ++nr) pool_cnt[qidx[nr] * nsubs + sub] = cur[nr];
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int nr = 0; nr < 2; ++nr)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.f;
+#pragma unroll 1
+        for (int kk = 0; kk < nk; ++kk) slab();
+        const int64_t trow = row0 + (int64_t)c_t * Geo::kBM;
+        const int32_t row_lane0 = (int32_t)trow + c.wm * (32 * MR) + 4 * (c.lane >> 5);
+        if (!(VAR & 1)) {
+            filter_epilogue_r<MR, (VAR & 8) != 0>(acc, tau, cur, pbase, (uint32_t)nsubs, pool, row_lane0, row_end);
+        } else {
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < 2; ++nr) asm volatile("" ::"v"(acc[mr][nr]));
+        }
+        c_t += nslices;
+        while (c_t >= ntiles) {
+            c_t -= ntiles;
+            ++c_q;
+        }
     }
+    store_counts(cur_q);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing dummy loads must land before the LDS is released
 }
 
