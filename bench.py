@@ -57,6 +57,8 @@ def main():
     ap.add_argument('--growth', type=int, default=0, help='fused launch growth percent (0 = library default)')
     ap.add_argument('--warm', type=int, default=0, help='dense warm-up rows (0 = library default)')
     ap.add_argument('--force-sharded', action='store_true', help='run the sharded code path even with one rank')
+    ap.add_argument('--split-bf16', action='store_true',
+                    help='LDOT_OPT_PRECISION=1: split-bf16 candidate pass (3 MFMA products per element); not the headline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-queries', type=int, default=2048)
     ap.add_argument('--normalised', action='store_true',
@@ -104,6 +106,8 @@ def main():
         ix = DenseFlatIndexer(D)
         ix.index.set_option(L.OPT_MODE, mode)
         ix.index.set_option(L.OPT_PROFILE, 1)
+        if args.split_bf16:
+            ix.index.set_option(L.OPT_PRECISION, 1)
         if args.growth:
             ix.index.set_option(L.OPT_GROWTH_PCT, args.growth)
         if args.warm:
@@ -125,6 +129,8 @@ def main():
         sh = ShardedFlatIndexer(D)
         sh.local.index.set_option(L.OPT_MODE, mode)
         sh.local.index.set_option(L.OPT_PROFILE, 1)
+        if args.split_bf16:
+            sh.local.index.set_option(L.OPT_PRECISION, 1)
         sh.index_local_shard(list(range(lo, hi)), x_local)
         flat = sh.local.index
         qper = (Q + world - 1) // world
@@ -195,6 +201,7 @@ def main():
                                                if args.normalised else
                                                'un-normalised inner product (BASELINE.json configs[3] / SURVEY S1)'),
                    'index_rows': N, 'queries': Q, 'dim': D, 'k': K, 'search_mode': args.mode,
+                   'candidate_precision': 'split-bf16 (3 products)' if args.split_bf16 else 'bf16',
                    'parallelism': f'row-sharded index x{world}' if world > 1 else 'single GPU'},
         **recall, 'results_sorted': sorted_ok,
         'overflowed_queries': int(stats['overflowed_queries']),

@@ -50,7 +50,9 @@ struct ldot_index {
     int d = 0, dpad = 0;
     int64_t ntotal = 0, cap_rows = 0;
     float* x32 = nullptr;      // [cap_rows][dpad] fp32 master copy (zero padded)
-    uint16_t* x16 = nullptr;   // [cap_rows][dpad] bf16 shadow
+    uint16_t* x16 = nullptr;   // [cap_rows][ld16()] bf16 shadow: dpad, or 3*dpad split-bf16 [hi|hi|lo] (precision 1)
+    int precision = 0;
+    int64_t ld16() const { return precision ? 3 * (int64_t)dpad : dpad; }
     // options
     int mode = LDOT_MODE_AUTO;
     int rescore = 1;
@@ -83,7 +85,7 @@ static int index_reserve(ldot_index* ix, int64_t rows, hipStream_t st) {
     cap = round_up(cap, 256);
     float* n32 = nullptr;
     uint16_t* n16 = nullptr;
-    const size_t b32 = (size_t)cap * ix->dpad * sizeof(float), b16 = (size_t)cap * ix->dpad * sizeof(uint16_t);
+    const size_t b32 = (size_t)cap * ix->dpad * sizeof(float), b16 = (size_t)cap * ix->ld16() * sizeof(uint16_t);
     LDOT_HIP_CHECK(hipMalloc((void**)&n32, b32));
     hipError_t e = hipMalloc((void**)&n16, b16);
     if (e != hipSuccess) {
@@ -91,7 +93,7 @@ static int index_reserve(ldot_index* ix, int64_t rows, hipStream_t st) {
         set_error("hipMalloc(%zu) failed: %s", b16, hipGetErrorString(e));
         return LDOT_ENOMEM;
     }
-    const size_t u32 = (size_t)ix->ntotal * ix->dpad * sizeof(float), u16 = (size_t)ix->ntotal * ix->dpad * 2;
+    const size_t u32 = (size_t)ix->ntotal * ix->dpad * sizeof(float), u16 = (size_t)ix->ntotal * ix->ld16() * 2;
     if (ix->ntotal > 0) {
         LDOT_HIP_CHECK(hipMemcpyAsync(n32, ix->x32, u32, hipMemcpyDeviceToDevice, st));
         LDOT_HIP_CHECK(hipMemcpyAsync(n16, ix->x16, u16, hipMemcpyDeviceToDevice, st));
@@ -157,7 +159,7 @@ int ldot_index_reset(ldot_index_t* ix) {
     LDOT_REQUIRE(ix != nullptr, LDOT_EINVAL, "index is NULL");
     if (ix->cap_rows > 0) {
         LDOT_HIP_CHECK(hipMemset(ix->x32, 0, (size_t)ix->cap_rows * ix->dpad * 4));
-        LDOT_HIP_CHECK(hipMemset(ix->x16, 0, (size_t)ix->cap_rows * ix->dpad * 2));
+        LDOT_HIP_CHECK(hipMemset(ix->x16, 0, (size_t)ix->cap_rows * ix->ld16() * 2));
     }
     ix->ntotal = 0;
     return LDOT_OK;
@@ -189,6 +191,32 @@ int ldot_index_set_option(ldot_index_t* ix, int option, int64_t value) {
             LDOT_REQUIRE(value >= 2048 && value % 256 == 0, LDOT_EINVAL, "warm_rows must be a multiple of 256 >= 2048");
             ix->warm_rows = value;
             return LDOT_OK;
+        case LDOT_OPT_PRECISION: {
+            LDOT_REQUIRE(value == 0 || value == 1, LDOT_EINVAL, "precision must be 0 (bf16) or 1 (split bf16)");
+            if ((int)value == ix->precision) return LDOT_OK;
+            ix->precision = (int)value;
+            if (ix->cap_rows == 0) return LDOT_OK;
+            // rebuild the shadow from the fp32 master copy in the new layout
+            uint16_t* n16 = nullptr;
+            const size_t b16 = (size_t)ix->cap_rows * ix->ld16() * sizeof(uint16_t);
+            hipError_t e = hipMalloc((void**)&n16, b16);
+            if (e != hipSuccess) {
+                ix->precision = 1 - ix->precision;
+                set_error("hipMalloc(%zu) failed: %s", b16, hipGetErrorString(e));
+                return LDOT_ENOMEM;
+            }
+            LDOT_HIP_CHECK(hipMemsetAsync(n16, 0, b16, nullptr));
+            int rc = launch_convert_rows(ix->x32, LDOT_F32, ix->dpad, ix->ntotal, ix->ntotal, ix->d, ix->dpad, 0, nullptr,
+                                         n16, ix->precision ? 1 : 0, nullptr);
+            LDOT_HIP_CHECK(hipStreamSynchronize(nullptr));
+            if (rc) {
+                (void)hipFree(n16);
+                return rc;
+            }
+            (void)hipFree(ix->x16);
+            ix->x16 = n16;
+            return LDOT_OK;
+        }
         case LDOT_OPT_GROWTH_PCT:
             LDOT_REQUIRE(value >= 5 && value <= 10000, LDOT_EINVAL, "growth_pct must be in [5, 10000]");
             ix->growth_pct = (int)value;
@@ -219,7 +247,7 @@ int ldot_index_add(ldot_index_t* ix, const void* rows, int64_t n, int dtype, int
         src = ix->w_stage.p;
     }
     rc = launch_convert_rows(src, dtype, ix->d, n, n, ix->d, ix->dpad, normalize, ix->x32 + ix->ntotal * ix->dpad,
-                             ix->x16 + ix->ntotal * ix->dpad, st);
+                             ix->x16 + ix->ntotal * ix->ld16(), ix->precision ? 1 : 0, st);
     if (rc) return rc;
     if (mem == LDOT_HOST) LDOT_HIP_CHECK(hipStreamSynchronize(st));   // staging buffer is reused by the next call
     ix->ntotal += n;
@@ -285,7 +313,7 @@ static void prof_collect(ldot_index* ix, hipStream_t st) {
 // dense scan of rows [r0, r1) for query block [q0, q0+nqb): materialise score chunks + streaming select
 static int dense_scan(ldot_index* ix, int64_t q0, int64_t nqb, int64_t nqb_pad, int64_t r0, int64_t r1, int kp,
                       float* tau, hipStream_t st) {
-    const uint16_t* q16 = (const uint16_t*)ix->w_q16.p + q0 * ix->dpad;
+    const uint16_t* q16 = (const uint16_t*)ix->w_q16.p + q0 * ix->ld16();
     float* ls = (float*)ix->w_ls.p + q0 * kp;
     int32_t* li = (int32_t*)ix->w_li.p + q0 * kp;
     const int64_t chunk = ix->chunk_rows;
@@ -297,7 +325,7 @@ static int dense_scan(ldot_index* ix, int64_t q0, int64_t nqb, int64_t nqb_pad, 
         // algorithmic work: the VALID queries x rows x d (tile padding is overhead, not work)
         prof_begin(ix, st, 2.0 * nqb * nrows * ix->d,
                    (double)nrows * ix->d * 2 + (double)nqb * ix->d * 2 + (double)nqb * nrows * 4);
-        rc = launch_score_dense(q16, ix->dpad, nqb_pad, ix->x16, ix->dpad, r, nrows_pad, ix->dpad, (float*)ix->w_S.p,
+        rc = launch_score_dense(q16, ix->ld16(), nqb_pad, ix->x16, ix->ld16(), r, nrows_pad, (int)ix->ld16(), (float*)ix->w_S.p,
                                 chunk, nqb, st);
         prof_end(ix, st);
         if (rc) return rc;
@@ -327,7 +355,7 @@ static int dense_scan_wide(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, i
         if ((rc = ix->w_mrg_l.ensure((size_t)nq * kp * 8))) return rc;
         prof_begin(ix, st, 2.0 * nq * nrows * ix->d,
                    (double)nrows * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * nrows * 4);
-        rc = launch_score_dense(ix->w_q16.p, ix->dpad, kBM, ix->x16, ix->dpad, r, nrows_pad, ix->dpad,
+        rc = launch_score_dense(ix->w_q16.p, ix->ld16(), kBM, ix->x16, ix->ld16(), r, nrows_pad, (int)ix->ld16(),
                                 (float*)ix->w_S.p, nrows_pad, nq, st);
         prof_end(ix, st);
         if (rc) return rc;
@@ -399,7 +427,7 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
         if (ix->ntotal - r - len < len / 4) len = ix->ntotal - r;   // no short tail launch (the pool bound has that slack)
         prof_begin(ix, st, 2.0 * nq * len * ix->d,
                    (double)len * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * kp * 8);
-        rc = launch_score_filter(ix->x16, ix->dpad, r, len, ix->w_q16.p, ix->dpad, nq_pad, ix->dpad, tau,
+        rc = launch_score_filter(ix->x16, ix->ld16(), r, len, ix->w_q16.p, ix->ld16(), nq_pad, (int)ix->ld16(), tau,
                                  (uint2*)ix->w_pool.p, (int32_t*)ix->w_pool_cnt.p, st);
         prof_end(ix, st);
         if (rc) return rc;
@@ -438,7 +466,7 @@ int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dty
     const int64_t nq_pad = round_up(nq, kBM);
     int rc;
     if ((rc = ix->w_q32.ensure((size_t)nq_pad * ix->dpad * 4))) return rc;
-    if ((rc = ix->w_q16.ensure((size_t)nq_pad * ix->dpad * 2))) return rc;
+    if ((rc = ix->w_q16.ensure((size_t)nq_pad * ix->ld16() * 2))) return rc;
     if ((rc = ix->w_ls.ensure((size_t)nq_pad * kp * 4))) return rc;
     if ((rc = ix->w_li.ensure((size_t)nq_pad * kp * 4))) return rc;
     if ((rc = ix->w_tau.ensure((size_t)nq_pad * 4))) return rc;
@@ -456,7 +484,7 @@ int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dty
         src = ix->w_stage.p;
     }
     if ((rc = launch_convert_rows(src, dtype, ix->d, nq, nq_pad, ix->d, ix->dpad, normalize, (float*)ix->w_q32.p,
-                                  (uint16_t*)ix->w_q16.p, st)))
+                                  (uint16_t*)ix->w_q16.p, ix->precision ? 2 : 0, st)))
         return rc;
     if ((rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, (float*)ix->w_tau.p, nq, nq_pad, st)))
         return rc;
@@ -587,7 +615,7 @@ int ldot_cls_pool(const void* seq, int dtype, int64_t B, int64_t stride_b, int64
                   void* out_bf16, void* stream) {
     LDOT_REQUIRE(seq != nullptr && (out_f32 || out_bf16), LDOT_EINVAL, "NULL buffer");
     LDOT_REQUIRE(B >= 0 && D > 0 && D <= 65536 && stride_b >= D, LDOT_EINVAL, "bad shape");
-    return launch_convert_rows(seq, dtype, stride_b, B, B, (int)D, (int)D, normalize, out_f32, (uint16_t*)out_bf16,
+    return launch_convert_rows(seq, dtype, stride_b, B, B, (int)D, (int)D, normalize, out_f32, (uint16_t*)out_bf16, 0,
                                (hipStream_t)stream);
 }
 

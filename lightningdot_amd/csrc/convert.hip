@@ -17,15 +17,19 @@ template <int DT>
 __global__ __launch_bounds__(256) void convert_rows_kernel(const void* __restrict__ src, int64_t ld_src, int64_t n,
                                                            int64_t n_pad, int d, int dpad, int normalize,
                                                            float* __restrict__ dst32,
-                                                           uint16_t* __restrict__ dst16) {
+                                                           uint16_t* __restrict__ dst16, int split) {
+    // split = 0: dst16 row = [bf16(v)] (dpad);  split-bf16 operands (3 * dpad per row, v ~ hi + lo to 16 mantissa bits):
+    // split = 1 (index side): [hi | hi | lo],  split = 2 (query side): [hi | lo | hi]  so that one K = 3*dpad contraction
+    // yields hi.hi + hi.lo + lo.hi
+    const int64_t ld16 = split ? 3 * (int64_t)dpad : dpad;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_pad) return;
     if (row >= n) {   // pad rows of the last query tile: zeros
-        for (int c = lane; c < dpad; c += 64) {
+        for (int c = lane; c < dpad; c += 64)
             if (dst32) dst32[row * dpad + c] = 0.f;
-            if (dst16) dst16[row * dpad + c] = 0;
-        }
+        if (dst16)
+            for (int64_t c = lane; c < ld16; c += 64) dst16[row * ld16 + c] = 0;
         return;
     }
     const int64_t so = row * ld_src;
@@ -49,27 +53,38 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(const void* __restric
             if (normalize) v = v * scale;
         }
         if (dst32) dst32[row * dpad + c] = v;
-        if (dst16) dst16[row * dpad + c] = f32_to_bf16_bits(v);
+        if (dst16) {
+            const uint16_t hi = f32_to_bf16_bits(v);
+            if (!split) {
+                dst16[row * ld16 + c] = hi;
+            } else {
+                const uint16_t lo = f32_to_bf16_bits(v - bf16_bits_to_f32(hi));   // exact difference, then rounded
+                uint16_t* o = dst16 + row * ld16 + c;
+                o[0] = hi;
+                o[dpad] = split == 1 ? hi : lo;
+                o[2 * dpad] = split == 1 ? lo : hi;
+            }
+        }
     }
 }
 
 int launch_convert_rows(const void* src, int dtype, int64_t ld_src, int64_t n, int64_t n_pad, int d, int dpad,
-                        int normalize, float* dst32, uint16_t* dst16, hipStream_t st) {
+                        int normalize, float* dst32, uint16_t* dst16, int split, hipStream_t st) {
     if (n_pad < n) n_pad = n;
     if (n_pad <= 0) return LDOT_OK;
     const dim3 grid((unsigned)((n_pad + 3) / 4)), block(256);
     switch (dtype) {
         case LDOT_F32:
             hipLaunchKernelGGL(convert_rows_kernel<LDOT_F32>, grid, block, 0, st, src, ld_src, n, n_pad, d, dpad, normalize,
-                               dst32, dst16);
+                               dst32, dst16, split);
             break;
         case LDOT_BF16:
             hipLaunchKernelGGL(convert_rows_kernel<LDOT_BF16>, grid, block, 0, st, src, ld_src, n, n_pad, d, dpad, normalize,
-                               dst32, dst16);
+                               dst32, dst16, split);
             break;
         case LDOT_F16:
             hipLaunchKernelGGL(convert_rows_kernel<LDOT_F16>, grid, block, 0, st, src, ld_src, n, n_pad, d, dpad, normalize,
-                               dst32, dst16);
+                               dst32, dst16, split);
             break;
         default:
             set_error("unsupported dtype %d", dtype);

@@ -16,8 +16,9 @@ constexpr int kPoolSubsMax = 1024;   // query-group width 1: 256 row slices x 4 
 
 // rows: convert n rows of `dtype` (row stride ld_src elements, d valid columns) into the padded fp32 master copy
 // and/or its bf16 shadow (row stride dpad, zero padded); optional L2 normalisation.  Rows [n, n_pad) are zero-filled.
+// split != 0: split-bf16 shadow of 3 * dpad per row (1: index side [hi|hi|lo], 2: query side [hi|lo|hi]).
 int launch_convert_rows(const void* src, int dtype, int64_t ld_src, int64_t n, int64_t n_pad, int d, int dpad,
-                        int normalize, float* dst32, uint16_t* dst16, hipStream_t st);
+                        int normalize, float* dst32, uint16_t* dst16, int split, hipStream_t st);
 
 int launch_score_dense(const void* q16, int64_t ldq_elems, int64_t nq_pad, const void* x16, int64_t ldx_elems,
                        int64_t xrow0, int64_t nrows_pad, int dpad, float* S, int64_t lds_elems, int64_t nq_valid,

@@ -287,3 +287,33 @@ def test_few_queries_wide_path(L, nq, n, d, k):
     ix.add(x2)
     s2, l2 = ix.search(q[:1], k)
     assert l2[0, 0] == n + 7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,mode', [(5000, 'dense'), (60000, 'fused')])
+def test_split_bf16_precision_on_crowded_scores(L, n, mode):
+    """Scores that crowd closer than bf16 resolves (rows = one large vector + 1e-3 perturbations): the accuracy contract of
+    the default bf16 candidate pass does not cover this; LDOT_OPT_PRECISION = 1 (split-bf16 operands) does."""
+    rng = np.random.default_rng(77)
+    d, nq, k = 128, 300, 10
+    u = rng.standard_normal(d).astype(np.float32)
+    x = (u[None, :] + 1e-3 * rng.standard_normal((n, d))).astype(np.float32)
+    q = (u[None, :] + 1e-3 * rng.standard_normal((nq, d))).astype(np.float32)
+    ix = _index(x, mode=L.MODE_DENSE if mode == 'dense' else L.MODE_FUSED)
+    ix.set_option(L.OPT_PRECISION, 1)          # rebuilds the shadow from the fp32 master copy
+    s, l = ix.search(q, k)
+    if mode == 'fused':
+        assert ix.last_stats()['fused_pairs'] > 0
+    assert_topk_matches(q, x, s, l, k, eps=2e-4)
+    # the default precision is expected to miss true neighbours here (documents the limit the option exists for)
+    ix.set_option(L.OPT_PRECISION, 0)
+    s0, l0 = ix.search(q, k)
+    full = q.astype(np.float64) @ x.astype(np.float64).T
+    kth = np.sort(full, axis=1)[:, -k][:, None]
+    missed = (np.take_along_axis(full, l0, axis=1) < kth - 2e-4).any(axis=1).mean()
+    assert missed > 0.2, missed
+    # and switching back restores exact results
+    ix.set_option(L.OPT_PRECISION, 1)
+    s1, l1 = ix.search(q, k)
+    np.testing.assert_array_equal(l1, l)
+    np.testing.assert_array_equal(s1, s)
