@@ -11,68 +11,172 @@
 namespace ldot {
 
 constexpr int kSgThreads = 256;
-constexpr int kSgTile = 64;   // 64 x 64 output tile per workgroup, one 32 x 32 MFMA tile per wave
-constexpr int kSgBK = 16;
-constexpr int kSgLd = kSgTile + 1;
+constexpr int kSgSlab = 2048;   // operand elements per K slab: (TILE 64, BK 32) or (TILE 128, BK 16) = 2 float4 per thread
 
-// C[m][n] (+)= alpha * sum_k A(m,k) * B(n,k),  A(m,k) = A[m*sam + k*sak], B(n,k) = B[n*sbn + k*sbk]
-__global__ __launch_bounds__(kSgThreads) void sgemm_kernel(const float* __restrict__ A, int64_t sam, int64_t sak,
-                                                           const float* __restrict__ B, int64_t sbn, int64_t sbk,
+// One operand slab: global -> registers (float4 along the operand's contiguous dimension, bounds-checked) -> LDS [k][r].
+// KFAST: element (r, k) at r*ld + k (rows of the operand are K-contiguous), else at k*ld + r.
+template <int TILE, bool KFAST>
+struct SgOperand {
+    static constexpr int BK = kSgSlab / TILE;
+    static constexpr int LD = TILE + 4;   // float4-aligned rows; the two k rows of an MFMA operand land 4 banks apart
+    float4 v[2];
+    __device__ __forceinline__ void fetch(const float* __restrict__ P, int64_t ld, int64_t r0, int64_t R, int64_t k0,
+                                          int64_t K, bool vec) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = threadIdx.x + i * kSgThreads;
+            int64_t r, k;
+            if (KFAST) {
+                r = r0 + id / (BK / 4);
+                k = k0 + (id % (BK / 4)) * 4;
+            } else {
+                k = k0 + id / (TILE / 4);
+                r = r0 + (id % (TILE / 4)) * 4;
+            }
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (KFAST) {
+                if (r < R) {
+                    const float* p = P + r * ld + k;
+                    if (vec && k + 3 < K) {
+                        x = *(const float4*)p;
+                    } else {
+                        if (k + 0 < K) x.x = p[0];
+                        if (k + 1 < K) x.y = p[1];
+                        if (k + 2 < K) x.z = p[2];
+                        if (k + 3 < K) x.w = p[3];
+                    }
+                }
+            } else {
+                if (k < K) {
+                    const float* p = P + k * ld + r;
+                    if (vec && r + 3 < R) {
+                        x = *(const float4*)p;
+                    } else {
+                        if (r + 0 < R) x.x = p[0];
+                        if (r + 1 < R) x.y = p[1];
+                        if (r + 2 < R) x.z = p[2];
+                        if (r + 3 < R) x.w = p[3];
+                    }
+                }
+            }
+            v[i] = x;
+        }
+    }
+    __device__ __forceinline__ void stash(float (*S)[LD]) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = threadIdx.x + i * kSgThreads;
+            if (KFAST) {
+                const int r = id / (BK / 4), k = (id % (BK / 4)) * 4;
+                S[k + 0][r] = v[i].x;
+                S[k + 1][r] = v[i].y;
+                S[k + 2][r] = v[i].z;
+                S[k + 3][r] = v[i].w;
+            } else {
+                const int k = id / (TILE / 4), r = (id % (TILE / 4)) * 4;
+                *(float4*)&S[k][r] = v[i];
+            }
+        }
+    }
+};
+
+// C[m][n] (+)= alpha * sum_k A(m,k) * B(n,k)   (fp32 MFMA 32x32x2: exact fp32 products, fp32 accumulation in K order)
+// TILE x TILE output per workgroup, 4 waves as 2 x 2, (TILE/64)^2 MFMA tiles per wave; the next K slab is fetched into
+// registers while the current one is multiplied.
+template <int TILE, bool AK, bool BKF>
+__global__ __launch_bounds__(kSgThreads) void sgemm_kernel(const float* __restrict__ A, int64_t lda,
+                                                           const float* __restrict__ B, int64_t ldb,
                                                            float* __restrict__ C, int64_t ldc, int64_t M, int64_t N,
-                                                           int64_t K, float alpha, int accumulate) {
-    __shared__ float As[kSgBK][kSgLd];
-    __shared__ float Bs[kSgBK][kSgLd];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int64_t m0 = (int64_t)blockIdx.y * kSgTile, n0 = (int64_t)blockIdx.x * kSgTile;
+                                                           int64_t K, float alpha, int accumulate, int vec) {
+    constexpr int BK = kSgSlab / TILE, LD = TILE + 4, WT = TILE / 64;
+    __shared__ __attribute__((aligned(16))) float As[BK][LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BK][LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t m0 = (int64_t)blockIdx.y * TILE, n0 = (int64_t)blockIdx.x * TILE;
     const int wm = wave >> 1, wn = wave & 1;
-    f32x16 acc;
+    f32x16 acc[WT][WT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const bool a_kfast = (sak == 1), b_kfast = (sbk == 1);
-    for (int64_t k0 = 0; k0 < K; k0 += kSgBK) {
+    for (int i = 0; i < WT; ++i)
 #pragma unroll
-        for (int i = 0; i < (kSgTile * kSgBK) / kSgThreads; ++i) {
-            const int e = t + i * kSgThreads;
-            {
-                const int kk = a_kfast ? (e % kSgBK) : (e / kSgTile);
-                const int mm = a_kfast ? (e / kSgBK) : (e % kSgTile);
-                const int64_t m = m0 + mm, k = k0 + kk;
-                As[kk][mm] = (m < M && k < K) ? A[m * sam + k * sak] : 0.f;
-            }
-            {
-                const int kk = b_kfast ? (e % kSgBK) : (e / kSgTile);
-                const int nn = b_kfast ? (e / kSgBK) : (e % kSgTile);
-                const int64_t n = n0 + nn, k = k0 + kk;
-                Bs[kk][nn] = (n < N && k < K) ? B[n * sbn + k * sbk] : 0.f;
-            }
-        }
+        for (int j = 0; j < WT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    SgOperand<TILE, AK> oa;
+    SgOperand<TILE, BKF> ob;
+    oa.fetch(A, lda, m0, M, 0, K, vec & 1);
+    ob.fetch(B, ldb, n0, N, 0, K, (vec >> 1) & 1);
+    for (int64_t k0 = 0; k0 < K; k0 += BK) {
+        oa.stash(As);
+        ob.stash(Bs);
         __syncthreads();
+        if (k0 + BK < K) {
+            oa.fetch(A, lda, m0, M, k0 + BK, K, vec & 1);
+            ob.fetch(B, ldb, n0, N, k0 + BK, K, (vec >> 1) & 1);
+        }
 #pragma unroll
-        for (int ks = 0; ks < kSgBK; ks += 2) {
-            const float a = As[ks + (lane >> 5)][wm * 32 + (lane & 31)];
-            const float b = Bs[ks + (lane >> 5)][wn * 32 + (lane & 31)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        for (int ks = 0; ks < BK; ks += 2) {
+            float a[WT], b[WT];
+#pragma unroll
+            for (int i = 0; i < WT; ++i) a[i] = As[ks + (lane >> 5)][(wm * WT + i) * 32 + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < WT; ++j) b[j] = Bs[ks + (lane >> 5)][(wn * WT + j) * 32 + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < WT; ++i)
+#pragma unroll
+                for (int j = 0; j < WT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
-    const int64_t n = n0 + wn * 32 + (lane & 31);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < M && n < N) {
-            const float v = __fmul_rn(alpha, acc[r]);
-            float* c = C + m * ldc + n;
-            *c = accumulate ? __fadd_rn(*c, v) : v;
+    for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int j = 0; j < WT; ++j) {
+            const int64_t n = n0 + (wn * WT + j) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + (wm * WT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < M && n < N) {
+                    const float v = __fmul_rn(alpha, acc[i][j][r]);
+                    float* c = C + m * ldc + n;
+                    *c = accumulate ? __fadd_rn(*c, v) : v;
+                }
+            }
         }
-    }
 }
 
+template <int TILE>
+static void sgemm_dispatch(bool ak, bool bk, dim3 grid, hipStream_t st, const float* A, int64_t lda, const float* B,
+                           int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha,
+                           int accumulate, int vec) {
+    if (ak && bk)
+        hipLaunchKernelGGL((sgemm_kernel<TILE, true, true>), grid, dim3(kSgThreads), 0, st, A, lda, B, ldb, C, ldc, M, N, K,
+                           alpha, accumulate, vec);
+    else if (ak && !bk)
+        hipLaunchKernelGGL((sgemm_kernel<TILE, true, false>), grid, dim3(kSgThreads), 0, st, A, lda, B, ldb, C, ldc, M, N,
+                           K, alpha, accumulate, vec);
+    else if (!ak && bk)
+        hipLaunchKernelGGL((sgemm_kernel<TILE, false, true>), grid, dim3(kSgThreads), 0, st, A, lda, B, ldb, C, ldc, M, N,
+                           K, alpha, accumulate, vec);
+    else
+        hipLaunchKernelGGL((sgemm_kernel<TILE, false, false>), grid, dim3(kSgThreads), 0, st, A, lda, B, ldb, C, ldc, M, N,
+                           K, alpha, accumulate, vec);
+}
+
+// A(m,k) = A[m*sam + k*sak], B(n,k) = B[n*sbn + k*sbk]; exactly one stride of each operand is 1
 static int launch_sgemm(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbn, int64_t sbk, float* C,
                         int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha, int accumulate, hipStream_t st) {
     if (M <= 0 || N <= 0) return LDOT_OK;
-    dim3 grid((unsigned)((N + kSgTile - 1) / kSgTile), (unsigned)((M + kSgTile - 1) / kSgTile));
-    hipLaunchKernelGGL(sgemm_kernel, grid, dim3(kSgThreads), 0, st, A, sam, sak, B, sbn, sbk, C, ldc, M, N, K, alpha,
-                       accumulate);
+    const bool ak = (sak == 1), bk = (sbk == 1);
+    const int64_t lda = ak ? sam : sak, ldb = bk ? sbn : sbk;
+    const int vec = ((lda % 4 == 0 && ((uintptr_t)A & 15) == 0) ? 1 : 0) | ((ldb % 4 == 0 && ((uintptr_t)B & 15) == 0) ? 2 : 0);
+    // 128^2 tiles once they alone fill the chip, else 64^2 (more workgroups: these problems are latency bound)
+    if ((M + 127) / 128 * ((N + 127) / 128) >= 256) {
+        dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
+        sgemm_dispatch<128>(ak, bk, grid, st, A, lda, B, ldb, C, ldc, M, N, K, alpha, accumulate, vec);
+    } else {
+        dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
+        sgemm_dispatch<64>(ak, bk, grid, st, A, lda, B, ldb, C, ldc, M, N, K, alpha, accumulate, vec);
+    }
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }
