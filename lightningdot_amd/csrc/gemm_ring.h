@@ -172,10 +172,10 @@ __device__ __forceinline__ void ringr_read_b(const RingCtx& c, const char* stage
 }
 
 // one k-step: MFMAs on (a[*], bcur) while a[*] is reloaded from (nstage, nks) and bnext is fetched
-template <int MR>
+template <int MR, bool SKIP_B = false>
 __device__ __forceinline__ void ringr_step(const RingCtx& c, FragsR<MR>& f, const int cur, const char* nstage,
                                            const int nks, f32x16 (&acc)[MR][2]) {
-    ringr_read_b<MR>(c, nstage, nks, f.b[cur ^ 1]);
+    if (!SKIP_B) ringr_read_b<MR>(c, nstage, nks, f.b[cur ^ 1]);   // (SKIP_B: profiling ablation only)
     const char* a_w = nstage + c.wm * (32 * MR * 64) + c.frag_off[nks];
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {

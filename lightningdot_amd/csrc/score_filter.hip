@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
                     } while (l_t >= ntiles);
                     sb.rsrc = ring_make_rsrc_n(Q16 + (int64_t)(qsub + l_q * qg) * kRBN * ldq_b, kRBN * ldq_b);
                 }
-                sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)l_t * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
+                sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)((VAR & 64) ? (l_t & 31) : l_t) * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
             }
         }
     };
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     int64_t s = 0;
     auto slab = [&]() {
         // k-step 0 of slab s (operands: a, b[0]); a <- k-step 1 of slab s, b[1] <- k-step 1 of slab s
-        if (!(VAR & 4)) ringr_step<MR>(c, f, 0, smem + (int)(s & 3) * Geo::kStage, 1, acc);
+        if (!(VAR & 4)) ringr_step<MR, (VAR & 32) != 0>(c, f, 0, smem + (int)(s & 3) * Geo::kStage, 1, acc);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of slab s are complete (WAR on its stage)
         if (VAR & 2)
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
         __builtin_amdgcn_s_barrier();                        // ... and everybody else's
         ++s;
         // k-step 1 of the old slab (operands: a, b[1]); a, b[0] <- k-step 0 of slab s (just opened)
-        if (!(VAR & 4)) ringr_step<MR>(c, f, 1, smem + (int)(s & 3) * Geo::kStage, 0, acc);
+        if (!(VAR & 4)) ringr_step<MR, (VAR & 32) != 0>(c, f, 1, smem + (int)(s & 3) * Geo::kStage, 0, acc);
         __builtin_amdgcn_sched_barrier(0);
         issue();                                             // slab s+3 (or a dummy) -> the stage slab s-1 vacated
     };
@@ -270,6 +270,8 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     if (variant == 16) rk = score_filter_r6_kernel<16>;
     if (variant == 18) rk = score_filter_r6_kernel<18>;
     if (variant == 20) rk = score_filter_r6_kernel<20>;
+    if (variant == 48) rk = score_filter_r6_kernel<48>;
+    if (variant == 80) rk = score_filter_r6_kernel<80>;   // 16 + every row tile aliased onto the first 32 tiles (all L2 hits)   // 16 + B-fragment ds_reads skipped (LDS read traffic -25 %)
     LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<6>::kLds));
     const int qg = fused_query_group(nq_pad);
     const int qg_log2 = qg == 8 ? 3 : qg == 4 ? 2 : qg == 2 ? 1 : 0;
