@@ -1,75 +1,45 @@
-// bf16 MFMA engine, second generation: a continuous stream of 32-deep K slabs through a 4-stage LDS ring.
+// bf16 MFMA engine on an LDS ring: a continuous stream of 32-deep K slabs through a 4-stage ring, (64*MR) x 256 tile.
 //
-//   * workgroup = 512 threads = 8 waves (2 along M x 4 along N), wave tile 128 x 64 (4 x 2 MFMA 32x32 tiles)
-//   * one slab = A rows [256] x 32 k  +  B rows [256] x 32 k  = 2 x 16 KiB; ring of 4 slabs = 128 KiB LDS
-//   * direct-to-LDS loads (global_load_lds_dwordx4); 64-byte LDS rows, 16-byte chunk index XOR ((row >> 2) & 3)
+//   * workgroup = 512 threads = 8 waves (2 along M x 4 along N), wave tile (32*MR) x 64 (MR x 2 MFMA 32x32 tiles)
+//   * one slab = A rows [64*MR] x 32 k  +  B rows [256] x 32 k; MR = 6: 24 + 16 KiB, ring of 4 slabs = 160 KiB = all LDS
+//   * direct-to-LDS loads (buffer_load ... lds, 16 B/lane); 64-byte LDS rows, 16-byte chunk index XOR ((row >> 2) & 3)
 //     applied on the per-lane SOURCE address and on the ds_read address -> conflict-free ds_read_b128
-//   * slabs are issued 3 ahead of the one being multiplied (96 KiB in flight per CU) and retired with a COUNTED
-//     s_waitcnt vmcnt(8): the loads of the next slabs stay in flight across the single raw s_barrier per slab
-//   * fragments are double-buffered in registers (F: k-step 0, G: k-step 1 of a slab) and the MFMAs of the last
-//     k-step of slab s are issued AFTER the barrier that opens slab s+1, so the matrix pipe has 8 MFMAs per wave
-//     to chew on while the first ds_reads of the new slab are in flight (no restart bubble)
+//   * slabs are issued 3 ahead of the one being multiplied and retired with a COUNTED s_waitcnt vmcnt: the loads of the
+//     next slabs stay in flight across the single raw s_barrier per slab
+//   * only the two B fragments are double-buffered in registers; every A fragment register is reloaded in place with
+//     the next k-step's data right after the two MFMAs that consume it (it then has (MR-1)*2 MFMA times to land)
 //   * the slab stream runs across output tiles: the loads of the next tile's first slabs are in flight while the
 //     current tile's epilogue (the threshold filter) runs.
+// (Earlier generations — 256x256 with a two-stage BK=64 pipeline and with double-buffered fragments on this ring — are in
+// the history: commits da2a5a4, 62cbd68.)
 #pragma once
 #include "ldot_common.h"
 
 namespace ldot {
 
-constexpr int kRBM = 256, kRBN = 256, kRBK = 32;
+constexpr int kRBN = 256, kRBK = 32;              // queries per tile, K depth of a slab
 constexpr int kRingThreads = 512;
 constexpr int kRingStages = 4;
-constexpr int kROpBytes = kRBM * kRBK * 2;        // 16 KiB per operand slab
-constexpr int kRStageBytes = 2 * kROpBytes;       // 32 KiB
-constexpr int kRingLdsBytes = kRingStages * kRStageBytes;   // 128 KiB
-constexpr int kRLoadsPerSlab = 4;                 // global_load_lds per thread per slab (2 A + 2 B)
+constexpr int kROpBytes = kRBN * kRBK * 2;        // 16 KiB: the B (query) slab
 
-typedef const __attribute__((address_space(1))) void* rg_gptr_t;
 typedef __attribute__((address_space(3))) void* rg_lptr_t;
-
-struct Frags {
-    bf16x8_t a[4], b[2];
-};
 
 struct RingCtx {
     int lane, wave, wm, wn;
     int frag_off[2];   // per-lane byte offset of k-step ks inside a 32-row block (64-byte rows)
-    int st_row[2];     // source row (within the 256-row slab) of staging instruction j
+    int st_row[2];     // source row (within a 256-row slab) of staging instruction j
     int st_col;        // source byte offset inside the 64-byte slab row
 };
 
 // Buffer-addressed staging: the operand panel of the current tile is described by a buffer resource (SGPRs, base
-// = first row of the panel), each lane keeps two constant 32-bit offsets (its rows of the two staging
-// instructions) and the K position rides in the scalar offset -> ZERO vector instructions per load.
+// = first row of the panel), each lane keeps constant 32-bit offsets (its rows of the staging instructions) and the
+// K position rides in the scalar offset -> ZERO vector instructions per load.
 struct RingSrc {
     __amdgpu_buffer_rsrc_t rsrc;
-    int voff[2];
 };
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t ring_make_rsrc(const char* panel_base, int64_t ld_bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)panel_base, 0, (int)(kRBM * ld_bytes), 0x00020000);
-}
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t ring_make_rsrc_n(const char* panel_base, int64_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)panel_base, 0, (int)bytes, 0x00020000);
-}
-
-template <int AUX = 0>
-__device__ __forceinline__ void ring_stage_operand_buf(const RingCtx& c, const RingSrc& src, int k0b, char* lds_slab) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (rg_lptr_t)(lds_slab + (j * 8 + c.wave) * 1024), 16,
-                                                 src.voff[j], k0b, 0, AUX);
-}
-
-// MFMA with a zero C operand (first k-step of an output tile): no accumulator clearing pass needed
-__device__ __forceinline__ void ring_mfma_first(const Frags& f, f32x16 (&acc)[4][2]) {
-    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int mr = 0; mr < 4; ++mr)
-#pragma unroll
-        for (int nr = 0; nr < 2; ++nr)
-            acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mr], f.b[nr], z, 0, 0, 0);
 }
 
 // hand a loaded value to the compiler as a plain register (its own s_waitcnt for the load is placed HERE, not at a
@@ -96,55 +66,6 @@ __device__ __forceinline__ void ring_ctx_init(RingCtx& c) {
     c.st_col = (((c.lane & 3) ^ ((c.lane >> 4) & 3)) << 4);
 }
 
-__device__ __forceinline__ void ring_stage_operand(const RingCtx& c, const char* __restrict__ base, int64_t ld_bytes,
-                                          int64_t row0, int k0b, char* lds_slab) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const char* src = base + (row0 + c.st_row[j]) * ld_bytes + k0b + c.st_col;
-        __builtin_amdgcn_global_load_lds((rg_gptr_t)src, (rg_lptr_t)(lds_slab + (j * 8 + c.wave) * 1024), 16, 0, 0);
-    }
-}
-
-__device__ __forceinline__ void ring_read_frags(const RingCtx& c, const char* stage, int ks, Frags& f) {
-    const char* a_w = stage + c.wm * (128 * 64) + c.frag_off[ks];
-    const char* b_w = stage + kROpBytes + c.wn * (64 * 64) + c.frag_off[ks];
-#pragma unroll
-    for (int mr = 0; mr < 4; ++mr) f.a[mr] = *(const bf16x8_t*)(a_w + mr * 2048);
-#pragma unroll
-    for (int nr = 0; nr < 2; ++nr) f.b[nr] = *(const bf16x8_t*)(b_w + nr * 2048);
-}
-
-__device__ __forceinline__ void ring_mfma(const Frags& f, f32x16 (&acc)[4][2]) {
-#pragma unroll
-    for (int mr = 0; mr < 4; ++mr)
-#pragma unroll
-        for (int nr = 0; nr < 2; ++nr)
-            acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mr], f.b[nr], acc[mr][nr], 0, 0, 0);
-}
-
-__device__ __forceinline__ void ring_zero(f32x16 (&acc)[4][2]) {
-#pragma unroll
-    for (int mr = 0; mr < 4; ++mr)
-#pragma unroll
-        for (int nr = 0; nr < 2; ++nr)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.f;
-}
-
-// wait until at most `slabs_in_flight` slabs (4 loads each) of this thread's direct-to-LDS loads are outstanding
-__device__ __forceinline__ void ring_wait_loads(int slabs_in_flight) {
-    if (slabs_in_flight >= 3)
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (slabs_in_flight == 2)
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (slabs_in_flight == 1)
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-
-// ---- third generation: (64*MR) x 256 tile, A fragments recycled in place -------------------------------------------
 // Wave tile (32*MR) x 64.  Per k-step the wave needs MR A fragments + 2 B fragments; only the B pair is double-buffered,
 // every A fragment register is reloaded with the NEXT k-step's data right after the two MFMAs that consume it were
 // issued (it then has (MR-1)*2 MFMA times to land).  MR = 6: 192 accumulator + 24 + 16 fragment VGPRs.
@@ -184,11 +105,5 @@ __device__ __forceinline__ void ringr_step(const RingCtx& c, FragsR<MR>& f, cons
         f.a[mr] = *(const bf16x8_t*)(a_w + mr * 2048);
     }
 }
-
-template <int MR>
-struct RingSrcR {
-    __amdgpu_buffer_rsrc_t rsrc;
-    int voff[RingGeom<MR>::kALoads > 2 ? RingGeom<MR>::kALoads : 2];
-};
 
 }  // namespace ldot

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
 #pragma unroll
     for (int j = 0; j < 2; ++j) vb[j] = c.st_row[j] * (int)ldq_b + c.st_col;
     int l_q = g0, l_t = t0, l_k = 0;
-    RingSrc sa, sb;   // (voff members unused here)
+    RingSrc sa, sb;
     sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)l_t * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
     sb.rsrc = ring_make_rsrc_n(Q16 + (int64_t)(qsub + l_q * qg) * kRBN * ldq_b, kRBN * ldq_b);
     int64_t issued = 0;
