@@ -17,7 +17,12 @@ template <int DT>
 __global__ __launch_bounds__(256) void convert_rows_kernel(const void* __restrict__ src, int64_t ld_src, int64_t n,
                                                            int64_t n_pad, int d, int dpad, int normalize,
                                                            float* __restrict__ dst32,
-                                                           uint16_t* __restrict__ dst16, int split) {
+                                                           uint16_t* __restrict__ dst16, int split,
+                                                           uint16_t* __restrict__ dst16b, int64_t row0b) {
+    // dst16b (optional): the same shadow row in the BLOCKED layout the fused kernel streams — 16 rows x 32 k (1 KiB) blocks,
+    // block (g, s) at ((g * nslab + s) * 512 elements, row r % 16 at +32 * (r % 16): one wave-level direct-to-LDS load
+    // instruction of the ring engine then reads ONE contiguous KiB (full 128-B lines) instead of 16 half lines.
+    // dst16b is the ARRAY base and row0b the array row of this launch's row 0 (blocks straddle launches).
     // split = 0: dst16 row = [bf16(v)] (dpad);  split-bf16 operands (3 * dpad per row, v ~ hi + lo to 16 mantissa bits):
     // split = 1 (index side): [hi | hi | lo],  split = 2 (query side): [hi | lo | hi]  so that one K = 3*dpad contraction
     // yields hi.hi + hi.lo + lo.hi
@@ -30,6 +35,10 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(const void* __restric
             if (dst32) dst32[row * dpad + c] = 0.f;
         if (dst16)
             for (int64_t c = lane; c < ld16; c += 64) dst16[row * ld16 + c] = 0;
+        if (dst16b) {
+            const int64_t rb = row0b + row, nslab = ld16 / 32;
+            for (int64_t c = lane; c < ld16; c += 64) dst16b[((rb >> 4) * nslab + (c >> 5)) * 512 + (rb & 15) * 32 + (c & 31)] = 0;
+        }
         return;
     }
     const int64_t so = row * ld_src;
@@ -53,38 +62,39 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(const void* __restric
             if (normalize) v = v * scale;
         }
         if (dst32) dst32[row * dpad + c] = v;
-        if (dst16) {
+        if (dst16 || dst16b) {
             const uint16_t hi = f32_to_bf16_bits(v);
-            if (!split) {
-                dst16[row * ld16 + c] = hi;
-            } else {
-                const uint16_t lo = f32_to_bf16_bits(v - bf16_bits_to_f32(hi));   // exact difference, then rounded
-                uint16_t* o = dst16 + row * ld16 + c;
-                o[0] = hi;
-                o[dpad] = split == 1 ? hi : lo;
-                o[2 * dpad] = split == 1 ? lo : hi;
+            const uint16_t lo = split ? f32_to_bf16_bits(v - bf16_bits_to_f32(hi)) : 0;   // exact difference, then rounded
+            const int nseg = split ? 3 : 1;
+            const int64_t rb = row0b + row, nslab = ld16 / 32;
+            for (int sgm = 0; sgm < nseg; ++sgm) {
+                const uint16_t val = (sgm == 0) ? hi : ((sgm == 1) == (split == 1) ? hi : lo);
+                const int64_t cc = (int64_t)sgm * dpad + c;
+                if (dst16) dst16[row * ld16 + cc] = val;
+                if (dst16b) dst16b[((rb >> 4) * nslab + (cc >> 5)) * 512 + (rb & 15) * 32 + (cc & 31)] = val;
             }
         }
     }
 }
 
 int launch_convert_rows(const void* src, int dtype, int64_t ld_src, int64_t n, int64_t n_pad, int d, int dpad,
-                        int normalize, float* dst32, uint16_t* dst16, int split, hipStream_t st) {
+                        int normalize, float* dst32, uint16_t* dst16, int split, uint16_t* dst16b, int64_t row0b,
+                        hipStream_t st) {
     if (n_pad < n) n_pad = n;
     if (n_pad <= 0) return LDOT_OK;
     const dim3 grid((unsigned)((n_pad + 3) / 4)), block(256);
     switch (dtype) {
         case LDOT_F32:
             hipLaunchKernelGGL(convert_rows_kernel<LDOT_F32>, grid, block, 0, st, src, ld_src, n, n_pad, d, dpad, normalize,
-                               dst32, dst16, split);
+                               dst32, dst16, split, dst16b, row0b);
             break;
         case LDOT_BF16:
             hipLaunchKernelGGL(convert_rows_kernel<LDOT_BF16>, grid, block, 0, st, src, ld_src, n, n_pad, d, dpad, normalize,
-                               dst32, dst16, split);
+                               dst32, dst16, split, dst16b, row0b);
             break;
         case LDOT_F16:
             hipLaunchKernelGGL(convert_rows_kernel<LDOT_F16>, grid, block, 0, st, src, ld_src, n, n_pad, d, dpad, normalize,
-                               dst32, dst16, split);
+                               dst32, dst16, split, dst16b, row0b);
             break;
         default:
             set_error("unsupported dtype %d", dtype);

@@ -17,8 +17,11 @@ constexpr int kPoolSubsMax = 1024;   // query-group width 1: 256 row slices x 4 
 // rows: convert n rows of `dtype` (row stride ld_src elements, d valid columns) into the padded fp32 master copy
 // and/or its bf16 shadow (row stride dpad, zero padded); optional L2 normalisation.  Rows [n, n_pad) are zero-filled.
 // split != 0: split-bf16 shadow of 3 * dpad per row (1: index side [hi|hi|lo], 2: query side [hi|lo|hi]).
+// dst16b (optional, ARRAY base; row0b = array row of this launch's first row): the same shadow in the blocked layout of
+// the fused kernel (1 KiB blocks of 16 rows x 32 k).
 int launch_convert_rows(const void* src, int dtype, int64_t ld_src, int64_t n, int64_t n_pad, int d, int dpad,
-                        int normalize, float* dst32, uint16_t* dst16, int split, hipStream_t st);
+                        int normalize, float* dst32, uint16_t* dst16, int split, uint16_t* dst16b, int64_t row0b,
+                        hipStream_t st);
 
 int launch_score_dense(const void* q16, int64_t ldq_elems, int64_t nq_pad, const void* x16, int64_t ldx_elems,
                        int64_t xrow0, int64_t nrows_pad, int dpad, float* S, int64_t lds_elems, int64_t nq_valid,
@@ -52,7 +55,8 @@ int launch_rescore(const float* q32, int64_t ldq, const float* x32, int64_t ldx,
 int fused_tile_rows();
 int fused_query_group(int64_t nq_pad);   // 8 / 4 / 2 / 1 -> 1024 / qg sub-pools per query, 256 / qg row slices
 
-// fused MFMA score + threshold filter over index rows [row0, row0 + nrows) (nrows_pad multiple of 256)
+// fused MFMA score + threshold filter over index rows [row0, row0 + nrows) (row0 multiple of 16); x16 / q16 are the BLOCKED
+// shadows (launch_convert_rows dst16b)
 int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_t nrows, const void* q16,
                         int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, uint2* pool, int32_t* pool_cnt,
                         hipStream_t st);

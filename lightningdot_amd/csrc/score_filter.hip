@@ -21,6 +21,12 @@
 // With qg = 8 the 32 workgroups of an XCD work on 8 query panels x 4 adjacent row tiles, so the private L2 holds
 // 8 Q panels (3 MiB) and streams each row panel once per query group.
 //
+// Operand layout: both bf16 shadows are read in the BLOCKED layout written by convert_rows_kernel (dst16b): 1 KiB blocks of
+// 16 rows x 32 k, block (g, s) of a 16-row group g and K slab s at ((g * nslab + s) KiB.  One wave-level direct-to-LDS load
+// instruction (64 lanes x 16 B = 16 rows x 64 B of one slab) then reads one contiguous KiB = eight full 128-B lines; with
+// row-major operands the same instruction touched 16 half lines, and the L2 request rate (one 64-B request per half line,
+// ~0.8 per clock and channel) bounded the L2->LDS stream: loads-only time 8.7 -> 5.9 ms, kernel -5.5 %.
+//
 // Earlier generations of this kernel (256x256 two-stage, commit da2a5a4; 256x256 on the LDS ring, commit 62cbd68) are in
 // the history; their measurements are in DESIGN.md section 5.2.
 #include <math.h>
@@ -120,9 +126,9 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     // ---- load cursor (see the second-generation kernel) ---------------------------------------------------------
     int va[Geo::kALoads], vb[2];
 #pragma unroll
-    for (int j = 0; j < Geo::kALoads; ++j) va[j] = ((j * 8 + c.wave) * 16 + (c.lane >> 2)) * (int)ldx_b + c.st_col;
+    for (int j = 0; j < Geo::kALoads; ++j) va[j] = (j * 8 + c.wave) * 16 * (int)ldx_b + (c.lane >> 2) * 64 + c.st_col;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) vb[j] = c.st_row[j] * (int)ldq_b + c.st_col;
+    for (int j = 0; j < 2; ++j) vb[j] = (j * 8 + c.wave) * 16 * (int)ldq_b + (c.lane >> 2) * 64 + c.st_col;
     int l_q = g0, l_t = t0, l_k = 0;
     RingSrc sa, sb;
     sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)l_t * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     int64_t issued = 0;
     auto issue = [&]() {
         char* st = smem + (int)(issued & 3) * Geo::kStage;
-        const int k0b = l_k * (kRBK * 2);
+        const int k0b = l_k * 1024;   // slab l_k of a 16-row group = its l_k-th KiB block
         if (!(VAR & 2) || issued < 4)
 #pragma unroll
         for (int j = 0; j < Geo::kALoads; ++j)
@@ -271,7 +277,7 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     if (variant == 18) rk = score_filter_r6_kernel<18>;
     if (variant == 20) rk = score_filter_r6_kernel<20>;
     if (variant == 48) rk = score_filter_r6_kernel<48>;
-    if (variant == 80) rk = score_filter_r6_kernel<80>;   // 16 + every row tile aliased onto the first 32 tiles (all L2 hits)   // 16 + B-fragment ds_reads skipped (LDS read traffic -25 %)
+    if (variant == 80) rk = score_filter_r6_kernel<80>;
     LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<6>::kLds));
     const int qg = fused_query_group(nq_pad);
     const int qg_log2 = qg == 8 ? 3 : qg == 4 ? 2 : qg == 2 ? 1 : 0;
