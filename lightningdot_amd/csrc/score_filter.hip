@@ -258,6 +258,12 @@ int fused_tile_rows() { return RingGeom<6>::kBM; }
 // has 256 / qg row slices and 1024 / qg sub-pools per query
 int fused_query_group(int64_t nq_pad) {
     const int64_t nqb = nq_pad / kRBN;
+    static int force = -1;   // LDOT_DEBUG_QG: experiment override (1, 2, 4 or 8)
+    if (force < 0) {
+        const char* e = getenv("LDOT_DEBUG_QG");
+        force = e ? atoi(e) : 0;
+    }
+    if (force == 1 || force == 2 || force == 4 || force == 8) return force;
     return nqb >= 8 ? 8 : nqb >= 4 ? 4 : nqb >= 2 ? 2 : 1;
 }
 
