@@ -16,6 +16,7 @@ def run(name, n_img, cpi, d=768, k=100):
     for direction, x, q, gt in (('txt2img', img, cap, torch.arange(n_img, device='cuda').repeat_interleave(cpi)),
                                 ('img2txt', cap, img.repeat_interleave(cpi, 0), None)):
         ix = FlatIPIndex(d)
+        if os.environ.get('MODE'): ix.set_option(1, int(os.environ['MODE']))
         torch.cuda.synchronize(); t0 = time.perf_counter()
         ix.add(x); torch.cuda.synchronize(); t_add = time.perf_counter() - t0
         ix.search_tensors(q, k); torch.cuda.synchronize()
