@@ -317,3 +317,31 @@ def test_split_bf16_precision_on_crowded_scores(L, n, mode):
     s1, l1 = ix.search(q, k)
     np.testing.assert_array_equal(l1, l)
     np.testing.assert_array_equal(s1, s)
+
+
+@pytest.mark.gpu
+def test_reset_then_refill_and_growth(L):
+    """reset() clears all three copies of the rows (fp32 master, row-major and blocked bf16 shadows); capacity growth copies
+    them (the blocked shadow in whole 16-row blocks, also when ntotal is not a multiple of 16)."""
+    rng = np.random.default_rng(3)
+    d, k = 64, 20
+    x1 = rng.standard_normal((40003, d)).astype(np.float32)
+    x2 = (rng.standard_normal((41001, d)) * 0.5).astype(np.float32)
+    q = rng.standard_normal((300, d)).astype(np.float32)
+    ix = _index(x1, mode=L.MODE_FUSED)
+    ix.search(q, k)
+    ix.reset()
+    assert ix.ntotal == 0
+    s, l = ix.search(q, k)
+    assert (l == -1).all()
+    ix.add(x2[:7])                     # partly filled first block
+    ix.add(x2[7:20011])
+    ix.add(x2[20011:])                 # crosses the old capacity: growth with copy
+    assert ix.ntotal == x2.shape[0]
+    s, l = ix.search(q, k)
+    assert ix.last_stats()['fused_pairs'] > 0
+    assert_topk_matches(q, x2, s, l, k)
+    more = rng.standard_normal((60000, d)).astype(np.float32)
+    ix.add(more)                       # second growth
+    s, l = ix.search(q, k)
+    assert_topk_matches(q, np.concatenate([x2, more]), s, l, k)
