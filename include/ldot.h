@@ -98,6 +98,16 @@ int ldot_index_set_option(ldot_index_t* ix, int option, int64_t value);
 /* out_scores: [nq*k] float, out_labels: [nq*k] int64, both in `out_mem` space. */
 int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize,
                       int k, float* out_scores, int64_t* out_labels, int out_mem, void* stream);
+/* The same search in two halves, for the row-sharded index (no reference counterpart): _begin generates the k'
+ * candidates of every query on this shard and copies their thresholds (the k'-th best candidate score per query, -inf
+ * while a query has fewer than k' candidates) to tau_out [nq] (device, may be NULL); the caller exchanges them
+ * (all-reduce MAX over the shards: at least k' candidates score >= that maximum globally, so nothing below it can be
+ * among the global k' best) and passes the result as `floor` [nq] (device, or NULL) to _finish, which re-scores only
+ * the candidates at or above the floor and writes the shard's partial top-k.  ldot_index_search = _begin + _finish(NULL). */
+int ldot_index_search_begin(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k,
+                            float* tau_out, void* stream);
+int ldot_index_search_finish(ldot_index_t* ix, const float* floor, float* out_scores, int64_t* out_labels, int out_mem,
+                             void* stream);
 /* own on-disk format ("LDOTIDX1": header + fp32 rows); bf16 shadow is rebuilt on load */
 int ldot_index_save(ldot_index_t* ix, const char* path);
 int ldot_index_load(const char* path, ldot_index_t** out);

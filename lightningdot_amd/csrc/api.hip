@@ -76,6 +76,9 @@ struct ldot_index {
     // the sub-pool counters and overflow flags are all-zero between searches (the pool select resets the counters it
     // reads); they are cleared only after a (re)allocation or an aborted / overflowed search
     bool pools_clean = false;
+    // a search in two halves (ldot_index_search_begin / _finish): what _finish needs to know
+    int64_t pend_nq = 0;
+    int pend_k = 0, pend_kp = 0;
 };
 
 static int index_reserve(ldot_index* ix, int64_t rows, hipStream_t st) {
@@ -358,7 +361,7 @@ static int dense_scan(ldot_index* ix, int64_t q0, int64_t nqb, int64_t nqb_pad, 
 // Few queries (one query tile) x many rows — the single-query serving shape (dvl/utils.py:204-211): one wide score
 // launch over up to 4M rows (only the valid query rows are stored), a segmented select with (query, segment)
 // parallelism and one merge.  HBM-bound: the index is streamed once.
-static int dense_scan_wide(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, int kp, hipStream_t st) {
+static int dense_scan_wide(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, int kp, float* tau, hipStream_t st) {
     const int64_t wide = (int64_t)1 << 22, seg_cols = 16384;
     float* ls = (float*)ix->w_ls.p;
     int32_t* li = (int32_t*)ix->w_li.p;
@@ -386,15 +389,17 @@ static int dense_scan_wide(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, i
         if ((rc = launch_select_lists(ps, pl, nq * kp, (int)nseg + 1, kp, nq, kp, (float*)ix->w_mrg_s.p,
                                       (int64_t*)ix->w_mrg_l.p, st)))
             return rc;
-        if ((rc = launch_parts_to_lists((const float*)ix->w_mrg_s.p, (const int64_t*)ix->w_mrg_l.p, nq * kp, ls, li, st)))
+        if ((rc = launch_parts_to_lists((const float*)ix->w_mrg_s.p, (const int64_t*)ix->w_mrg_l.p, nq * kp, ls, li, kp, tau, st)))
             return rc;
         ix->stats[2] += nrows * nq;
     }
     return LDOT_OK;
 }
 
-static int dense_scan_all(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, int kp, float* tau, hipStream_t st) {
-    if (nq <= kBM && tau == nullptr && r1 - r0 > 2 * ix->chunk_rows) return dense_scan_wide(ix, nq, r0, r1, kp, st);
+// (tau is always maintained: the fused scan continues from it, a sharded search exchanges it)
+static int dense_scan_all(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, int kp, float* tau, bool allow_wide,
+                          hipStream_t st) {
+    if (allow_wide && nq <= kBM && r1 - r0 > 2 * ix->chunk_rows) return dense_scan_wide(ix, nq, r0, r1, kp, tau, st);
     // query blocks bound the dense score workspace (<= ~2 GiB at the default chunk)
     const int64_t qb_max = std::max<int64_t>(kBM, ((int64_t)1 << 29) / ix->chunk_rows / kBM * kBM);
     for (int64_t q0 = 0; q0 < nq; q0 += qb_max) {
@@ -420,7 +425,7 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
     const int64_t nslices = 256 / qg, nsubs = 4 * nslices;
     const int64_t warm =
         std::min(ix->ntotal, std::max<int64_t>(ix->warm_rows, round_up(bm * nslices * (int64_t)kp / 1024, 256)));
-    if ((rc = dense_scan_all(ix, nq, 0, warm, kp, tau, st))) return rc;
+    if ((rc = dense_scan_all(ix, nq, 0, warm, kp, tau, false, st))) return rc;
     if (warm >= ix->ntotal) return LDOT_OK;
     if ((rc = ix->w_pool.ensure((size_t)nq_pad * nsubs * kPoolCap * 8))) return rc;
     const size_t cnt_bytes = (size_t)nq_pad * nsubs * 4, over_bytes = (size_t)nq_pad * 4;
@@ -468,16 +473,16 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
     return LDOT_OK;
 }
 
-int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k,
-                      float* out_scores, int64_t* out_labels, int out_mem, void* stream) {
+int ldot_index_search_begin(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k,
+                            float* tau_out, void* stream) {
     LDOT_REQUIRE(ix != nullptr, LDOT_EINVAL, "index is NULL");
     LDOT_REQUIRE(nq >= 0, LDOT_EINVAL, "negative query count");
     LDOT_REQUIRE(k >= 1 && k <= kMaxK, LDOT_EINVAL, "k must be in [1, %d] (got %d)", kMaxK, k);
     LDOT_REQUIRE(dtype >= 0 && dtype <= 2, LDOT_EINVAL, "bad dtype %d", dtype);
-    LDOT_REQUIRE((mem == LDOT_HOST || mem == LDOT_DEVICE) && (out_mem == LDOT_HOST || out_mem == LDOT_DEVICE),
-                 LDOT_EINVAL, "bad memory space");
+    LDOT_REQUIRE(mem == LDOT_HOST || mem == LDOT_DEVICE, LDOT_EINVAL, "bad memory space");
+    ix->pend_nq = 0;
     if (nq == 0) return LDOT_OK;
-    LDOT_REQUIRE(queries && out_scores && out_labels, LDOT_EINVAL, "NULL buffer");
+    LDOT_REQUIRE(queries != nullptr, LDOT_EINVAL, "NULL buffer");
     hipStream_t st = (hipStream_t)stream;
     for (int i = 0; i < 4; ++i) ix->stats[i] = 0;
     const int kp = candidate_len(ix, k);
@@ -489,10 +494,6 @@ int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dty
     if ((rc = ix->w_ls.ensure((size_t)nq_pad * kp * 4))) return rc;
     if ((rc = ix->w_li.ensure((size_t)nq_pad * kp * 4))) return rc;
     if ((rc = ix->w_tau.ensure((size_t)nq_pad * 4))) return rc;
-    if (out_mem == LDOT_HOST) {
-        if ((rc = ix->w_outs.ensure((size_t)nq * k * 4))) return rc;
-        if ((rc = ix->w_outl.ensure((size_t)nq * k * 8))) return rc;
-    }
 
     // ingest queries -> fp32 (exact re-score operand) + bf16 (MFMA operand); pad rows of the last tile are zero
     const void* src = queries;
@@ -505,8 +506,8 @@ int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dty
     if ((rc = launch_convert_rows(src, dtype, ix->d, nq, nq_pad, ix->d, ix->dpad, normalize, (float*)ix->w_q32.p,
                                   (uint16_t*)ix->w_q16.p, ix->precision ? 2 : 0, (uint16_t*)ix->w_q16b.p, 0, st)))
         return rc;
-    if ((rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, (float*)ix->w_tau.p, nq, nq_pad, st)))
-        return rc;
+    float* tau = (float*)ix->w_tau.p;
+    if ((rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, tau, nq, nq_pad, st))) return rc;
 
     if (ix->ntotal > 0) {
         bool fused = ix->mode == LDOT_MODE_FUSED || (ix->mode == LDOT_MODE_AUTO && ix->ntotal >= 32768);
@@ -514,26 +515,59 @@ int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dty
             bool overflowed = false;
             if ((rc = fused_scan(ix, nq, nq_pad, kp, st, &overflowed))) return rc;
             if (overflowed) {   // adversarial row order: redo everything with the always-correct dense path
-                if ((rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, nullptr, 0, 0, st)))
+                if ((rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, tau, nq, nq_pad, st)))
                     return rc;
                 fused = false;
             }
         }
-        if (!fused && (rc = dense_scan_all(ix, nq, 0, ix->ntotal, kp, nullptr, st))) return rc;
+        if (!fused && (rc = dense_scan_all(ix, nq, 0, ix->ntotal, kp, tau, true, st))) return rc;
+    }
+    if (tau_out) LDOT_HIP_CHECK(hipMemcpyAsync(tau_out, tau, (size_t)nq * 4, hipMemcpyDeviceToDevice, st));
+    if (mem == LDOT_HOST) LDOT_HIP_CHECK(hipStreamSynchronize(st));   // the staging buffer is reused by the next call
+    ix->pend_nq = nq;
+    ix->pend_k = k;
+    ix->pend_kp = kp;
+    return LDOT_OK;
+}
+
+int ldot_index_search_finish(ldot_index_t* ix, const float* floor, float* out_scores, int64_t* out_labels, int out_mem,
+                             void* stream) {
+    LDOT_REQUIRE(ix != nullptr, LDOT_EINVAL, "index is NULL");
+    LDOT_REQUIRE(out_mem == LDOT_HOST || out_mem == LDOT_DEVICE, LDOT_EINVAL, "bad memory space");
+    const int64_t nq = ix->pend_nq;
+    if (nq == 0) return LDOT_OK;
+    LDOT_REQUIRE(out_scores && out_labels, LDOT_EINVAL, "NULL buffer");
+    hipStream_t st = (hipStream_t)stream;
+    const int k = ix->pend_k, kp = ix->pend_kp;
+    ix->pend_nq = 0;
+    int rc;
+    if (out_mem == LDOT_HOST) {
+        if ((rc = ix->w_outs.ensure((size_t)nq * k * 4))) return rc;
+        if ((rc = ix->w_outl.ensure((size_t)nq * k * 8))) return rc;
     }
     // device outputs are written by the re-score kernel directly; host outputs go through the workspace
     float* dst_s = out_mem == LDOT_DEVICE ? out_scores : (float*)ix->w_outs.p;
     int64_t* dst_l = out_mem == LDOT_DEVICE ? out_labels : (int64_t*)ix->w_outl.p;
     if ((rc = launch_rescore((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, nq,
-                             (const float*)ix->w_ls.p, (const int32_t*)ix->w_li.p, kp, k, ix->rescore, dst_s, dst_l, st)))
+                             (const float*)ix->w_ls.p, (const int32_t*)ix->w_li.p, kp, k, ix->rescore, floor, dst_s, dst_l,
+                             st)))
         return rc;
     if (out_mem == LDOT_HOST) {
         LDOT_HIP_CHECK(hipMemcpyAsync(out_scores, dst_s, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
         LDOT_HIP_CHECK(hipMemcpyAsync(out_labels, dst_l, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
+        LDOT_HIP_CHECK(hipStreamSynchronize(st));
     }
-    if (out_mem == LDOT_HOST || mem == LDOT_HOST) LDOT_HIP_CHECK(hipStreamSynchronize(st));
     prof_collect(ix, st);
     return LDOT_OK;
+}
+
+int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k,
+                      float* out_scores, int64_t* out_labels, int out_mem, void* stream) {
+    LDOT_REQUIRE(out_mem == LDOT_HOST || out_mem == LDOT_DEVICE, LDOT_EINVAL, "bad memory space");
+    if (nq > 0) LDOT_REQUIRE(out_scores && out_labels, LDOT_EINVAL, "NULL buffer");
+    int rc = ldot_index_search_begin(ix, queries, nq, dtype, mem, normalize, k, nullptr, stream);
+    if (rc) return rc;
+    return ldot_index_search_finish(ix, nullptr, out_scores, out_labels, out_mem, stream);
 }
 
 int ldot_index_last_profile(const ldot_index_t* ix, double out[4]) {

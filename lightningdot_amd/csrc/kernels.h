@@ -39,8 +39,8 @@ int launch_select_dense_parts(const float* S, int64_t lds_elems, int64_t nq, int
 // list bookkeeping for the segmented path
 int launch_lists_to_parts(const float* list_s, const int32_t* list_i, int64_t n, float* part_s, int64_t* part_l,
                           hipStream_t st);
-int launch_parts_to_lists(const float* out_s, const int64_t* out_l, int64_t n, float* list_s, int32_t* list_i,
-                          hipStream_t st);
+int launch_parts_to_lists(const float* out_s, const int64_t* out_l, int64_t n, float* list_s, int32_t* list_i, int kp,
+                          float* tau, hipStream_t st);
 int launch_select_pools(const uint2* pool, const int32_t* pool_cnt, int nsubs, int64_t nq, float* list_s,
                         int32_t* list_i, int kp, float* tau, int32_t* overflow_flags, hipStream_t st);
 // generic merge of explicit candidate lists: cand_[sl] is [nq][ncand] (labels int64, -1 = empty) -> [nq][k_out]
@@ -49,8 +49,8 @@ int launch_select_lists(const float* cand_s, const int64_t* cand_l, int64_t part
 
 // exact fp32 re-score of the kp candidates of every query, final ordering, top-k output.
 int launch_rescore(const float* q32, int64_t ldq, const float* x32, int64_t ldx, int dpad, int64_t nq,
-                   const float* list_s, const int32_t* list_i, int kp, int k, int do_rescore, float* out_s,
-                   int64_t* out_l, hipStream_t st);
+                   const float* list_s, const int32_t* list_i, int kp, int k, int do_rescore, const float* floor,
+                   float* out_s, int64_t* out_l, hipStream_t st);
 
 int fused_tile_rows();
 int fused_query_group(int64_t nq_pad);   // 8 / 4 / 2 / 1 -> 1024 / qg sub-pools per query, 256 / qg row slices

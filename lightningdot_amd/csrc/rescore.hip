@@ -13,7 +13,8 @@ __global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __rest
                                                              const float* __restrict__ x32, int64_t ldx, int dpad,
                                                              const float* __restrict__ list_s,
                                                              const int32_t* __restrict__ list_i, int kp, int k,
-                                                             int do_rescore, float* __restrict__ out_s,
+                                                             int do_rescore, const float* __restrict__ floor,
+                                                             float* __restrict__ out_s,
                                                              int64_t* __restrict__ out_l) {
     __shared__ __attribute__((aligned(16))) uint64_t keys[4096];   // next power of two >= kMaxKp
     static_assert(kMaxKp <= 4096, "re-score key buffer");
@@ -30,7 +31,12 @@ __global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __rest
     for (int e0 = wave * U; e0 < kp; e0 += (kRsThreads / 64) * U) {
         int32_t r[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) r[u] = (e0 + u < kp) ? list_i[q * kp + e0 + u] : -1;
+        for (int u = 0; u < U; ++u) {
+            r[u] = (e0 + u < kp) ? list_i[q * kp + e0 + u] : -1;
+            // sharded search: candidates below the floor (the best k'-th candidate score of any shard) cannot be among the
+            // global k' best candidates and are not re-scored
+            if (floor && r[u] >= 0 && list_s[q * kp + e0 + u] < floor[q]) r[u] = -1;
+        }
         float s[U];
         if (do_rescore) {
             float acc[U][4];
@@ -83,11 +89,11 @@ __global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __rest
 }
 
 int launch_rescore(const float* q32, int64_t ldq, const float* x32, int64_t ldx, int dpad, int64_t nq,
-                   const float* list_s, const int32_t* list_i, int kp, int k, int do_rescore, float* out_s,
-                   int64_t* out_l, hipStream_t st) {
+                   const float* list_s, const int32_t* list_i, int kp, int k, int do_rescore, const float* floor,
+                   float* out_s, int64_t* out_l, hipStream_t st) {
     if (nq <= 0) return LDOT_OK;
     hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)nq), dim3(kRsThreads), 0, st, q32, ldq, x32, ldx, dpad,
-                       list_s, list_i, kp, k, do_rescore, out_s, out_l);
+                       list_s, list_i, kp, k, do_rescore, floor, out_s, out_l);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

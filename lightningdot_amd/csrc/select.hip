@@ -438,12 +438,15 @@ __global__ __launch_bounds__(256) void lists_to_parts_kernel(const float* __rest
         pl[i] = (int64_t)li[i];
     }
 }
+// (the merged lists are sorted: the threshold of a full list is its last entry)
 __global__ __launch_bounds__(256) void parts_to_lists_kernel(const float* __restrict__ os, const int64_t* __restrict__ ol,
-                                                             int64_t n, float* __restrict__ ls, int32_t* __restrict__ li) {
+                                                             int64_t n, float* __restrict__ ls, int32_t* __restrict__ li,
+                                                             int kp, float* __restrict__ tau) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
         ls[i] = os[i];
         li[i] = (int32_t)ol[i];
+        if (tau && (i % kp) == kp - 1) tau[i / kp] = ol[i] >= 0 ? os[i] : -INFINITY;
     }
 }
 
@@ -658,11 +661,11 @@ int launch_lists_to_parts(const float* list_s, const int32_t* list_i, int64_t n,
     return LDOT_OK;
 }
 
-int launch_parts_to_lists(const float* out_s, const int64_t* out_l, int64_t n, float* list_s, int32_t* list_i,
-                          hipStream_t st) {
+int launch_parts_to_lists(const float* out_s, const int64_t* out_l, int64_t n, float* list_s, int32_t* list_i, int kp,
+                          float* tau, hipStream_t st) {
     if (n <= 0) return LDOT_OK;
     hipLaunchKernelGGL(parts_to_lists_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out_s, out_l, n,
-                       list_s, list_i);
+                       list_s, list_i, kp, tau);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

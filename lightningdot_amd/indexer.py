@@ -123,6 +123,35 @@ class FlatIPIndex:
                                             L.DEVICE, _stream_ptr()))
         return scores, labels
 
+    def search_begin(self, queries, k: int):
+        """First half of a sharded search (CUDA tensors): generates this shard's candidates and returns their thresholds,
+        a float32 CUDA tensor [nq] (the k'-th best candidate score per query, -inf while fewer than k' candidates)."""
+        import torch
+        keep, ptr, nq, dt, mem = _describe(queries, self.d)
+        if mem != L.DEVICE:
+            raise ValueError('search_begin expects a CUDA tensor')
+        tau = torch.empty((nq,), dtype=torch.float32, device=keep.device)
+        L.check(self._lib.ldot_index_search_begin(self._h, ptr, nq, dt, mem, int(self.normalize), int(k),
+                                                  ctypes.c_void_p(tau.data_ptr()), _stream_ptr()))
+        self._pending = (nq, int(k), keep.device)
+        return tau
+
+    def search_finish(self, floor=None):
+        """Second half: re-scores the candidates at or above ``floor`` ([nq] float32 CUDA tensor, e.g. the all-reduce MAX of
+        the shards' thresholds; None = all) and returns this shard's partial top-k (scores, labels) as CUDA tensors."""
+        import torch
+        nq, k, dev = self._pending
+        scores = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        labels = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        fptr = ctypes.c_void_p(0)
+        if floor is not None:
+            floor = floor.to(device=dev, dtype=torch.float32).contiguous()
+            assert floor.shape == (nq,)
+            fptr = ctypes.c_void_p(floor.data_ptr())
+        L.check(self._lib.ldot_index_search_finish(self._h, fptr, ctypes.c_void_p(scores.data_ptr()),
+                                                   ctypes.c_void_p(labels.data_ptr()), L.DEVICE, _stream_ptr()))
+        return scores, labels
+
     def get_rows(self, row0: int, n: int) -> np.ndarray:
         out = np.empty((n, self.d), dtype=np.float32)
         L.check(self._lib.ldot_index_get_rows(self._h, int(row0), int(n), ctypes.c_void_p(out.ctypes.data), L.HOST,

@@ -3,7 +3,8 @@
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Rank r holds index rows
 [offset_r, offset_r + n_r); a search is
     1. all-gather of the query embeddings each rank encoded            (10 000 x 768 fp32 ~ 30 MB in total)
-    2. local fused search of ALL queries against the local shard       (libldot.so)
+    2. local fused candidate pass of ALL queries against the local shard (libldot.so), all-reduce(MAX) of the per-query
+       candidate thresholds (Q x 4 B), exact re-score of the local candidates at or above the global threshold
     3. exchange of the partial top-k lists by query slice               (all-to-all on RCCL; Q x k x 12 B per rank)
     4. merge of the G partial lists of the local query slice           (ldot_merge_topk, HIP)
 so every rank ends with the final global top-k of the queries it contributed.  The scores against disjoint row
@@ -103,7 +104,13 @@ class ShardedFlatIndexer:
         if self._custom:
             s, l = self._local_search(q_all, k)
         else:
-            s, l = self.local.search_knn_tensors(q_all, k)
+            # candidates on this shard, then ONE small all-reduce (MAX) of the per-query candidate thresholds: at least k'
+            # candidates score >= that maximum globally, so every shard re-scores only its candidates at or above it
+            # (~k'/G per shard instead of k'): the re-score gather is the largest per-query cost of a shard
+            tau = self.local.index.search_begin(q_all, k)
+            if self.world > 1:
+                dist.all_reduce(tau, op=dist.ReduceOp.MAX, group=self.group)
+            s, l = self.local.index.search_finish(tau)
         l = torch.where(l >= 0, l + self.offsets[self.rank], l)          # local row -> global row, padding stays -1
         starts = [0]
         for c in counts:

@@ -345,3 +345,41 @@ def test_reset_then_refill_and_growth(L):
     ix.add(more)                       # second growth
     s, l = ix.search(q, k)
     assert_topk_matches(q, np.concatenate([x2, more]), s, l, k)
+
+
+@pytest.mark.gpu
+def test_search_begin_finish_with_floor(L):
+    """The two-halves search of the sharded index: thresholds out, floor in.  With floor = None (or the shard's own
+    threshold) the result equals ldot_index_search; a higher floor drops exactly the candidates below it."""
+    import torch
+    rng = np.random.default_rng(21)
+    n, d, nq, k = 50000, 64, 300, 20
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    ix = _index(x)
+    qt = torch.from_numpy(q).cuda()
+    s_ref, l_ref = ix.search_tensors(qt, k)
+    tau = ix.search_begin(qt, k)
+    assert tau.shape == (nq,) and torch.isfinite(tau).all()
+    s0, l0 = ix.search_finish(None)
+    assert torch.equal(s0, s_ref) and torch.equal(l0, l_ref)
+    ix.search_begin(qt, k)
+    s1, l1 = ix.search_finish(tau)                      # own threshold: nothing is dropped
+    assert torch.equal(s1, s_ref) and torch.equal(l1, l_ref)
+    # a floor between the 5th and 6th exact score keeps (about) the five best: bf16 candidate scores differ from the exact
+    # ones by ~1e-2 here, so compare through the exact scores with that slack
+    floor = ((s_ref[:, 4] + s_ref[:, 5]) * 0.5).contiguous()
+    ix.search_begin(qt, k)
+    s2, l2 = ix.search_finish(floor)
+    kept = (l2 >= 0).sum(1)
+    assert (kept >= 3).all() and (kept <= 8).all(), kept
+    for j in range(nq):
+        m = int(kept[j])
+        assert torch.equal(l2[j, :min(m, 3)], l_ref[j, :min(m, 3)])
+        assert (l2[j, m:] == -1).all()
+    # dense path (small index) maintains the thresholds too
+    ixs = _index(x[:3000])
+    t2 = ixs.search_begin(qt, k)
+    ss, ll = ixs.search_finish(t2)
+    s3, l3 = ixs.search_tensors(qt, k)
+    assert torch.isfinite(t2).all() and torch.equal(ss, s3) and torch.equal(ll, l3)
