@@ -21,23 +21,45 @@ __global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __rest
     const int64_t q = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* qrow = q32 + q * ldq;
+    // 1. compact the live candidates (valid row, and at or above the floor of a sharded search: candidates below the best
+    //    k'-th candidate score of any shard cannot be among the global k' best) to keys[0..m): {candidate score bits, row}.
+    //    The order of the compaction does not matter (the final sort orders by exact score, then row).
+    __shared__ int m_sh;
+    if (threadIdx.x == 0) m_sh = 0;
+    __syncthreads();
+    const float fl = floor ? floor[q] : -INFINITY;
+    for (int e0 = 0; e0 < kp; e0 += kRsThreads) {
+        const int e = e0 + threadIdx.x;
+        int32_t r = -1;
+        float cs = 0.f;
+        if (e < kp) {
+            r = list_i[q * kp + e];
+            cs = list_s[q * kp + e];
+        }
+        const bool live = r >= 0 && !(cs < fl);
+        const unsigned long long mask = __ballot(live);
+        int base = 0;
+        if (lane == 0 && mask) base = atomicAdd(&m_sh, __popcll(mask));
+        base = __shfl(base, 0);
+        if (live) keys[base + __popcll(mask & ((1ull << lane) - 1ull))] = ((uint64_t)__float_as_uint(cs) << 32) | (uint32_t)r;
+    }
+    __syncthreads();
+    const int m = m_sh;
     int P = 2;
-    while (P < kp) P <<= 1;
-    for (int e = kp + threadIdx.x; e < P; e += kRsThreads) keys[e] = ~0ull;
-    // four candidates per wave iteration: their row gathers are independent, so 4x the loads are in flight; the
-    // arithmetic of one candidate (4 fmaf chains over the columns lane*4 + 256*i, pairwise sum, xor-shuffle tree) does
-    // not depend on the grouping
+    while (P < m) P <<= 1;
+    // 2. exact scores.  Four candidates per wave iteration: their row gathers are independent, so 4x the loads are in
+    //    flight; the arithmetic of one candidate (4 fmaf chains over the columns lane*4 + 256*i, pairwise sum, xor-shuffle
+    //    tree) does not depend on the grouping.
     constexpr int U = 4;
-    for (int e0 = wave * U; e0 < kp; e0 += (kRsThreads / 64) * U) {
+    for (int e0 = wave * U; e0 < m; e0 += (kRsThreads / 64) * U) {
         int32_t r[U];
+        float s[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            r[u] = (e0 + u < kp) ? list_i[q * kp + e0 + u] : -1;
-            // sharded search: candidates below the floor (the best k'-th candidate score of any shard) cannot be among the
-            // global k' best candidates and are not re-scored
-            if (floor && r[u] >= 0 && list_s[q * kp + e0 + u] < floor[q]) r[u] = -1;
+            const uint64_t kv = (e0 + u < m) ? keys[e0 + u] : ~0ull;
+            r[u] = (e0 + u < m) ? (int32_t)(uint32_t)kv : -1;
+            s[u] = __uint_as_float((uint32_t)(kv >> 32));
         }
-        float s[U];
         if (do_rescore) {
             float acc[U][4];
 #pragma unroll
@@ -46,7 +68,7 @@ __global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __rest
                 const f32x4 qv = *(const f32x4*)(qrow + c);
                 f32x4 xv[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {   // r[u] is wave-uniform; empty slots (and an empty index) load nothing
+                for (int u = 0; u < U; ++u) {   // r[u] is wave-uniform
                     xv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (r[u] >= 0) xv[u] = *(const f32x4*)(x32 + (int64_t)r[u] * ldx + c);
                 }
@@ -64,20 +86,19 @@ __global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __rest
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) s[u] += __shfl_xor(s[u], o);
             }
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; ++u) s[u] = (r[u] >= 0) ? list_s[q * kp + e0 + u] : 0.f;
         }
         if (lane == 0) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (e0 + u < kp) keys[e0 + u] = (r[u] >= 0) ? (((uint64_t)desc_key(s[u]) << 32) | (uint32_t)r[u]) : ~0ull;
+                if (e0 + u < m) keys[e0 + u] = ((uint64_t)desc_key(s[u]) << 32) | (uint32_t)r[u];
         }
     }
     __syncthreads();
+    for (int e = m + threadIdx.x; e < P; e += kRsThreads) keys[e] = ~0ull;
+    __syncthreads();
     bitonic_sort_lds(keys, P);
     for (int e = threadIdx.x; e < k; e += kRsThreads) {
-        const uint64_t key = (e < P) ? keys[e] : ~0ull;
+        const uint64_t key = (e < m) ? keys[e] : ~0ull;
         if (key != ~0ull) {
             out_s[q * k + e] = desc_key_to_float((uint32_t)(key >> 32));
             out_l[q * k + e] = (int64_t)(uint32_t)(key & 0xffffffffu);
