@@ -510,7 +510,10 @@ int ldot_index_search_begin(ldot_index_t* ix, const void* queries, int64_t nq, i
     if ((rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, tau, nq, nq_pad, st))) return rc;
 
     if (ix->ntotal > 0) {
-        bool fused = ix->mode == LDOT_MODE_FUSED || (ix->mode == LDOT_MODE_AUTO && ix->ntotal >= 32768);
+        // AUTO: the fused scan pays off from ~32k rows (tools/auto_threshold.py); very large batches (COCO-5k sized image->text
+        // with the reference's un-deduplicated queries) already from 16k rows, where the dense score matrix is the cost
+        bool fused = ix->mode == LDOT_MODE_FUSED ||
+                     (ix->mode == LDOT_MODE_AUTO && (ix->ntotal >= 32768 || (ix->ntotal >= 16384 && nq >= 16384)));
         if (fused) {
             bool overflowed = false;
             if ((rc = fused_scan(ix, nq, nq_pad, kp, st, &overflowed))) return rc;

@@ -282,6 +282,7 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     if (variant == 16) rk = score_filter_r6_kernel<16>;
     if (variant == 18) rk = score_filter_r6_kernel<18>;
     if (variant == 20) rk = score_filter_r6_kernel<20>;
+    if (variant == 17) rk = score_filter_r6_kernel<17>;   // no epilogue at all (upper bound of hiding it)
     if (variant == 48) rk = score_filter_r6_kernel<48>;
     if (variant == 80) rk = score_filter_r6_kernel<80>;
     LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<6>::kLds));
