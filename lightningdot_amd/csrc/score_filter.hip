@@ -60,6 +60,15 @@ __device__ __forceinline__ float max4_raw(float a0, float a1, float a2, float a3
     return m;
 }
 
+__device__ __forceinline__ float max8_raw(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+    float m;
+    asm volatile(
+        "v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max_f32 %0, %0, %8"
+        : "=&v"(m)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));
+    return m;
+}
+
 template <int MR, bool NOSTORE>
 __device__ __forceinline__ void filter_epilogue_r(const f32x16 (&acc)[MR][2], const float (&tau)[2], int (&cur)[2],
                                                   const uint32_t (&pbase)[2], uint32_t nsubs, uint2* __restrict__ pool,
@@ -73,16 +82,26 @@ __device__ __forceinline__ void filter_epilogue_r(const f32x16 (&acc)[MR][2], co
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float a0 = acc[mr][nr][4 * g + 0], a1 = acc[mr][nr][4 * g + 1];
-                const float a2 = acc[mr][nr][4 * g + 2], a3 = acc[mr][nr][4 * g + 3];
-                const float m = max4_raw(a0, a1, a2, a3);
-                if (m >= tau[nr]) {
-                    const int32_t rb = row_lane0 + mr * 32 + 8 * g;
-                    filter_append<NOSTORE>(a0, tau[nr], rb + 0, row_end, cur[nr], pbase[nr], nsubs, pool);
-                    filter_append<NOSTORE>(a1, tau[nr], rb + 1, row_end, cur[nr], pbase[nr], nsubs, pool);
-                    filter_append<NOSTORE>(a2, tau[nr], rb + 2, row_end, cur[nr], pbase[nr], nsubs, pool);
-                    filter_append<NOSTORE>(a3, tau[nr], rb + 3, row_end, cur[nr], pbase[nr], nsubs, pool);
+            for (int h = 0; h < 2; ++h) {   // eight scores per test: 4 VALU + compare + branch on the fast path
+                const float a0 = acc[mr][nr][8 * h + 0], a1 = acc[mr][nr][8 * h + 1];
+                const float a2 = acc[mr][nr][8 * h + 2], a3 = acc[mr][nr][8 * h + 3];
+                const float a4 = acc[mr][nr][8 * h + 4], a5 = acc[mr][nr][8 * h + 5];
+                const float a6 = acc[mr][nr][8 * h + 6], a7 = acc[mr][nr][8 * h + 7];
+                const float m = max8_raw(a0, a1, a2, a3, a4, a5, a6, a7);
+                if (m >= tau[nr]) {   // rare: find the half (usually one) that holds the hit
+                    const int32_t rb = row_lane0 + mr * 32 + 16 * h;   // registers 8h..8h+3: rows +0..3, 8h+4..8h+7: rows +8..11
+                    if (max4_raw(a0, a1, a2, a3) >= tau[nr]) {
+                        filter_append<NOSTORE>(a0, tau[nr], rb + 0, row_end, cur[nr], pbase[nr], nsubs, pool);
+                        filter_append<NOSTORE>(a1, tau[nr], rb + 1, row_end, cur[nr], pbase[nr], nsubs, pool);
+                        filter_append<NOSTORE>(a2, tau[nr], rb + 2, row_end, cur[nr], pbase[nr], nsubs, pool);
+                        filter_append<NOSTORE>(a3, tau[nr], rb + 3, row_end, cur[nr], pbase[nr], nsubs, pool);
+                    }
+                    if (max4_raw(a4, a5, a6, a7) >= tau[nr]) {
+                        filter_append<NOSTORE>(a4, tau[nr], rb + 8, row_end, cur[nr], pbase[nr], nsubs, pool);
+                        filter_append<NOSTORE>(a5, tau[nr], rb + 9, row_end, cur[nr], pbase[nr], nsubs, pool);
+                        filter_append<NOSTORE>(a6, tau[nr], rb + 10, row_end, cur[nr], pbase[nr], nsubs, pool);
+                        filter_append<NOSTORE>(a7, tau[nr], rb + 11, row_end, cur[nr], pbase[nr], nsubs, pool);
+                    }
                 }
             }
         }
