@@ -92,6 +92,21 @@ __device__ __forceinline__ void ringr_read_b(const RingCtx& c, const char* stage
     for (int nr = 0; nr < 2; ++nr) b[nr] = *(const bf16x8_t*)(b_w + nr * 2048);
 }
 
+// first k-step of an output tile: C = 0 is an inline constant of the MFMA, so the accumulators need no clearing pass
+template <int MR>
+__device__ __forceinline__ void ringr_step_first(const RingCtx& c, FragsR<MR>& f, const int cur, const char* nstage,
+                                                 const int nks, f32x16 (&acc)[MR][2]) {
+    ringr_read_b<MR>(c, nstage, nks, f.b[cur ^ 1]);
+    const char* a_w = nstage + c.wm * (32 * MR * 64) + c.frag_off[nks];
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+        acc[mr][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mr], f.b[cur][0], z, 0, 0, 0);
+        acc[mr][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mr], f.b[cur][1], z, 0, 0, 0);
+        f.a[mr] = *(const bf16x8_t*)(a_w + mr * 2048);
+    }
+}
+
 // one k-step: MFMAs on (a[*], bcur) while a[*] is reloaded from (nstage, nks) and bnext is fetched
 template <int MR, bool SKIP_B = false>
 __device__ __forceinline__ void ringr_step(const RingCtx& c, FragsR<MR>& f, const int cur, const char* nstage,

@@ -32,6 +32,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gemm_ring.h"
 #include "kernels.h"
 
@@ -203,9 +205,16 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
         f.b[1][1] = f.b[0][1];
     }
     int64_t s = 0;
-    auto slab = [&]() {
+    // FIRST: the first slab of an output tile (its first MFMAs take C = 0 instead of a cleared accumulator)
+    auto slab = [&](auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         // k-step 0 of slab s (operands: a, b[0]); a <- k-step 1 of slab s, b[1] <- k-step 1 of slab s
-        if (!(VAR & 4)) ringr_step<MR, (VAR & 32) != 0>(c, f, 0, smem + (int)(s & 3) * Geo::kStage, 1, acc);
+        if (!(VAR & 4)) {
+            if (FIRST)
+                ringr_step_first<MR>(c, f, 0, smem + (int)(s & 3) * Geo::kStage, 1, acc);
+            else
+                ringr_step<MR, (VAR & 32) != 0>(c, f, 0, smem + (int)(s & 3) * Geo::kStage, 1, acc);
+        }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of slab s are complete (WAR on its stage)
         if (VAR & 2)
@@ -242,14 +251,17 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
                 cur[nr] = 0;
             }
         }
+        if (VAR & 4) {
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr)
+            for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-            for (int nr = 0; nr < 2; ++nr)
+                for (int nr = 0; nr < 2; ++nr)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.f;
+        }
+        slab(std::true_type{});
 #pragma unroll 1
-        for (int kk = 0; kk < nk; ++kk) slab();
+        for (int kk = 1; kk < nk; ++kk) slab(std::false_type{});
         const int64_t trow = row0 + (int64_t)c_t * Geo::kBM;
         const int32_t row_lane0 = (int32_t)trow + c.wm * (32 * MR) + 4 * (c.lane >> 5);
         if (!(VAR & 1)) {
