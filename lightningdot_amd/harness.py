@@ -16,7 +16,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
-from .indexer import DenseFlatIndexer
+from .indexer import DenseFlatIndexer, DenseHNSWFlatIndexer
 from .loss import BiEncoderNllLoss, _calc_loss
 
 
@@ -29,9 +29,7 @@ def _dedup_last(ids):
 
 
 def get_indexer(bi_encoder, eval_dataloader, args, hnsw_index, img_retrieval=True):
-    """dvl/trainer.py:93-110 (flat index only; ``hnsw_index`` is the reference's approximate alternative, §8f-4)."""
-    if hnsw_index:
-        raise NotImplementedError('HNSW index is out of scope (SURVEY §8f rank 4); use the exact flat index')
+    """dvl/trainer.py:93-110 (``hnsw_index`` selects the reference's DenseHNSWFlatIndexer surface, exact-backed here)."""
     bi_encoder.eval()
     ids, vecs = [], []
     for batch in eval_dataloader:
@@ -45,15 +43,13 @@ def get_indexer(bi_encoder, eval_dataloader, args, hnsw_index, img_retrieval=Tru
             vecs.append(local_q_vector.detach())
     allv = torch.cat(vecs, 0)
     keys, last = _dedup_last(ids)
-    indexer = DenseFlatIndexer(args.vector_size)
+    indexer = (DenseHNSWFlatIndexer if hnsw_index else DenseFlatIndexer)(args.vector_size)
     indexer.index_tensor(keys, allv[torch.as_tensor(last, device=allv.device)])
     return indexer
 
 
 def eval_model_on_dataloader(bi_encoder, eval_dataloader, args, img2txt: Optional[Dict] = None, num_tops=100,
                              no_eval=False):
-    if getattr(args, 'hnsw_index', False):
-        raise NotImplementedError('HNSW index is out of scope (SURVEY §8f rank 4); use the exact flat index')
     total_loss = 0.0
     bi_encoder.eval()
     total_correct_predictions = 0
@@ -85,8 +81,9 @@ def eval_model_on_dataloader(bi_encoder, eval_dataloader, args, img2txt: Optiona
 
     query_txt_t = torch.cat(query_txt, 0)
     query_img_t = torch.cat(query_img, 0)
-    indexer_img = DenseFlatIndexer(args.vector_size)
-    indexer_txt = DenseFlatIndexer(args.vector_size)
+    indexer_cls = DenseHNSWFlatIndexer if getattr(args, 'hnsw_index', False) else DenseFlatIndexer   # trainer.py:122-127
+    indexer_img = indexer_cls(args.vector_size)
+    indexer_txt = indexer_cls(args.vector_size)
     img_keys, img_last = _dedup_last(query_img_id)
     txt_keys, txt_last = _dedup_last(query_txt_id)
     dev = query_txt_t.device

@@ -260,3 +260,87 @@ class DenseFlatIndexer(DenseIndexer):
     def search_knn_tensors(self, query_vectors, top_docs: int):
         """(scores [nq, k], row labels [nq, k]) as device tensors; map labels with ``index_id_to_db_id``."""
         return self.index.search_tensors(query_vectors, top_docs)
+
+
+class DenseHNSWFlatIndexer(DenseIndexer):
+    """faiss_indexers.py:90-154 — the reference's ``--hnsw_index`` alternative: faiss IndexHNSWFlat over vectors augmented
+    with one extra dimension sqrt(phi - |x|^2) (phi = max |x|^2), queries augmented with 0, so that L2 order = inner
+    product order; ``search_knn`` returns the SQUARED L2 distances of the augmented vectors, ascending.
+
+    Here the graph is not needed: the exact scan of a 1M x 768 index takes < 1 ms per query batch on an MI355X, so the
+    class keeps the reference's surface (constructor arguments, all-data-at-once rule, phi bookkeeping, score semantics,
+    id mapping) on top of the exact flat index.  Neighbours are the exact ones (recall 1.0 instead of HNSW's ~0.99);
+    distances are |q|^2 + phi - 2 q.x from the exact fp32 inner products."""
+
+    def __init__(self, vector_sz: int, buffer_size: int = 50000, store_n: int = 512, ef_search: int = 128,
+                 ef_construction: int = 200):
+        super(DenseHNSWFlatIndexer, self).__init__(buffer_size=buffer_size)
+        self.index = FlatIPIndex(vector_sz)
+        self.store_n, self.ef_search, self.ef_construction = store_n, ef_search, ef_construction   # kept, unused
+        self.phi = 0               # the reference's re-index guard (:106,112-113,154)
+        self._phi_value = 0.0      # max squared row norm of the indexed data
+
+    def _check_first(self):
+        if self.phi > 0:
+            raise RuntimeError('DPR HNSWF index needs to index all data at once,'
+                               'results will be unpredictable otherwise.')
+
+    def index_data(self, data: List[Tuple[object, np.array]]):
+        self._check_first()
+        n = len(data)
+        phi = 0
+        for _, doc_vector in data:                     # :114-118 (float32 arithmetic like the reference)
+            v = doc_vector.detach().cpu().numpy() if _is_tensor(doc_vector) else np.asarray(doc_vector)
+            phi = max(phi, (v ** 2).sum())
+        logger.info('HNSWF DotProduct -> L2 space phi={}'.format(phi))
+        self.phi = 0                                   # (:119: the reference resets its guard here)
+        self._phi_value = max(float(phi), self._phi_value)
+        for i in range(0, n, self.buffer_size):
+            chunk = data[i:i + self.buffer_size]
+            if chunk and _is_tensor(chunk[0][1]):
+                import torch
+                vectors = torch.stack([t[1].reshape(-1) for t in chunk], dim=0)
+            else:
+                vectors = np.concatenate([np.reshape(t[1], (1, -1)) for t in chunk], axis=0)
+            self._update_id_mapping([t[0] for t in chunk])
+            self.index.add(vectors)
+            logger.info('data indexed %d', len(self.index_id_to_db_id))
+        logger.info('Total data indexed %d', len(self.index_id_to_db_id))
+
+    def index_tensor(self, db_ids: List, vectors):
+        """Device path: ids + one [n, d] tensor."""
+        self._check_first()
+        if len(db_ids) != vectors.shape[0]:
+            raise ValueError('ids / vectors length mismatch')
+        if vectors.shape[0]:
+            self._phi_value = max(self._phi_value, float((vectors.float() ** 2).sum(dim=1).max().item()))
+        self._update_id_mapping(list(db_ids))
+        self.index.add(vectors)
+
+    def _to_l2(self, q_sqnorm, ip, labels):
+        dist = q_sqnorm[:, None] + np.float32(self._phi_value) - 2.0 * ip
+        return np.where(labels >= 0, dist, np.float32(3.4028234663852886e38)).astype(np.float32)   # faiss pads with FLT_MAX
+
+    def search_knn(self, query_vectors: np.array, top_docs: int) -> List[Tuple[List[object], List[float]]]:
+        if _is_tensor(query_vectors):
+            ip, indexes = self.index.search_tensors(query_vectors, top_docs)
+            qn = (query_vectors.float() ** 2).sum(dim=1).cpu().numpy()
+            ip, indexes = ip.cpu().numpy(), indexes.cpu().numpy()
+        else:
+            q = np.asarray(query_vectors, dtype=np.float32)
+            ip, indexes = self.index.search(q, top_docs)
+            qn = (q ** 2).sum(axis=1)
+        scores = self._to_l2(qn.astype(np.float32), ip, indexes)
+        ids = self.index_id_to_db_id
+        db_ids = [[ids[i] for i in query_top_idxs] for query_top_idxs in indexes.tolist()]
+        return [(db_ids[i], scores[i]) for i in range(len(db_ids))]
+
+    def deserialize_from(self, file: str):
+        super(DenseHNSWFlatIndexer, self).deserialize_from(file)
+        # to trigger the error on subsequent indexing (:152-154)
+        self.phi = 1
+        phi = 0.0
+        for r0 in range(0, self.index.ntotal, 65536):
+            rows = self.index.get_rows(r0, min(65536, self.index.ntotal - r0))
+            phi = max(phi, float((rows ** 2).sum(axis=1).max()))
+        self._phi_value = phi

@@ -410,3 +410,40 @@ def hard_negative_postprocess(hard_neg_img: Dict, hard_neg_txt: Dict, train_txt2
     sampled_txt = {k: rng.sample(sorted(v), num_hard_negatives) for k, v in hn_txt.items()}
     sampled_img = {k: rng.sample(v, num_hard_negatives) for k, v in hn_img.items()}
     return hn_img, hn_txt, sampled_txt, sampled_img
+
+
+class DenseHNSWFlatIndexerOracle:
+    """CPU restatement of dvl/indexer/faiss_indexers.py:90-154 with EXACT search standing in for faiss.IndexHNSWFlat
+    (third-party, approximate; parity unpinned like IndexFlatIP): rows augmented with sqrt(phi - |x|^2), queries with 0,
+    squared L2 distances ascending (= inner products descending), ids through the id list."""
+
+    def __init__(self, vector_sz: int, buffer_size: int = 50000):
+        self.buffer_size = buffer_size
+        self.index_id_to_db_id = []
+        self.rows = np.zeros((0, vector_sz + 1), dtype=np.float32)
+        self.phi = 0
+
+    def index_data(self, data):
+        if self.phi > 0:
+            raise RuntimeError('DPR HNSWF index needs to index all data at once,'
+                               'results will be unpredictable otherwise.')
+        phi = 0
+        for _, v in data:                                            # :114-118
+            phi = max(phi, (np.asarray(v) ** 2).sum())
+        self.phi = 0                                                 # :119
+        for i in range(0, len(data), self.buffer_size):              # :122-134
+            chunk = data[i:i + self.buffer_size]
+            vectors = [np.reshape(np.asarray(t[1], dtype=np.float32), (1, -1)) for t in chunk]
+            norms = [(v ** 2).sum() for v in vectors]
+            aux = [np.sqrt(phi - n) for n in norms]
+            aug = np.concatenate([np.hstack((v, np.reshape(a, (-1, 1)))) for v, a in zip(vectors, aux)], axis=0)
+            self.index_id_to_db_id.extend([t[0] for t in chunk])
+            self.rows = np.concatenate([self.rows, aug.astype(np.float32)], axis=0)
+
+    def search_knn(self, query_vectors, top_docs):
+        q = np.asarray(query_vectors, dtype=np.float32)
+        qa = np.hstack((q, np.zeros((len(q), 1), dtype=np.float32)))                       # :141-142
+        d2 = ((qa[:, None, :].astype(np.float64) - self.rows[None, :, :].astype(np.float64)) ** 2).sum(-1)
+        order = np.argsort(d2, axis=1, kind='stable')[:, :top_docs]
+        scores = np.take_along_axis(d2, order, axis=1).astype(np.float32)
+        return [([self.index_id_to_db_id[i] for i in row], scores[j]) for j, row in enumerate(order.tolist())]

@@ -383,3 +383,35 @@ def test_search_begin_finish_with_floor(L):
     ss, ll = ixs.search_finish(t2)
     s3, l3 = ixs.search_tensors(qt, k)
     assert torch.isfinite(t2).all() and torch.equal(ss, s3) and torch.equal(ll, l3)
+
+
+@pytest.mark.gpu
+def test_hnsw_indexer_surface_is_exact_backed(L, tmp_path):
+    """DenseHNSWFlatIndexer (the reference's --hnsw_index alternative, faiss_indexers.py:90-154): same surface and score
+    semantics (squared L2 of the phi-augmented vectors, ascending), exact neighbours."""
+    from lightningdot_amd.indexer import DenseHNSWFlatIndexer
+    rng = np.random.default_rng(12)
+    n, d, nq, k = 700, 48, 40, 15
+    x = (rng.standard_normal((n, d)) * rng.uniform(0.5, 2.0, (n, 1))).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    data = [('id%d' % i, x[i]) for i in range(n)]
+    ix = DenseHNSWFlatIndexer(d, buffer_size=256)
+    ix.index_data(data)
+    oc = O.DenseHNSWFlatIndexerOracle(d, buffer_size=256)
+    oc.index_data(data)
+    got, exp = ix.search_knn(q, k), oc.search_knn(q, k)
+    for (gi, gs), (ei, es) in zip(got, exp):
+        assert gi == ei
+        np.testing.assert_allclose(gs, es, rtol=1e-4, atol=1e-3)
+        assert (np.diff(gs) >= -1e-4).all()                      # ascending distances
+    # serialisation keeps the id list and phi; indexing again afterwards is refused like the reference (:152-154,112-113)
+    f = str(tmp_path / 'hn')
+    ix.serialize(f)
+    ix2 = DenseHNSWFlatIndexer(d)
+    ix2.deserialize_from(f)
+    got2 = ix2.search_knn(q, k)
+    for (gi, gs), (hi, hs) in zip(got, got2):
+        assert gi == hi
+        np.testing.assert_allclose(gs, hs, rtol=1e-6, atol=1e-5)
+    with pytest.raises(RuntimeError):
+        ix2.index_data(data[:3])
