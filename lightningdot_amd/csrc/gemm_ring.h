@@ -26,8 +26,7 @@ typedef __attribute__((address_space(3))) void* rg_lptr_t;
 
 struct RingCtx {
     int lane, wave, wm, wn;
-    int frag_off[2];   // per-lane byte offset of k-step ks inside a 32-row block (64-byte rows)
-    int st_row[2];     // source row (within a 256-row slab) of staging instruction j
+    int frag_off0;     // per-lane byte offset of k-step 0 inside a 32-row block (64-byte rows); k-step 1 = ^ 32
     int st_col;        // source byte offset inside the 64-byte slab row
 };
 
@@ -57,12 +56,9 @@ __device__ __forceinline__ void ring_ctx_init(RingCtx& c) {
     c.wn = c.wave & 3;
     const int r = c.lane & 31;
     const int x = (r >> 2) & 3;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) c.frag_off[ks] = r * 64 + ((((ks << 1) | (c.lane >> 5)) ^ x) << 4);
+    c.frag_off0 = r * 64 + (((c.lane >> 5) ^ x) << 4);   // chunk index ((ks << 1) | half) ^ x: ks toggles bit 1 = 32 bytes
     // staging instruction j of wave w fills LDS bytes [(j*8+w)*1024, +1024) = slab rows (j*8+w)*16 .. +16;
     // lane i lands on row (i >> 2), physical chunk (i & 3) and therefore fetches logical chunk (i&3) ^ swz(row)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) c.st_row[j] = (j * 8 + c.wave) * 16 + (c.lane >> 2);
     c.st_col = (((c.lane & 3) ^ ((c.lane >> 4) & 3)) << 4);
 }
 
@@ -87,24 +83,9 @@ struct FragsR {
 
 template <int MR>
 __device__ __forceinline__ void ringr_read_b(const RingCtx& c, const char* stage, int ks, bf16x8_t (&b)[2]) {
-    const char* b_w = stage + RingGeom<MR>::kAOpBytes + c.wn * (64 * 64) + c.frag_off[ks];
+    const char* b_w = stage + RingGeom<MR>::kAOpBytes + c.wn * (64 * 64) + (c.frag_off0 ^ (ks << 5));
 #pragma unroll
     for (int nr = 0; nr < 2; ++nr) b[nr] = *(const bf16x8_t*)(b_w + nr * 2048);
-}
-
-// first k-step of an output tile: C = 0 is an inline constant of the MFMA, so the accumulators need no clearing pass
-template <int MR>
-__device__ __forceinline__ void ringr_step_first(const RingCtx& c, FragsR<MR>& f, const int cur, const char* nstage,
-                                                 const int nks, f32x16 (&acc)[MR][2]) {
-    ringr_read_b<MR>(c, nstage, nks, f.b[cur ^ 1]);
-    const char* a_w = nstage + c.wm * (32 * MR * 64) + c.frag_off[nks];
-    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int mr = 0; mr < MR; ++mr) {
-        acc[mr][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mr], f.b[cur][0], z, 0, 0, 0);
-        acc[mr][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mr], f.b[cur][1], z, 0, 0, 0);
-        f.a[mr] = *(const bf16x8_t*)(a_w + mr * 2048);
-    }
 }
 
 // one k-step: MFMAs on (a[*], bcur) while a[*] is reloaded from (nstage, nks) and bnext is fetched
@@ -112,7 +93,7 @@ template <int MR, bool SKIP_B = false>
 __device__ __forceinline__ void ringr_step(const RingCtx& c, FragsR<MR>& f, const int cur, const char* nstage,
                                            const int nks, f32x16 (&acc)[MR][2]) {
     if (!SKIP_B) ringr_read_b<MR>(c, nstage, nks, f.b[cur ^ 1]);   // (SKIP_B: profiling ablation only)
-    const char* a_w = nstage + c.wm * (32 * MR * 64) + c.frag_off[nks];
+    const char* a_w = nstage + c.wm * (32 * MR * 64) + (c.frag_off0 ^ (nks << 5));
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
         acc[mr][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mr], f.b[cur][0], acc[mr][0], 0, 0, 0);

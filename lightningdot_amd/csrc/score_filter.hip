@@ -71,43 +71,58 @@ __device__ __forceinline__ float max8_raw(float a0, float a1, float a2, float a3
     return m;
 }
 
-template <int MR, bool NOSTORE>
-__device__ __forceinline__ void filter_epilogue_r(const f32x16 (&acc)[MR][2], const float (&tau)[2], int (&cur)[2],
-                                                  const uint32_t (&pbase)[2], uint32_t nsubs, uint2* __restrict__ pool,
-                                                  int32_t row_lane0, int32_t row_end) {
-    // MFMA -> VALU read hazard cover for the inline-asm reads below (32x32x16 bf16: 8 passes, <= 18 wait states)
+// MFMA -> VALU read hazard cover for the inline-asm accumulator reads of the epilogue (32x32x16 bf16: 8 passes, <= 18 wait
+// states since the last MFMA issue; hipcc does not pad hazards for inline asm)
+__device__ __forceinline__ void filter_hazard_cover() {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+}
+
+// threshold filter of one 32-row block (mr) of the wave tile: both query columns of the lane, eight scores per test
+// (three v_max3 + v_max + compare + branch on the fast path), a hit localised by halves
+template <bool NOSTORE>
+__device__ __forceinline__ void filter_epilogue_mr(const f32x16& acc0, const f32x16& acc1, int mr, const float (&tau)[2],
+                                                   int (&cur)[2], uint32_t pbase0, uint32_t pstep, uint32_t nsubs,
+                                                   uint2* __restrict__ pool, int32_t row_wave0, int32_t row_end) {
 #pragma unroll
     for (int nr = 0; nr < 2; ++nr) {
+        const f32x16& a = nr ? acc1 : acc0;
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {   // eight scores per test: 4 VALU + compare + branch on the fast path
-                const float a0 = acc[mr][nr][8 * h + 0], a1 = acc[mr][nr][8 * h + 1];
-                const float a2 = acc[mr][nr][8 * h + 2], a3 = acc[mr][nr][8 * h + 3];
-                const float a4 = acc[mr][nr][8 * h + 4], a5 = acc[mr][nr][8 * h + 5];
-                const float a6 = acc[mr][nr][8 * h + 6], a7 = acc[mr][nr][8 * h + 7];
-                const float m = max8_raw(a0, a1, a2, a3, a4, a5, a6, a7);
-                if (m >= tau[nr]) {   // rare: find the half (usually one) that holds the hit
-                    const int32_t rb = row_lane0 + mr * 32 + 16 * h;   // registers 8h..8h+3: rows +0..3, 8h+4..8h+7: rows +8..11
-                    if (max4_raw(a0, a1, a2, a3) >= tau[nr]) {
-                        filter_append<NOSTORE>(a0, tau[nr], rb + 0, row_end, cur[nr], pbase[nr], nsubs, pool);
-                        filter_append<NOSTORE>(a1, tau[nr], rb + 1, row_end, cur[nr], pbase[nr], nsubs, pool);
-                        filter_append<NOSTORE>(a2, tau[nr], rb + 2, row_end, cur[nr], pbase[nr], nsubs, pool);
-                        filter_append<NOSTORE>(a3, tau[nr], rb + 3, row_end, cur[nr], pbase[nr], nsubs, pool);
-                    }
-                    if (max4_raw(a4, a5, a6, a7) >= tau[nr]) {
-                        filter_append<NOSTORE>(a4, tau[nr], rb + 8, row_end, cur[nr], pbase[nr], nsubs, pool);
-                        filter_append<NOSTORE>(a5, tau[nr], rb + 9, row_end, cur[nr], pbase[nr], nsubs, pool);
-                        filter_append<NOSTORE>(a6, tau[nr], rb + 10, row_end, cur[nr], pbase[nr], nsubs, pool);
-                        filter_append<NOSTORE>(a7, tau[nr], rb + 11, row_end, cur[nr], pbase[nr], nsubs, pool);
-                    }
+        for (int h = 0; h < 2; ++h) {
+            const float a0 = a[8 * h + 0], a1 = a[8 * h + 1], a2 = a[8 * h + 2], a3 = a[8 * h + 3];
+            const float a4 = a[8 * h + 4], a5 = a[8 * h + 5], a6 = a[8 * h + 6], a7 = a[8 * h + 7];
+            const float m = max8_raw(a0, a1, a2, a3, a4, a5, a6, a7);
+            if (m >= tau[nr]) {   // rare: find the half (usually one) that holds the hit
+                // (rare path: the lane's row offset and the sub-pool base are derived here instead of living in registers)
+                // registers 8h..8h+3: rows +0..3, 8h+4..8h+7: rows +8..11
+                const int32_t rb = row_wave0 + 4 * (int32_t)((threadIdx.x & 63) >> 5) + mr * 32 + 16 * h;
+                const uint32_t pb = pbase0 + (uint32_t)nr * pstep;
+                if (max4_raw(a0, a1, a2, a3) >= tau[nr]) {
+                    filter_append<NOSTORE>(a0, tau[nr], rb + 0, row_end, cur[nr], pb, nsubs, pool);
+                    filter_append<NOSTORE>(a1, tau[nr], rb + 1, row_end, cur[nr], pb, nsubs, pool);
+                    filter_append<NOSTORE>(a2, tau[nr], rb + 2, row_end, cur[nr], pb, nsubs, pool);
+                    filter_append<NOSTORE>(a3, tau[nr], rb + 3, row_end, cur[nr], pb, nsubs, pool);
+                }
+                if (max4_raw(a4, a5, a6, a7) >= tau[nr]) {
+                    filter_append<NOSTORE>(a4, tau[nr], rb + 8, row_end, cur[nr], pb, nsubs, pool);
+                    filter_append<NOSTORE>(a5, tau[nr], rb + 9, row_end, cur[nr], pb, nsubs, pool);
+                    filter_append<NOSTORE>(a6, tau[nr], rb + 10, row_end, cur[nr], pb, nsubs, pool);
+                    filter_append<NOSTORE>(a7, tau[nr], rb + 11, row_end, cur[nr], pb, nsubs, pool);
                 }
             }
         }
     }
+}
+
+template <int MR, bool NOSTORE>
+__device__ __forceinline__ void filter_epilogue_r(const f32x16 (&acc)[MR][2], const float (&tau)[2], int (&cur)[2],
+                                                  uint32_t pbase0, uint32_t pstep, uint32_t nsubs, uint2* __restrict__ pool,
+                                                  int32_t row_wave0, int32_t row_end) {
+    filter_hazard_cover();
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+        filter_epilogue_mr<NOSTORE>(acc[mr][0], acc[mr][1], mr, tau, cur, pbase0, pstep, nsubs, pool, row_wave0, row_end);
 }
 
 template <int N>
@@ -145,11 +160,10 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     const int g0 = slice / ntiles, t0 = slice % ntiles;                          // first unit of this stream
 
     // ---- load cursor (see the second-generation kernel) ---------------------------------------------------------
-    int va[Geo::kALoads], vb[2];
-#pragma unroll
-    for (int j = 0; j < Geo::kALoads; ++j) va[j] = (j * 8 + c.wave) * 16 * (int)ldx_b + (c.lane >> 2) * 64 + c.st_col;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) vb[j] = (j * 8 + c.wave) * 16 * (int)ldq_b + (c.lane >> 2) * 64 + c.st_col;
+    // one per-lane offset serves every staging instruction of both operands (their row strides are equal): the row-group
+    // step of instruction j (j * 8 groups of 16 rows) and the slab (KiB block) ride in the scalar offset
+    const int vo = c.wave * 16 * (int)ldx_b + (c.lane >> 2) * 64 + c.st_col;
+    const int jstep = 8 * 16 * (int)ldx_b;
     int l_q = g0, l_t = t0, l_k = 0;
     RingSrc sa, sb;
     sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)l_t * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
@@ -161,12 +175,12 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
         if (!(VAR & 2) || issued < 4)
 #pragma unroll
         for (int j = 0; j < Geo::kALoads; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(sa.rsrc, (rg_lptr_t)(st + (j * 8 + c.wave) * 1024), 16, va[j], k0b, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(sa.rsrc, (rg_lptr_t)(st + (j * 8 + c.wave) * 1024), 16, vo, k0b + j * jstep, 0, 0);
         if (!(VAR & 2) || issued < 4)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(sb.rsrc, (rg_lptr_t)(st + Geo::kAOpBytes + (j * 8 + c.wave) * 1024),
-                                                     16, vb[j], k0b, 0, 0);
+                                                     16, vo, k0b + j * jstep, 0, 0);
         ++issued;
         if (issued < S) {
             if (++l_k == nk) {   // next unit of this stream
@@ -193,11 +207,12 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     // ---- compute side --------------------------------------------------------------------------------------
     float tau[2];
     int cur[2] = {0, 0};
-    uint32_t pbase[2];
+    uint32_t pbase0 = 0;                                             // sub-pool base of the lane's first query column
+    const uint32_t pstep = 32u * kPoolCap * (uint32_t)nsubs;         // ... the second one is 32 queries further
     f32x16 acc[MR][2];
     FragsR<MR> f;
     {
-        const char* a_w = smem + c.wm * (32 * MR * 64) + c.frag_off[0];
+        const char* a_w = smem + c.wm * (32 * MR * 64) + c.frag_off0;
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) f.a[mr] = *(const bf16x8_t*)(a_w + mr * 2048);
         ringr_read_b<MR>(c, smem, 0, f.b[0]);
@@ -205,15 +220,37 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
         f.b[1][1] = f.b[0][1];
     }
     int64_t s = 0;
-    // FIRST: the first slab of an output tile (its first MFMAs take C = 0 instead of a cleared accumulator)
-    auto slab = [&](auto first_tag) {
-        constexpr bool FIRST = decltype(first_tag)::value;
+    // MODE 0: a slab inside a tile.  MODE 1: the first slab of the first tile (its first MFMAs take C = 0 instead of a
+    // cleared accumulator).  MODE 2: the first slab of a later tile, FUSED with the threshold filter of the tile just
+    // finished: block by block (mr), the filter reads the finished scores and the C = 0 MFMAs of the new tile overwrite
+    // them, so the matrix pipe works on block mr while the VALU filters block mr + 1 (the filter alone leaves the matrix
+    // pipe idle: all waves run it at the same time).
+    int32_t epi_row_wave0 = 0;   // (uniform) first row of the wave's block of the tile whose filter is pending
+    auto slab = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        char* st0 = smem + (int)(s & 3) * Geo::kStage;
         // k-step 0 of slab s (operands: a, b[0]); a <- k-step 1 of slab s, b[1] <- k-step 1 of slab s
         if (!(VAR & 4)) {
-            if (FIRST)
-                ringr_step_first<MR>(c, f, 0, smem + (int)(s & 3) * Geo::kStage, 1, acc);
-            else
-                ringr_step<MR, (VAR & 32) != 0>(c, f, 0, smem + (int)(s & 3) * Geo::kStage, 1, acc);
+            if (MODE == 0) {
+                ringr_step<MR, (VAR & 32) != 0>(c, f, 0, st0, 1, acc);
+            } else {
+                ringr_read_b<MR>(c, st0, 1, f.b[1]);
+                const char* a_w = st0 + c.wm * (32 * MR * 64) + (c.frag_off0 ^ 32);
+                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (MODE == 2 && !(VAR & 1)) filter_hazard_cover();
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr) {
+                    if (MODE == 2 && !(VAR & 1)) {
+                        filter_epilogue_mr<(VAR & 8) != 0>(acc[mr][0], acc[mr][1], mr, tau, cur, pbase0, pstep, (uint32_t)nsubs,
+                                                           pool, epi_row_wave0, row_end);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    acc[mr][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mr], f.b[0][0], z, 0, 0, 0);
+                    acc[mr][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mr], f.b[0][1], z, 0, 0, 0);
+                    f.a[mr] = *(const bf16x8_t*)(a_w + mr * 2048);
+                    if (MODE == 2 && !(VAR & 1)) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of slab s are complete (WAR on its stage)
@@ -228,6 +265,9 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
         __builtin_amdgcn_sched_barrier(0);
         issue();                                             // slab s+3 (or a dummy) -> the stage slab s-1 vacated
     };
+    using M0 = std::integral_constant<int, 0>;
+    using M1 = std::integral_constant<int, 1>;
+    using M2 = std::integral_constant<int, 2>;
 
     // the counters' query index is recomputed at store time (two VGPR pairs less live across the tile loop)
     auto store_counts = [&](int g) {
@@ -237,45 +277,52 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
             pool_cnt[qi * nsubs + sub] = cur[nr];
         }
     };
-    int c_q = g0, c_t = t0, cur_q = -1;
+    auto setup_group = [&](int g) {
+#pragma unroll
+        for (int nr = 0; nr < 2; ++nr) {
+            const int64_t qi = (int64_t)(qsub + g * qg) * kRBN + c.wn * 64 + nr * 32 + (c.lane & 31);
+            tau[nr] = (VAR & 16) ? INFINITY : ring_launder(tau_g[qi]);
+            if (nr == 0) pbase0 = (uint32_t)(qi * kPoolCap * nsubs + sub);
+            cur[nr] = 0;
+        }
+    };
+    int c_q = g0, c_t = t0, cur_q = g0;
+    setup_group(c_q);
+    if (VAR & 4) {
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int nr = 0; nr < 2; ++nr)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.f;
+    }
+    slab(M1{});
 #pragma unroll 1
     for (int j = 0; j < ntile_total; ++j) {
-        if (c_q != cur_q) {   // (uniform) the stream moves on to the next query group
-            if (cur_q >= 0) store_counts(cur_q);
-            cur_q = c_q;
-#pragma unroll
-            for (int nr = 0; nr < 2; ++nr) {
-                const int64_t qi = (int64_t)(qsub + c_q * qg) * kRBN + c.wn * 64 + nr * 32 + (c.lane & 31);
-                tau[nr] = (VAR & 16) ? INFINITY : ring_launder(tau_g[qi]);
-                pbase[nr] = (uint32_t)(qi * kPoolCap * nsubs + sub);
-                cur[nr] = 0;
-            }
-        }
-        if (VAR & 4) {
-#pragma unroll
-            for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-                for (int nr = 0; nr < 2; ++nr)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.f;
-        }
-        slab(std::true_type{});
 #pragma unroll 1
-        for (int kk = 1; kk < nk; ++kk) slab(std::false_type{});
+        for (int kk = 1; kk < nk; ++kk) slab(M0{});
+        // tile j is complete in acc
         const int64_t trow = row0 + (int64_t)c_t * Geo::kBM;
-        const int32_t row_lane0 = (int32_t)trow + c.wm * (32 * MR) + 4 * (c.lane >> 5);
-        if (!(VAR & 1)) {
-            filter_epilogue_r<MR, (VAR & 8) != 0>(acc, tau, cur, pbase, (uint32_t)nsubs, pool, row_lane0, row_end);
+        epi_row_wave0 = (int32_t)trow + c.wm * (32 * MR);
+        c_t += nslices;
+        while (c_t >= ntiles) {
+            c_t -= ntiles;
+            ++c_q;
+        }
+        if (j + 1 < ntile_total) {
+            slab(M2{});                 // filter of tile j fused with the first slab of tile j + 1
+            if (c_q != cur_q) {         // (uniform) the stream moves on to the next query group
+                store_counts(cur_q);
+                cur_q = c_q;
+                setup_group(c_q);
+            }
+        } else if (!(VAR & 1)) {
+            filter_epilogue_r<MR, (VAR & 8) != 0>(acc, tau, cur, pbase0, pstep, (uint32_t)nsubs, pool, epi_row_wave0, row_end);
         } else {
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
                 for (int nr = 0; nr < 2; ++nr) asm volatile("" ::"v"(acc[mr][nr]));
-        }
-        c_t += nslices;
-        while (c_t >= ntiles) {
-            c_t -= ntiles;
-            ++c_q;
         }
     }
     store_counts(cur_q);
@@ -302,6 +349,7 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
                         int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, uint2* pool, int32_t* pool_cnt,
                         hipStream_t st) {
     if (nrows <= 0 || nq_pad <= 0) return LDOT_OK;
+    LDOT_REQUIRE(ldx_elems == ldq_elems, LDOT_EINVAL, "index and query shadows must have the same row stride");
     // LDOT_DEBUG_VARIANT selects an ablation build of the kernel (profiling only; results are then meaningless):
     //   16 tau = +inf (epilogue fast path only), 18 = 16 + no global loads after the prologue, 20 = 16 + no MFMA/ds_read
     static int variant = -1;
