@@ -60,6 +60,9 @@ def main():
     ap.add_argument('--split-bf16', action='store_true',
                     help='LDOT_OPT_PRECISION=1: split-bf16 candidate pass (3 MFMA products per element); not the headline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to exercise the N > 1 '
+                                                      'bookkeeping on a one-GPU box together with --all-on-device0)')
+    ap.add_argument('--all-on-device0', action='store_true', help='debug: every rank uses cuda:0')
     ap.add_argument('--cpu-sample-queries', type=int, default=2048)
     ap.add_argument('--normalised', action='store_true',
                     help='second series (SURVEY 8d): rows and queries scaled to unit L2 norm (cosine scores)')
@@ -69,6 +72,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if args.all_on_device0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     sharded = world > 1 or args.force_sharded
@@ -76,7 +81,10 @@ def main():
         import torch.distributed as dist
         if 'MASTER_ADDR' not in os.environ:
             os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from lightningdot_amd import _lib as L
     from lightningdot_amd.indexer import DenseFlatIndexer
