@@ -62,6 +62,7 @@ extern "C" {
 #define LDOT_OPT_PROFILE 5      /* 1: bracket every score-kernel launch with HIP events (see ldot_index_last_profile) */
 #define LDOT_OPT_WARM_ROWS 6    /* rows scored densely before the fused filter starts (default 4096, multiple of 256) */
 #define LDOT_OPT_GROWTH_PCT 7   /* fused launch i covers growth% of the rows already scanned (default 150) */
+#define LDOT_OPT_RESERVE_ROWS 9  /* allocate capacity for this many rows now (no growth copies while filling a large index) */
 #define LDOT_OPT_PRECISION 8    /* candidate generation: 0 (default) bf16 operands; 1 split-bf16 operands (x ~ hi + lo, three
                                  * MFMA products per element: ~16 mantissa bits, 3x the MFMA work and 3x the shadow) for
                                  * data whose scores crowd closer than bf16 resolves; reported scores are fp32-exact in both */

@@ -238,6 +238,12 @@ int ldot_index_set_option(ldot_index_t* ix, int option, int64_t value) {
             ix->x16b = n16b;
             return LDOT_OK;
         }
+        case LDOT_OPT_RESERVE_ROWS: {
+            // allocate capacity up front: a large index then never pays the x1.5 growth copies (which transiently need old +
+            // new buffers in HBM)
+            LDOT_REQUIRE(value >= 0 && value < 0x7ffffff0ll, LDOT_EINVAL, "bad reserve size");
+            return index_reserve(ix, std::max<int64_t>(value, ix->ntotal), nullptr);
+        }
         case LDOT_OPT_GROWTH_PCT:
             LDOT_REQUIRE(value >= 5 && value <= 10000, LDOT_EINVAL, "growth_pct must be in [5, 10000]");
             ix->growth_pct = (int)value;

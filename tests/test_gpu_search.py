@@ -341,8 +341,9 @@ def test_reset_then_refill_and_growth(L):
     s, l = ix.search(q, k)
     assert ix.last_stats()['fused_pairs'] > 0
     assert_topk_matches(q, x2, s, l, k)
+    ix.set_option(L.OPT_RESERVE_ROWS, 200000)   # explicit reservation: the next add does not reallocate
     more = rng.standard_normal((60000, d)).astype(np.float32)
-    ix.add(more)                       # second growth
+    ix.add(more)
     s, l = ix.search(q, k)
     assert_topk_matches(q, np.concatenate([x2, more]), s, l, k)
 

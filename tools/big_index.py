@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lightningdot_amd.indexer import FlatIPIndex
 N, D, Q, K, CH = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000, 768, 4096, 100, 500_000
 ix = FlatIPIndex(D)
+ix.set_option(9, N)   # LDOT_OPT_RESERVE_ROWS
 g = torch.Generator(device='cuda'); gt = (torch.arange(Q, device='cuda') * 999331) % N
 qs = torch.zeros(Q, D, device='cuda')
 t0 = time.perf_counter()
