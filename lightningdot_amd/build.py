@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(PKG, 'libldot.so')
 SOURCES = ['api.hip', 'convert.hip', 'score_dense.hip', 'score_filter.hip', 'select.hip', 'rescore.hip', 'loss.hip']
-HEADERS = ['ldot_common.h', 'gemm_tile.h', 'gemm_ring.h', 'bitonic.h', 'kernels.h', os.path.join('..', '..', 'include', 'ldot.h')]
+HEADERS = ['ldot_common.h', 'gemm_ring.h', 'bitonic.h', 'kernels.h', os.path.join('..', '..', 'include', 'ldot.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
 

@@ -8,7 +8,6 @@
 #include <new>
 #include <vector>
 
-#include "gemm_tile.h"
 #include "kernels.h"
 
 namespace ldot {
@@ -50,8 +49,8 @@ struct ldot_index {
     int d = 0, dpad = 0;
     int64_t ntotal = 0, cap_rows = 0;
     float* x32 = nullptr;      // [cap_rows][dpad] fp32 master copy (zero padded)
-    uint16_t* x16 = nullptr;   // [cap_rows][ld16()] bf16 shadow: dpad, or 3*dpad split-bf16 [hi|hi|lo] (precision 1)
-    uint16_t* x16b = nullptr;  // the same shadow in the blocked layout streamed by the fused kernel (16 rows x 32 k blocks)
+    uint16_t* x16b = nullptr;  // bf16 shadow (dpad per row, or 3*dpad split-bf16 [hi|hi|lo] with precision 1) in the blocked
+                               // layout both MFMA kernels stream: 1 KiB blocks of 16 rows x 32 k
     int precision = 0;
     int64_t ld16() const { return precision ? 3 * (int64_t)dpad : dpad; }
     // options
@@ -70,7 +69,7 @@ struct ldot_index {
     double prof[4] = {0, 0, 0, 0};
     // workspaces
     DevBuf w_q16b;
-    DevBuf w_stage, w_q32, w_q16, w_ls, w_li, w_S, w_outs, w_outl, w_tau, w_pool, w_pool_cnt, w_over;
+    DevBuf w_stage, w_q32, w_ls, w_li, w_S, w_outs, w_outl, w_tau, w_pool, w_pool_cnt, w_over;
     DevBuf w_part_s, w_part_l, w_mrg_s, w_mrg_l;
     int64_t stats[4] = {0, 0, 0, 0};
     // the sub-pool counters and overflow flags are all-zero between searches (the pool select resets the counters it
@@ -89,34 +88,28 @@ static int index_reserve(ldot_index* ix, int64_t rows, hipStream_t st) {
     int64_t cap = std::max<int64_t>(need, ix->cap_rows + ix->cap_rows / 2);
     cap = round_up(cap, 256);
     float* n32 = nullptr;
-    uint16_t *n16 = nullptr, *n16b = nullptr;
+    uint16_t* n16b = nullptr;
     const size_t b32 = (size_t)cap * ix->dpad * sizeof(float), b16 = (size_t)cap * ix->ld16() * sizeof(uint16_t);
     LDOT_HIP_CHECK(hipMalloc((void**)&n32, b32));
-    hipError_t e = hipMalloc((void**)&n16, b16);
-    if (e == hipSuccess) e = hipMalloc((void**)&n16b, b16);
+    hipError_t e = hipMalloc((void**)&n16b, b16);
     if (e != hipSuccess) {
         (void)hipFree(n32);
-        if (n16) (void)hipFree(n16);
         set_error("hipMalloc(%zu) failed: %s", b16, hipGetErrorString(e));
         return LDOT_ENOMEM;
     }
-    const size_t u32 = (size_t)ix->ntotal * ix->dpad * sizeof(float), u16 = (size_t)ix->ntotal * ix->ld16() * 2;
+    const size_t u32 = (size_t)ix->ntotal * ix->dpad * sizeof(float);
     if (ix->ntotal > 0) {
         LDOT_HIP_CHECK(hipMemcpyAsync(n32, ix->x32, u32, hipMemcpyDeviceToDevice, st));
-        LDOT_HIP_CHECK(hipMemcpyAsync(n16, ix->x16, u16, hipMemcpyDeviceToDevice, st));
     }
     // blocked shadow: whole 16-row blocks (the last one may be partly filled; its unused rows are zero)
     const size_t u16b = (size_t)round_up(ix->ntotal, 16) * ix->ld16() * 2;
     if (ix->ntotal > 0) LDOT_HIP_CHECK(hipMemcpyAsync(n16b, ix->x16b, u16b, hipMemcpyDeviceToDevice, st));
     LDOT_HIP_CHECK(hipMemsetAsync((char*)n16b + u16b, 0, b16 - u16b, st));
     LDOT_HIP_CHECK(hipMemsetAsync((char*)n32 + u32, 0, b32 - u32, st));
-    LDOT_HIP_CHECK(hipMemsetAsync((char*)n16 + u16, 0, b16 - u16, st));
     LDOT_HIP_CHECK(hipStreamSynchronize(st));
     if (ix->x32) (void)hipFree(ix->x32);
-    if (ix->x16) (void)hipFree(ix->x16);
     if (ix->x16b) (void)hipFree(ix->x16b);
     ix->x32 = n32;
-    ix->x16 = n16;
     ix->x16b = n16b;
     ix->cap_rows = cap;
     return LDOT_OK;
@@ -156,9 +149,8 @@ int ldot_index_create(int d, ldot_index_t** out) {
 int ldot_index_destroy(ldot_index_t* ix) {
     if (!ix) return LDOT_OK;
     if (ix->x32) (void)hipFree(ix->x32);
-    if (ix->x16) (void)hipFree(ix->x16);
     if (ix->x16b) (void)hipFree(ix->x16b);
-    DevBuf* bufs[] = {&ix->w_q16b, &ix->w_stage, &ix->w_q32, &ix->w_q16, &ix->w_ls, &ix->w_li, &ix->w_S, &ix->w_outs,
+    DevBuf* bufs[] = {&ix->w_q16b, &ix->w_stage, &ix->w_q32, &ix->w_ls, &ix->w_li, &ix->w_S, &ix->w_outs,
                       &ix->w_outl, &ix->w_tau, &ix->w_pool, &ix->w_pool_cnt, &ix->w_over,
                       &ix->w_part_s, &ix->w_part_l, &ix->w_mrg_s, &ix->w_mrg_l};
     for (DevBuf* b : bufs) b->release();
@@ -173,7 +165,6 @@ int ldot_index_reset(ldot_index_t* ix) {
     LDOT_REQUIRE(ix != nullptr, LDOT_EINVAL, "index is NULL");
     if (ix->cap_rows > 0) {
         LDOT_HIP_CHECK(hipMemset(ix->x32, 0, (size_t)ix->cap_rows * ix->dpad * 4));
-        LDOT_HIP_CHECK(hipMemset(ix->x16, 0, (size_t)ix->cap_rows * ix->ld16() * 2));
         LDOT_HIP_CHECK(hipMemset(ix->x16b, 0, (size_t)ix->cap_rows * ix->ld16() * 2));
     }
     ix->ntotal = 0;
@@ -212,29 +203,23 @@ int ldot_index_set_option(ldot_index_t* ix, int option, int64_t value) {
             ix->precision = (int)value;
             if (ix->cap_rows == 0) return LDOT_OK;
             // rebuild the shadow from the fp32 master copy in the new layout
-            uint16_t *n16 = nullptr, *n16b = nullptr;
+            uint16_t* n16b = nullptr;
             const size_t b16 = (size_t)ix->cap_rows * ix->ld16() * sizeof(uint16_t);
-            hipError_t e = hipMalloc((void**)&n16, b16);
-            if (e == hipSuccess) e = hipMalloc((void**)&n16b, b16);
+            hipError_t e = hipMalloc((void**)&n16b, b16);
             if (e != hipSuccess) {
-                if (n16) (void)hipFree(n16);
                 ix->precision = 1 - ix->precision;
                 set_error("hipMalloc(%zu) failed: %s", b16, hipGetErrorString(e));
                 return LDOT_ENOMEM;
             }
-            LDOT_HIP_CHECK(hipMemsetAsync(n16, 0, b16, nullptr));
             LDOT_HIP_CHECK(hipMemsetAsync(n16b, 0, b16, nullptr));
             int rc = launch_convert_rows(ix->x32, LDOT_F32, ix->dpad, ix->ntotal, ix->ntotal, ix->d, ix->dpad, 0, nullptr,
-                                         n16, ix->precision ? 1 : 0, n16b, 0, nullptr);
+                                         nullptr, ix->precision ? 1 : 0, n16b, 0, nullptr);
             LDOT_HIP_CHECK(hipStreamSynchronize(nullptr));
             if (rc) {
-                (void)hipFree(n16);
                 (void)hipFree(n16b);
                 return rc;
             }
-            (void)hipFree(ix->x16);
             (void)hipFree(ix->x16b);
-            ix->x16 = n16;
             ix->x16b = n16b;
             return LDOT_OK;
         }
@@ -274,7 +259,7 @@ int ldot_index_add(ldot_index_t* ix, const void* rows, int64_t n, int dtype, int
         src = ix->w_stage.p;
     }
     rc = launch_convert_rows(src, dtype, ix->d, n, n, ix->d, ix->dpad, normalize, ix->x32 + ix->ntotal * ix->dpad,
-                             ix->x16 + ix->ntotal * ix->ld16(), ix->precision ? 1 : 0, ix->x16b, ix->ntotal, st);
+                             nullptr, ix->precision ? 1 : 0, ix->x16b, ix->ntotal, st);
     if (rc) return rc;
     if (mem == LDOT_HOST) LDOT_HIP_CHECK(hipStreamSynchronize(st));   // staging buffer is reused by the next call
     ix->ntotal += n;
@@ -340,7 +325,7 @@ static void prof_collect(ldot_index* ix, hipStream_t st) {
 // dense scan of rows [r0, r1) for query block [q0, q0+nqb): materialise score chunks + streaming select
 static int dense_scan(ldot_index* ix, int64_t q0, int64_t nqb, int64_t nqb_pad, int64_t r0, int64_t r1, int kp,
                       float* tau, hipStream_t st) {
-    const uint16_t* q16 = (const uint16_t*)ix->w_q16.p + q0 * ix->ld16();
+    const uint16_t* q16 = (const uint16_t*)ix->w_q16b.p + q0 * ix->ld16();   // (q0 is a multiple of 256: whole 16-row blocks)
     float* ls = (float*)ix->w_ls.p + q0 * kp;
     int32_t* li = (int32_t*)ix->w_li.p + q0 * kp;
     const int64_t chunk = ix->chunk_rows;
@@ -352,7 +337,7 @@ static int dense_scan(ldot_index* ix, int64_t q0, int64_t nqb, int64_t nqb_pad, 
         // algorithmic work: the VALID queries x rows x d (tile padding is overhead, not work)
         prof_begin(ix, st, 2.0 * nqb * nrows * ix->d,
                    (double)nrows * ix->d * 2 + (double)nqb * ix->d * 2 + (double)nqb * nrows * 4);
-        rc = launch_score_dense(q16, ix->ld16(), nqb_pad, ix->x16, ix->ld16(), r, nrows_pad, (int)ix->ld16(), (float*)ix->w_S.p,
+        rc = launch_score_dense(q16, ix->ld16(), nqb_pad, ix->x16b, ix->ld16(), r, nrows_pad, (int)ix->ld16(), (float*)ix->w_S.p,
                                 chunk, nqb, st);
         prof_end(ix, st);
         if (rc) return rc;
@@ -382,7 +367,7 @@ static int dense_scan_wide(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, i
         if ((rc = ix->w_mrg_l.ensure((size_t)nq * kp * 8))) return rc;
         prof_begin(ix, st, 2.0 * nq * nrows * ix->d,
                    (double)nrows * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * nrows * 4);
-        rc = launch_score_dense(ix->w_q16.p, ix->ld16(), kBM, ix->x16, ix->ld16(), r, nrows_pad, (int)ix->ld16(),
+        rc = launch_score_dense(ix->w_q16b.p, ix->ld16(), kBM, ix->x16b, ix->ld16(), r, nrows_pad, (int)ix->ld16(),
                                 (float*)ix->w_S.p, nrows_pad, nq, st);
         prof_end(ix, st);
         if (rc) return rc;
@@ -495,7 +480,6 @@ int ldot_index_search_begin(ldot_index_t* ix, const void* queries, int64_t nq, i
     const int64_t nq_pad = round_up(nq, kBM);
     int rc;
     if ((rc = ix->w_q32.ensure((size_t)nq_pad * ix->dpad * 4))) return rc;
-    if ((rc = ix->w_q16.ensure((size_t)nq_pad * ix->ld16() * 2))) return rc;
     if ((rc = ix->w_q16b.ensure((size_t)nq_pad * ix->ld16() * 2))) return rc;
     if ((rc = ix->w_ls.ensure((size_t)nq_pad * kp * 4))) return rc;
     if ((rc = ix->w_li.ensure((size_t)nq_pad * kp * 4))) return rc;
@@ -510,7 +494,7 @@ int ldot_index_search_begin(ldot_index_t* ix, const void* queries, int64_t nq, i
         src = ix->w_stage.p;
     }
     if ((rc = launch_convert_rows(src, dtype, ix->d, nq, nq_pad, ix->d, ix->dpad, normalize, (float*)ix->w_q32.p,
-                                  (uint16_t*)ix->w_q16.p, ix->precision ? 2 : 0, (uint16_t*)ix->w_q16b.p, 0, st)))
+                                  nullptr, ix->precision ? 2 : 0, (uint16_t*)ix->w_q16b.p, 0, st)))
         return rc;
     float* tau = (float*)ix->w_tau.p;
     if ((rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, tau, nq, nq_pad, st))) return rc;

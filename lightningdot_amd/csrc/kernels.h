@@ -4,6 +4,9 @@
 
 namespace ldot {
 
+constexpr int kBM = 256;           // queries are padded to a multiple of this (the fused kernel's query tile)
+constexpr int kBN = 256;           // dense chunks cover a multiple of this many index rows
+constexpr int kBK = 64;            // the feature dimension is padded to a multiple of this
 constexpr int kMaxK = 2048;        // largest k of a search
 constexpr int kMaxKp = 3072;       // largest candidate-list length k' = k + margin: k' + 1024 keys fit a 32 KiB LDS buffer
 constexpr int kSelThreads = 256;
@@ -23,6 +26,7 @@ int launch_convert_rows(const void* src, int dtype, int64_t ld_src, int64_t n, i
                         int normalize, float* dst32, uint16_t* dst16, int split, uint16_t* dst16b, int64_t row0b,
                         hipStream_t st);
 
+// q16 / x16 are the BLOCKED shadows (launch_convert_rows dst16b), nq_pad a multiple of 256, xrow0 a multiple of 16
 int launch_score_dense(const void* q16, int64_t ldq_elems, int64_t nq_pad, const void* x16, int64_t ldx_elems,
                        int64_t xrow0, int64_t nrows_pad, int dpad, float* S, int64_t lds_elems, int64_t nq_valid,
                        hipStream_t st);
