@@ -7,8 +7,9 @@
 
 namespace ldot {
 
-constexpr int kRsThreads = 256;
 
+// THREADS = 256 for batches (many queries in flight per CU), 1024 for a handful of queries (16 waves gather the rows of one query)
+template <int kRsThreads>
 __global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __restrict__ q32, int64_t ldq,
                                                              const float* __restrict__ x32, int64_t ldx, int dpad,
                                                              const float* __restrict__ list_s,
@@ -113,8 +114,12 @@ int launch_rescore(const float* q32, int64_t ldq, const float* x32, int64_t ldx,
                    const float* list_s, const int32_t* list_i, int kp, int k, int do_rescore, const float* floor,
                    float* out_s, int64_t* out_l, hipStream_t st) {
     if (nq <= 0) return LDOT_OK;
-    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)nq), dim3(kRsThreads), 0, st, q32, ldq, x32, ldx, dpad,
-                       list_s, list_i, kp, k, do_rescore, floor, out_s, out_l);
+    if (nq <= 128)
+        hipLaunchKernelGGL(rescore_kernel<1024>, dim3((unsigned)nq), dim3(1024), 0, st, q32, ldq, x32, ldx, dpad, list_s,
+                           list_i, kp, k, do_rescore, floor, out_s, out_l);
+    else
+        hipLaunchKernelGGL(rescore_kernel<256>, dim3((unsigned)nq), dim3(256), 0, st, q32, ldq, x32, ldx, dpad, list_s,
+                           list_i, kp, k, do_rescore, floor, out_s, out_l);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }
