@@ -538,36 +538,43 @@ __global__ __launch_bounds__(kSelThreads) void select_pools_block_kernel(const u
     sel.init(keys, &count, kp, cap);
     float* ls = list_s + q * kp;
     int32_t* li = list_i + q * kp;
-    sel.load_list(ls, li);
     const uint2* base = pool + q * (int64_t)kPoolCap * nsubs;
+    int32_t* cnt = pool_cnt + q * (int64_t)nsubs;
     bool over = false;
-    for (int s0 = 0; s0 < nsubs; s0 += 2 * kSelThreads) {
-        int c[2];
+    // a lone workgroup pays every dependent global round trip in full: the counters of SPT x 256 sub-pools are fetched in one
+    // batch (together with the running list), then four entry levels of all of them in another
+    constexpr int SPT = 4, LV = 4;
+    for (int s0 = 0; s0 < nsubs; s0 += SPT * kSelThreads) {
+        int c[SPT];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < SPT; ++g) {
             const int sidx = s0 + g * kSelThreads + threadIdx.x;
-            int v = 0;
-            if (sidx < nsubs) {
-                v = pool_cnt[q * (int64_t)nsubs + sidx];
-                pool_cnt[q * (int64_t)nsubs + sidx] = 0;
-            }
-            over |= v > kPoolCap;
-            c[g] = v < kPoolCap ? v : kPoolCap;
+            c[g] = sidx < nsubs ? cnt[sidx] : 0;
         }
-        const int cm = max(c[0], c[1]);
-        for (int e0 = 0; __syncthreads_or(cm > e0); e0 += 2) {
-            sel.reserve(4 * kSelThreads);
-            uint2 v[2][2];
+        if (s0 == 0) sel.load_list(ls, li);
+        int cm = 0;
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
+        for (int g = 0; g < SPT; ++g) {
+            const int sidx = s0 + g * kSelThreads + threadIdx.x;
+            if (sidx < nsubs) cnt[sidx] = 0;
+            over |= c[g] > kPoolCap;
+            c[g] = c[g] < kPoolCap ? c[g] : kPoolCap;
+            cm = max(cm, c[g]);
+        }
+        for (int e0 = 0; __syncthreads_or(cm > e0); e0 += LV) {
+            uint2 v[SPT][LV];
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+            for (int g = 0; g < SPT; ++g)
+#pragma unroll
+                for (int u = 0; u < LV; ++u)
                     v[g][u] = (e0 + u < c[g]) ? base[(int64_t)(e0 + u) * nsubs + s0 + g * kSelThreads + threadIdx.x]
                                               : make_uint2(0u, 0u);
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
+            for (int u = 0; u < LV; ++u) {
+                sel.reserve(SPT * kSelThreads);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) sel.push(make_key(__uint_as_float(v[g][u].x), v[g][u].y), e0 + u < c[g]);
+                for (int g = 0; g < SPT; ++g) sel.push(make_key(__uint_as_float(v[g][u].x), v[g][u].y), e0 + u < c[g]);
+            }
         }
     }
     sel.finish(ls, li, tau ? tau + q : nullptr);
