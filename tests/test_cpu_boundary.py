@@ -109,3 +109,17 @@ def test_config_surface_matches_reference_golden(golden_dir, tmp_path):
         assert got['max_txt_len'] == 32 and g['cmds_only']['max_txt_len'] == 60
     finally:
         sys.argv = saved
+
+
+def test_rerank_recall_host_logic():
+    """rerank.py:256-290 restated: an oracle scorer (1 for the positive, 0 otherwise) lifts Recall@1 to the first-stage
+    Recall@threshold; a constant scorer keeps the first-stage order (topk is stable enough for distinct positions)."""
+    from lightningdot_amd.rerank import rerank_recall
+    rankings = {q: ['i%d' % ((q * 7 + j) % 200) for j in range(100)] for q in range(50)}
+    pos = {q: rankings[q][(q * 3) % 60] for q in range(50)}               # positive at first-stage rank (3q mod 60)
+    res = rerank_recall(rankings, lambda q, c: 1.0 if c == pos[q] else 0.0, lambda q, ids: pos[q] in ids)
+    for th in (10, 20, 50, 100):
+        expect = sum(((q * 3) % 60) < th for q in range(50)) / 50.0
+        assert res[th][1] == expect and res[th][10] == expect
+    res2 = rerank_recall(rankings, lambda q, c: None, lambda q, ids: pos[q] in ids)   # scorer knows nothing -> missing score
+    assert 0.0 <= res2[10][10] <= 1.0
