@@ -416,3 +416,33 @@ def test_hnsw_indexer_surface_is_exact_backed(L, tmp_path):
         np.testing.assert_allclose(gs, hs, rtol=1e-6, atol=1e-5)
     with pytest.raises(RuntimeError):
         ix2.index_data(data[:3])
+
+
+@pytest.mark.gpu
+def test_two_handles_from_two_threads(L):
+    """Handles are independent (no global mutable state beyond the thread-local error string): two threads search their own
+    indexes on their own streams concurrently and get the same results as alone."""
+    import threading
+    import torch
+    rng = np.random.default_rng(4)
+    xs = [rng.standard_normal((40000, 64)).astype(np.float32) for _ in range(2)]
+    qs = [rng.standard_normal((700, 64)).astype(np.float32) for _ in range(2)]
+    ixs = [_index(x) for x in xs]
+    ref = [ix.search(q, 20) for ix, q in zip(ixs, qs)]
+    out, errs = [None, None], []
+
+    def work(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(8):
+                    out[i] = ixs[i].search(qs[i], 20)
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for i in range(2):
+        np.testing.assert_array_equal(out[i][1], ref[i][1])
+        np.testing.assert_array_equal(out[i][0], ref[i][0])
