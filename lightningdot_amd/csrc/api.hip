@@ -74,7 +74,7 @@ struct ldot_index {
     int64_t stats[4] = {0, 0, 0, 0};
     // the sub-pool counters and overflow flags are all-zero between searches (the pool select resets the counters it
     // reads); they are cleared only after a (re)allocation or an aborted / overflowed search
-    bool pools_clean = false;
+    bool pools_clean = false, flags_clean = false;
     // a search in two halves (ldot_index_search_begin / _finish): what _finish needs to know
     int64_t pend_nq = 0;
     int pend_k = 0, pend_kp = 0;
@@ -389,13 +389,14 @@ static int dense_scan_wide(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, i
 
 // (tau is always maintained: the fused scan continues from it, a sharded search exchanges it)
 static int dense_scan_all(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, int kp, float* tau, bool allow_wide,
-                          hipStream_t st) {
-    if (allow_wide && nq <= kBM && r1 - r0 > 2 * ix->chunk_rows) return dense_scan_wide(ix, nq, r0, r1, kp, tau, st);
+                          hipStream_t st, int64_t q_base = 0) {
+    if (allow_wide && q_base == 0 && nq <= kBM && r1 - r0 > 2 * ix->chunk_rows)
+        return dense_scan_wide(ix, nq, r0, r1, kp, tau, st);
     // query blocks bound the dense score workspace (<= ~2 GiB at the default chunk)
     const int64_t qb_max = std::max<int64_t>(kBM, ((int64_t)1 << 29) / ix->chunk_rows / kBM * kBM);
     for (int64_t q0 = 0; q0 < nq; q0 += qb_max) {
         const int64_t nqb = std::min(qb_max, nq - q0);
-        int rc = dense_scan(ix, q0, nqb, round_up(nqb, kBM), r0, r1, kp, tau, st);
+        int rc = dense_scan(ix, q_base + q0, nqb, round_up(nqb, kBM), r0, r1, kp, tau, st);
         if (rc) return rc;
     }
     return LDOT_OK;
@@ -403,12 +404,18 @@ static int dense_scan_all(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, in
 
 // fused scan: dense warm-up of the first rows (gives every query a full list and a threshold), then
 // geometrically growing fused-filter launches, each followed by the pool select that raises the thresholds.
-static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStream_t st, bool* overflowed) {
-    *overflowed = false;
-    float* tau = (float*)ix->w_tau.p;
+// Queries are processed in chunks of kFusedQueryChunk (bounds the candidate pools: 196 KiB per query at 128 sub-pools).
+constexpr int64_t kFusedQueryChunk = 16384;
+
+static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_pad, int kp, hipStream_t st) {
+    float* tau = (float*)ix->w_tau.p + q0;
+    float* ls = (float*)ix->w_ls.p + q0 * kp;
+    int32_t* li = (int32_t*)ix->w_li.p + q0 * kp;
+    const uint16_t* q16 = (const uint16_t*)ix->w_q16b.p + q0 * ix->ld16();   // (q0 is a multiple of 256: whole 16-row blocks)
+    int32_t* over = (int32_t*)ix->w_over.p + q0;
     int rc;
     // Pool sizing rule: a launch over `len` rows after `r` scanned rows admits ~kp*len/r candidates per query,
-    // spread over lane-private sub-pools of kPoolCap entries.  Keeping the expectation <= 1024 per query
+    // spread over lane-private sub-pools of kPoolCap records.  Keeping the expectation <= 1024 per query
     // (8 per sub-pool, overflow probability ~1e-11 each) bounds len <= r*1024/kp; the smallest launch is one tile
     // per row slice, hence the warm-up covers at least 8*kp rows.
     const int64_t bm = fused_tile_rows();
@@ -416,17 +423,13 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
     const int64_t nslices = 256 / qg, nsubs = 4 * nslices;
     const int64_t warm =
         std::min(ix->ntotal, std::max<int64_t>(ix->warm_rows, round_up(bm * nslices * (int64_t)kp / 1024, 256)));
-    if ((rc = dense_scan_all(ix, nq, 0, warm, kp, tau, false, st))) return rc;
+    if ((rc = dense_scan_all(ix, nq, 0, warm, kp, (float*)ix->w_tau.p, false, st, q0))) return rc;
     if (warm >= ix->ntotal) return LDOT_OK;
-    if ((rc = ix->w_pool.ensure((size_t)nq_pad * nsubs * kPoolCap * 8))) return rc;
-    const size_t cnt_bytes = (size_t)nq_pad * nsubs * 4, over_bytes = (size_t)nq_pad * 4;
-    if (cnt_bytes > ix->w_pool_cnt.bytes || over_bytes > ix->w_over.bytes) ix->pools_clean = false;
+    if ((rc = ix->w_pool.ensure((size_t)nq_pad * nsubs * kPoolCap * kPoolRecBytes))) return rc;
+    const size_t cnt_bytes = (size_t)nq_pad * nsubs * 4;
+    if (cnt_bytes > ix->w_pool_cnt.bytes) ix->pools_clean = false;
     if ((rc = ix->w_pool_cnt.ensure(cnt_bytes))) return rc;
-    if ((rc = ix->w_over.ensure(over_bytes))) return rc;
-    if (!ix->pools_clean) {
-        LDOT_HIP_CHECK(hipMemsetAsync(ix->w_over.p, 0, ix->w_over.bytes, st));
-        LDOT_HIP_CHECK(hipMemsetAsync(ix->w_pool_cnt.p, 0, ix->w_pool_cnt.bytes, st));
-    }
+    if (!ix->pools_clean) LDOT_HIP_CHECK(hipMemsetAsync(ix->w_pool_cnt.p, 0, ix->w_pool_cnt.bytes, st));
     ix->pools_clean = false;   // until this scan has completed
     // (the pad queries' thresholds are +inf since init_lists: they never produce candidates)
     // few query blocks: admissions are cheap, launches are not -> let the launch length grow up to the pool bound
@@ -441,16 +444,31 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
         if (ix->ntotal - r - len < len / 4) len = ix->ntotal - r;   // no short tail launch (the pool bound has that slack)
         prof_begin(ix, st, 2.0 * nq * len * ix->d,
                    (double)len * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * kp * 8);
-        rc = launch_score_filter(ix->x16b, ix->ld16(), r, len, ix->w_q16b.p, ix->ld16(), nq_pad, (int)ix->ld16(), tau,
-                                 (uint2*)ix->w_pool.p, (int32_t*)ix->w_pool_cnt.p, st);
+        rc = launch_score_filter(ix->x16b, ix->ld16(), r, len, q16, ix->ld16(), nq_pad, (int)ix->ld16(), tau,
+                                 (uint4*)ix->w_pool.p, (int32_t*)ix->w_pool_cnt.p, st);
         prof_end(ix, st);
         if (rc) return rc;
-        rc = launch_select_pools((const uint2*)ix->w_pool.p, (const int32_t*)ix->w_pool_cnt.p, (int)nsubs, nq, (float*)ix->w_ls.p, (int32_t*)ix->w_li.p, kp,
-                                 tau,
-                                 (int32_t*)ix->w_over.p, st);
+        rc = launch_select_pools((const uint4*)ix->w_pool.p, (const int32_t*)ix->w_pool_cnt.p, (int)nsubs, nq,
+                                 (int32_t)ix->ntotal, ls, li, kp, tau, over, st);
         if (rc) return rc;
         ix->stats[3] += len * nq;
         r += len;
+    }
+    ix->pools_clean = true;   // the pool selects reset every counter they read
+    return LDOT_OK;
+}
+
+static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStream_t st, bool* overflowed) {
+    *overflowed = false;
+    int rc;
+    const size_t over_bytes = (size_t)nq_pad * 4;
+    const bool fresh_flags = over_bytes > ix->w_over.bytes;
+    if ((rc = ix->w_over.ensure(over_bytes))) return rc;
+    if (fresh_flags || !ix->flags_clean) LDOT_HIP_CHECK(hipMemsetAsync(ix->w_over.p, 0, ix->w_over.bytes, st));
+    ix->flags_clean = false;
+    for (int64_t q0 = 0; q0 < nq; q0 += kFusedQueryChunk) {
+        const int64_t nqc = std::min(kFusedQueryChunk, nq - q0);
+        if ((rc = fused_scan_chunk(ix, q0, nqc, round_up(nqc, kBM), kp, st))) return rc;
     }
     // any query whose lane-private pool overflowed lost candidates: detect (one small D2H) and let the caller redo
     std::vector<int32_t> over((size_t)nq);
@@ -460,7 +478,7 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
     for (int32_t v : over) n_over += (v != 0);
     ix->stats[1] = n_over;
     *overflowed = n_over > 0;
-    ix->pools_clean = n_over == 0;   // the counters were reset by the pool selects; flags are zero unless set
+    ix->flags_clean = n_over == 0;
     return LDOT_OK;
 }
 

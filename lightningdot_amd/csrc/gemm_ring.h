@@ -88,10 +88,17 @@ __device__ __forceinline__ void ringr_read_b(const RingCtx& c, const char* stage
     for (int nr = 0; nr < 2; ++nr) b[nr] = *(const bf16x8_t*)(b_w + nr * 2048);
 }
 
-// one k-step: MFMAs on (a[*], bcur) while a[*] is reloaded from (nstage, nks) and bnext is fetched
-template <int MR, bool SKIP_B = false>
+struct RingNoHook {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+
+// one k-step: MFMAs on (a[*], bcur) while a[*] is reloaded from (nstage, nks) and bnext is fetched.  hook(mr) runs after
+// row block mr: the fused kernel issues its direct-to-LDS slab loads there ONE PIECE AT A TIME instead of as a burst after the
+// k-step (a burst of 8 waves x 5 pieces fills the texture-address FIFO and every wave blocks on VMEM issue while the matrix pipe
+// drains: tools/mfma_ceiling.hip measures 80 % -> 92 % matrix-pipe issue for this change alone).
+template <int MR, bool SKIP_B = false, typename Hook = RingNoHook>
 __device__ __forceinline__ void ringr_step(const RingCtx& c, FragsR<MR>& f, const int cur, const char* nstage,
-                                           const int nks, f32x16 (&acc)[MR][2]) {
+                                           const int nks, f32x16 (&acc)[MR][2], const Hook& hook = Hook()) {
     if (!SKIP_B) ringr_read_b<MR>(c, nstage, nks, f.b[cur ^ 1]);   // (SKIP_B: profiling ablation only)
     const char* a_w = nstage + c.wm * (32 * MR * 64) + (c.frag_off0 ^ (nks << 5));
 #pragma unroll
@@ -99,6 +106,7 @@ __device__ __forceinline__ void ringr_step(const RingCtx& c, FragsR<MR>& f, cons
         acc[mr][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mr], f.b[cur][0], acc[mr][0], 0, 0, 0);
         acc[mr][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mr], f.b[cur][1], acc[mr][1], 0, 0, 0);
         f.a[mr] = *(const bf16x8_t*)(a_w + mr * 2048);
+        hook(mr);
     }
 }
 

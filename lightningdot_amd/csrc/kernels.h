@@ -11,10 +11,16 @@ constexpr int kMaxK = 2048;        // largest k of a search
 constexpr int kMaxKp = 3072;       // largest candidate-list length k' = k + margin: k' + 1024 keys fit a 32 KiB LDS buffer
 constexpr int kSelThreads = 256;
 
-// fused-filter candidate pools: per query, nsubs = 4 * (row slices) lane-private sub-pools of kPoolCap {score, row}
-// words, laid out entry-major: pool[(q * kPoolCap + e) * nsubs + sub].
+// fused-filter candidate pools: per query, nsubs = 4 * (row slices) lane-private sub-pools of kPoolCap RECORDS.  A record is
+// what one lane holds when its 8-score test fires: the 8 scores of accumulator registers 8h..8h+7 of one 32x32 tile (rows
+// rb + {0,1,2,3,8,9,10,11}) and rb — three 16-byte planes {s0..s3}, {s4..s7}, {rb,-,-,-}, laid out entry-major and plane-major:
+// pool[((q * kPoolCap + e) * 3 + plane) * nsubs + sub].  The filter does not localise the hit (no per-score compares, no
+// nested branches on the matrix pipe's critical path: three stores straight from the accumulator registers); the pool select
+// applies the threshold to the 8 scores of every record.
 // sub-pool id = ((slice * 2 + wm) * 2 + (lane >> 5)); slices = 256 / (query blocks per XCD) = 32 .. 256
 constexpr int kPoolCap = 32;
+constexpr int kPoolPlanes = 3;
+constexpr int kPoolRecBytes = 16 * kPoolPlanes;
 constexpr int kPoolSubsMax = 1024;   // query-group width 1: 256 row slices x 4 lanes
 
 // rows: convert n rows of `dtype` (row stride ld_src elements, d valid columns) into the padded fp32 master copy
@@ -45,7 +51,8 @@ int launch_lists_to_parts(const float* list_s, const int32_t* list_i, int64_t n,
                           hipStream_t st);
 int launch_parts_to_lists(const float* out_s, const int64_t* out_l, int64_t n, float* list_s, int32_t* list_i, int kp,
                           float* tau, hipStream_t st);
-int launch_select_pools(const uint2* pool, const int32_t* pool_cnt, int nsubs, int64_t nq, float* list_s,
+// row_end: records may carry rows of the zero padding behind the last index row (>= row_end): dropped here
+int launch_select_pools(const uint4* pool, const int32_t* pool_cnt, int nsubs, int64_t nq, int32_t row_end, float* list_s,
                         int32_t* list_i, int kp, float* tau, int32_t* overflow_flags, hipStream_t st);
 // generic merge of explicit candidate lists: cand_[sl] is [nq][ncand] (labels int64, -1 = empty) -> [nq][k_out]
 int launch_select_lists(const float* cand_s, const int64_t* cand_l, int64_t part_stride, int nparts, int k_in,
@@ -62,7 +69,7 @@ int fused_query_group(int64_t nq_pad);   // 8 / 4 / 2 / 1 -> 1024 / qg sub-pools
 // fused MFMA score + threshold filter over index rows [row0, row0 + nrows) (row0 multiple of 16); x16 / q16 are the BLOCKED
 // shadows (launch_convert_rows dst16b)
 int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_t nrows, const void* q16,
-                        int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, uint2* pool, int32_t* pool_cnt,
+                        int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, uint4* pool, int32_t* pool_cnt,
                         hipStream_t st);
 
 // loss path (fp32-input MFMA)

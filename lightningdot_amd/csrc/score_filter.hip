@@ -39,18 +39,6 @@
 
 namespace ldot {
 
-// Append one candidate to this lane's sub-pool (cursor `cur`, clamped at kPoolCap; the true count is kept so overflow
-// is detectable).  pbase = q * kPoolCap * nsubs + sub, entry e lives at pbase + e * nsubs.
-template <bool NOSTORE = false>
-__device__ __forceinline__ void filter_append(float v, float tau, int32_t row, int32_t row_end, int& cur, uint32_t pbase,
-                                              uint32_t nsubs, uint2* __restrict__ pool) {
-    if (v >= tau && row < row_end) {
-        const int p = cur;
-        cur = p + 1;
-        if (p < kPoolCap && !NOSTORE) pool[pbase + (uint32_t)p * nsubs] = make_uint2(__float_as_uint(v), (uint32_t)row);
-    }
-}
-
 // ---- third generation: (64*MR) x 256 tile on the ring, A fragments recycled in place (gemm_ring.h) -------------
 // max of four accumulator registers in two instructions.  fmaxf() would add a canonicalising v_max per MFMA
 // output (hipcc cannot prove MFMA results are quiet); scores are never signalling NaNs, so v_max3 is applied
@@ -80,11 +68,14 @@ __device__ __forceinline__ void filter_hazard_cover() {
 }
 
 // threshold filter of one 32-row block (mr) of the wave tile: both query columns of the lane, eight scores per test
-// (three v_max3 + v_max + compare + branch on the fast path), a hit localised by halves
+// (three v_max3 + v_max + compare + branch on the fast path).  A firing test does NOT localise the hit: the lane appends one
+// record = the 8 scores (two 16-byte stores straight from the accumulator registers) + their base row to its sub-pool (cursor
+// `cur`, clamped at kPoolCap; the true count is kept so that overflow is detectable) and the pool select thresholds them.
+// pbase = (q * kPoolCap * 3) * nsubs + sub in 16-byte units; entry e, plane p at pbase + (e * 3 + p) * nsubs.
 template <bool NOSTORE>
 __device__ __forceinline__ void filter_epilogue_mr(const f32x16& acc0, const f32x16& acc1, int mr, const float (&tau)[2],
                                                    int (&cur)[2], uint32_t pbase0, uint32_t pstep, uint32_t nsubs,
-                                                   uint2* __restrict__ pool, int32_t row_wave0, int32_t row_end) {
+                                                   uint4* __restrict__ pool, int32_t row_wave0) {
 #pragma unroll
     for (int nr = 0; nr < 2; ++nr) {
         const f32x16& a = nr ? acc1 : acc0;
@@ -93,22 +84,17 @@ __device__ __forceinline__ void filter_epilogue_mr(const f32x16& acc0, const f32
             const float a0 = a[8 * h + 0], a1 = a[8 * h + 1], a2 = a[8 * h + 2], a3 = a[8 * h + 3];
             const float a4 = a[8 * h + 4], a5 = a[8 * h + 5], a6 = a[8 * h + 6], a7 = a[8 * h + 7];
             const float m = max8_raw(a0, a1, a2, a3, a4, a5, a6, a7);
-            if (m >= tau[nr]) {   // rare: find the half (usually one) that holds the hit
+            if (m >= tau[nr]) {   // rare (a few per tile and wave)
                 // (rare path: the lane's row offset and the sub-pool base are derived here instead of living in registers)
                 // registers 8h..8h+3: rows +0..3, 8h+4..8h+7: rows +8..11
                 const int32_t rb = row_wave0 + 4 * (int32_t)((threadIdx.x & 63) >> 5) + mr * 32 + 16 * h;
-                const uint32_t pb = pbase0 + (uint32_t)nr * pstep;
-                if (max4_raw(a0, a1, a2, a3) >= tau[nr]) {
-                    filter_append<NOSTORE>(a0, tau[nr], rb + 0, row_end, cur[nr], pb, nsubs, pool);
-                    filter_append<NOSTORE>(a1, tau[nr], rb + 1, row_end, cur[nr], pb, nsubs, pool);
-                    filter_append<NOSTORE>(a2, tau[nr], rb + 2, row_end, cur[nr], pb, nsubs, pool);
-                    filter_append<NOSTORE>(a3, tau[nr], rb + 3, row_end, cur[nr], pb, nsubs, pool);
-                }
-                if (max4_raw(a4, a5, a6, a7) >= tau[nr]) {
-                    filter_append<NOSTORE>(a4, tau[nr], rb + 8, row_end, cur[nr], pb, nsubs, pool);
-                    filter_append<NOSTORE>(a5, tau[nr], rb + 9, row_end, cur[nr], pb, nsubs, pool);
-                    filter_append<NOSTORE>(a6, tau[nr], rb + 10, row_end, cur[nr], pb, nsubs, pool);
-                    filter_append<NOSTORE>(a7, tau[nr], rb + 11, row_end, cur[nr], pb, nsubs, pool);
+                const int p = cur[nr];
+                cur[nr] = p + 1;
+                if (p < kPoolCap && !NOSTORE) {
+                    uint4* rec = pool + (pbase0 + (uint32_t)nr * pstep + (uint32_t)p * (kPoolPlanes * nsubs));
+                    rec[0] = make_uint4(__float_as_uint(a0), __float_as_uint(a1), __float_as_uint(a2), __float_as_uint(a3));
+                    rec[nsubs] = make_uint4(__float_as_uint(a4), __float_as_uint(a5), __float_as_uint(a6), __float_as_uint(a7));
+                    rec[2 * nsubs] = make_uint4((uint32_t)rb, 0u, 0u, 0u);
                 }
             }
         }
@@ -117,12 +103,12 @@ __device__ __forceinline__ void filter_epilogue_mr(const f32x16& acc0, const f32
 
 template <int MR, bool NOSTORE>
 __device__ __forceinline__ void filter_epilogue_r(const f32x16 (&acc)[MR][2], const float (&tau)[2], int (&cur)[2],
-                                                  uint32_t pbase0, uint32_t pstep, uint32_t nsubs, uint2* __restrict__ pool,
-                                                  int32_t row_wave0, int32_t row_end) {
+                                                  uint32_t pbase0, uint32_t pstep, uint32_t nsubs, uint4* __restrict__ pool,
+                                                  int32_t row_wave0) {
     filter_hazard_cover();
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr)
-        filter_epilogue_mr<NOSTORE>(acc[mr][0], acc[mr][1], mr, tau, cur, pbase0, pstep, nsubs, pool, row_wave0, row_end);
+        filter_epilogue_mr<NOSTORE>(acc[mr][0], acc[mr][1], mr, tau, cur, pbase0, pstep, nsubs, pool, row_wave0);
 }
 
 template <int N>
@@ -135,7 +121,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int VAR>
 __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     const char* __restrict__ X16, int64_t ldx_b, int64_t row0, int64_t nrows, const char* __restrict__ Q16,
-    int64_t ldq_b, int nqb, int nk, const float* __restrict__ tau_g, uint2* __restrict__ pool,
+    int64_t ldq_b, int nqb, int nk, const float* __restrict__ tau_g, uint4* __restrict__ pool,
     int32_t* __restrict__ pool_cnt, int qg_log2) {
     constexpr int MR = 6;
     using Geo = RingGeom<MR>;
@@ -150,7 +136,6 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     const int qsub = slot & (qg - 1), nsub = slot >> qg_log2;
     const int slice = xcd * nstream + nsub;
     const int ntiles = (int)((nrows + Geo::kBM - 1) / Geo::kBM);
-    const int32_t row_end = (int32_t)(row0 + nrows);
     const int sub = (slice * 2 + c.wm) * 2 + (c.lane >> 5);
     const int nq_iter = (nqb > qsub) ? (nqb - qsub + qg - 1) >> qg_log2 : 0;   // query groups in which this qsub is valid
     const int64_t nunits = (int64_t)nq_iter * ntiles;                            // (group, tile) units of this qsub
@@ -169,18 +154,19 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)l_t * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
     sb.rsrc = ring_make_rsrc_n(Q16 + (int64_t)(qsub + l_q * qg) * kRBN * ldq_b, kRBN * ldq_b);
     int64_t issued = 0;
-    auto issue = [&]() {
+    // one slab = kLoads pieces per wave (3 of the row panel, 2 of the query panel).  piece(j) issues one of them into the stage
+    // of slab `issued`; advance() moves the cursor to the next slab once all pieces are out.
+    auto piece = [&](const int j) {
         char* st = smem + (int)(issued & 3) * Geo::kStage;
         const int k0b = l_k * 1024;   // slab l_k of a 16-row group = its l_k-th KiB block
-        if (!(VAR & 2) || issued < 4)
-#pragma unroll
-        for (int j = 0; j < Geo::kALoads; ++j)
+        if ((VAR & 2) && issued >= 4) return;
+        if (j < Geo::kALoads)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(sa.rsrc, (rg_lptr_t)(st + (j * 8 + c.wave) * 1024), 16, vo, k0b + j * jstep, 0, 0);
-        if (!(VAR & 2) || issued < 4)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(sb.rsrc, (rg_lptr_t)(st + Geo::kAOpBytes + (j * 8 + c.wave) * 1024),
-                                                     16, vo, k0b + j * jstep, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(sb.rsrc, (rg_lptr_t)(st + Geo::kAOpBytes + ((j - Geo::kALoads) * 8 + c.wave) * 1024),
+                                                     16, vo, k0b + (j - Geo::kALoads) * jstep, 0, 0);
+    };
+    auto advance = [&]() {
         ++issued;
         if (issued < S) {
             if (++l_k == nk) {   // next unit of this stream
@@ -197,6 +183,30 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
             }
         }
     };
+    auto issue = [&]() {
+#pragma unroll
+        for (int j = 0; j < Geo::kLoads; ++j) piece(j);
+        advance();
+    };
+    // the pieces of a slab ride between the MFMAs of two k-steps: pieces 0..2 after row blocks 1, 3, 5 of the k-step that follows
+    // the barrier (the stage they overwrite was vacated there), pieces 3, 4 after row blocks 1, 3 of the next k-step (before the
+    // next barrier's counted vmcnt, which therefore still sees whole slabs)
+    bool defer_burst = false;
+    auto hook_post = [&](int mr) {
+        if (!(VAR & 128)) {   // default: the whole slab as a burst after the k-step (VAR & 128: piece by piece, see below)
+            if (mr == MR - 1 && !defer_burst) issue();
+            return;
+        }
+        if (mr & 1) piece(mr >> 1);
+    };
+    auto hook_pre = [&](int mr) {
+        if (!(VAR & 128)) return;
+        if (mr == 1) piece(3);
+        if (mr == 3) {
+            piece(4);
+            advance();
+        }
+    };
     issue();
     issue();
     issue();
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     float tau[2];
     int cur[2] = {0, 0};
     uint32_t pbase0 = 0;                                             // sub-pool base of the lane's first query column
-    const uint32_t pstep = 32u * kPoolCap * (uint32_t)nsubs;         // ... the second one is 32 queries further
+    const uint32_t pstep = 32u * kPoolCap * kPoolPlanes * (uint32_t)nsubs;   // ... the second one is 32 queries further
     f32x16 acc[MR][2];
     FragsR<MR> f;
     {
@@ -224,7 +234,9 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     // cleared accumulator).  MODE 2: the first slab of a later tile, FUSED with the threshold filter of the tile just
     // finished: block by block (mr), the filter reads the finished scores and the C = 0 MFMAs of the new tile overwrite
     // them, so the matrix pipe works on block mr while the VALU filters block mr + 1 (the filter alone leaves the matrix
-    // pipe idle: all waves run it at the same time).
+    // pipe idle: all waves run it at the same time).  The LAST slab of a tile that a MODE 2 slab follows (defer_burst): its trailing
+    // burst of slab loads is deferred until after the filter, so that the filter's pool stores do not queue behind 40 LDS-DMA
+    // pieces in the CU's texture-address FIFO while the matrix pipe waits for the wave (VAR & 256: no deferral, ablation).
     int32_t epi_row_wave0 = 0;   // (uniform) first row of the wave's block of the tile whose filter is pending
     auto slab = [&](auto mode_tag) {
         constexpr int MODE = decltype(mode_tag)::value;
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
         // k-step 0 of slab s (operands: a, b[0]); a <- k-step 1 of slab s, b[1] <- k-step 1 of slab s
         if (!(VAR & 4)) {
             if (MODE == 0) {
-                ringr_step<MR, (VAR & 32) != 0>(c, f, 0, st0, 1, acc);
+                ringr_step<MR, (VAR & 32) != 0>(c, f, 0, st0, 1, acc, hook_pre);
             } else {
                 ringr_read_b<MR>(c, st0, 1, f.b[1]);
                 const char* a_w = st0 + c.wm * (32 * MR * 64) + (c.frag_off0 ^ 32);
@@ -242,14 +254,16 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
                 for (int mr = 0; mr < MR; ++mr) {
                     if (MODE == 2 && !(VAR & 1)) {
                         filter_epilogue_mr<(VAR & 8) != 0>(acc[mr][0], acc[mr][1], mr, tau, cur, pbase0, pstep, (uint32_t)nsubs,
-                                                           pool, epi_row_wave0, row_end);
+                                                           pool, epi_row_wave0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     acc[mr][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mr], f.b[0][0], z, 0, 0, 0);
                     acc[mr][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mr], f.b[0][1], z, 0, 0, 0);
                     f.a[mr] = *(const bf16x8_t*)(a_w + mr * 2048);
+                    if (MODE == 2) hook_pre(mr);   // (MODE 1 = the very first slab: no slab is half issued yet)
                     if (MODE == 2 && !(VAR & 1)) __builtin_amdgcn_sched_barrier(0);
                 }
+                if (MODE == 2 && !(VAR & 256)) issue();   // the burst the previous (MODE 3) slab deferred
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -261,9 +275,9 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
         __builtin_amdgcn_s_barrier();                        // ... and everybody else's
         ++s;
         // k-step 1 of the old slab (operands: a, b[1]); a, b[0] <- k-step 0 of slab s (just opened)
-        if (!(VAR & 4)) ringr_step<MR, (VAR & 32) != 0>(c, f, 1, smem + (int)(s & 3) * Geo::kStage, 0, acc);
+        // ... and the first three pieces of slab s+3 (or a dummy) -> the stage slab s-1 vacated at the barrier
+        if (!(VAR & 4)) ringr_step<MR, (VAR & 32) != 0>(c, f, 1, smem + (int)(s & 3) * Geo::kStage, 0, acc, hook_post);
         __builtin_amdgcn_sched_barrier(0);
-        issue();                                             // slab s+3 (or a dummy) -> the stage slab s-1 vacated
     };
     using M0 = std::integral_constant<int, 0>;
     using M1 = std::integral_constant<int, 1>;
@@ -282,7 +296,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
         for (int nr = 0; nr < 2; ++nr) {
             const int64_t qi = (int64_t)(qsub + g * qg) * kRBN + c.wn * 64 + nr * 32 + (c.lane & 31);
             tau[nr] = (VAR & 16) ? INFINITY : ring_launder(tau_g[qi]);
-            if (nr == 0) pbase0 = (uint32_t)(qi * kPoolCap * nsubs + sub);
+            if (nr == 0) pbase0 = (uint32_t)(qi * kPoolCap * kPoolPlanes * nsubs + sub);
             cur[nr] = 0;
         }
     };
@@ -300,7 +314,11 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
 #pragma unroll 1
     for (int j = 0; j < ntile_total; ++j) {
 #pragma unroll 1
-        for (int kk = 1; kk < nk; ++kk) slab(M0{});
+        for (int kk = 1; kk < nk; ++kk) {
+            defer_burst = !(VAR & 256) && kk == nk - 1 && j + 1 < ntile_total;   // (uniform) see MODE 2
+            slab(M0{});
+        }
+        defer_burst = false;
         // tile j is complete in acc
         const int64_t trow = row0 + (int64_t)c_t * Geo::kBM;
         epi_row_wave0 = (int32_t)trow + c.wm * (32 * MR);
@@ -317,7 +335,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
                 setup_group(c_q);
             }
         } else if (!(VAR & 1)) {
-            filter_epilogue_r<MR, (VAR & 8) != 0>(acc, tau, cur, pbase0, pstep, (uint32_t)nsubs, pool, epi_row_wave0, row_end);
+            filter_epilogue_r<MR, (VAR & 8) != 0>(acc, tau, cur, pbase0, pstep, (uint32_t)nsubs, pool, epi_row_wave0);
         } else {
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr)
@@ -346,7 +364,7 @@ int fused_query_group(int64_t nq_pad) {
 }
 
 int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_t nrows, const void* q16,
-                        int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, uint2* pool, int32_t* pool_cnt,
+                        int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, uint4* pool, int32_t* pool_cnt,
                         hipStream_t st) {
     if (nrows <= 0 || nq_pad <= 0) return LDOT_OK;
     LDOT_REQUIRE(ldx_elems == ldq_elems, LDOT_EINVAL, "index and query shadows must have the same row stride");
@@ -364,6 +382,10 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     if (variant == 17) rk = score_filter_r6_kernel<17>;   // no epilogue at all (upper bound of hiding it)
     if (variant == 48) rk = score_filter_r6_kernel<48>;
     if (variant == 80) rk = score_filter_r6_kernel<80>;
+    if (variant == 8) rk = score_filter_r6_kernel<8>;
+    if (variant == 256) rk = score_filter_r6_kernel<256>;
+    if (variant == 128) rk = score_filter_r6_kernel<128>;
+    if (variant == 144) rk = score_filter_r6_kernel<144>;
     LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<6>::kLds));
     const int qg = fused_query_group(nq_pad);
     const int qg_log2 = qg == 8 ? 3 : qg == 4 ? 2 : qg == 2 ? 1 : 0;

@@ -453,12 +453,15 @@ __global__ __launch_bounds__(256) void parts_to_lists_kernel(const float* __rest
 // pool source: the per-query sub-pools filled by the fused filter kernel; resets the counters afterwards.
 // One wave per query (no cross-wave barriers), small LDS footprint -> many queries resident per CU.
 constexpr int kPoolSelThreads = 64;
-// LV = entry levels fetched per step (x 2 groups of 64 sub-pools): a step appends at most 2 * LV * 64 candidates on top of
-// a full list, which sizes the LDS key buffer (cap >= kp + 2 * LV * 64) and with it the workgroups per CU.
+// A step (one entry level of 64 sub-pools = 64 records of 8 scores) appends at most 512 candidates on top of a full list,
+// which sizes the LDS key buffer (cap >= kp + 512) and with it the workgroups per CU.  (LV: unused, kept for the launch sites.)
+// rows of the 8 scores of a record relative to its base row (accumulator registers 8h..8h+3 / 8h+4..8h+7 of a 32x32 MFMA tile)
+__device__ __forceinline__ int pool_rec_row(int j) { return j < 4 ? j : j + 4; }
+
 template <int LV, int QPW>
-__global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(const uint2* __restrict__ pool,
+__global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(const uint4* __restrict__ pool,
                                                                        int32_t* __restrict__ pool_cnt, int nsubs, int64_t nq,
-                                                                       float* __restrict__ list_s,
+                                                                       int32_t row_end, float* __restrict__ list_s,
                                                                        int32_t* __restrict__ list_i, int kp, int cap,
                                                                        float* __restrict__ tau,
                                                                        int32_t* __restrict__ overflow, int dbg) {
@@ -473,47 +476,48 @@ __global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(con
     float* ls = list_s + q * kp;
     int32_t* li = list_i + q * kp;
     int32_t* cnt = pool_cnt + q * (int64_t)nsubs;
-    // counters of the first 128 sub-pools are requested before the list so that both round trips overlap
-    int cn[2];
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int sidx = g * kPoolSelThreads + lane;
-        cn[g] = sidx < nsubs ? cnt[sidx] : 0;
-    }
+    // counters of the first 64 sub-pools are requested before the list so that both round trips overlap
+    int cn = lane < nsubs ? cnt[lane] : 0;
     if (!(dbg & 4)) sel.load_list(ls, li);
     bool over = false;
-    // entry-major pools: level e of all sub-pools is one contiguous run of 8-byte words -> coalesced reads of the few
-    // levels in use.  Two groups of 64 sub-pools x LV entry levels per step.
-    const uint2* base = pool + q * (int64_t)kPoolCap * nsubs;
-    for (int s0 = 0; s0 < nsubs; s0 += 2 * kPoolSelThreads) {
-        int c[2];
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int sidx = s0 + g * kPoolSelThreads + lane;
-            over |= cn[g] > kPoolCap;
-            c[g] = cn[g] < kPoolCap ? cn[g] : kPoolCap;
-            if (sidx < nsubs) cnt[sidx] = 0;
-            const int nidx = sidx + 2 * kPoolSelThreads;       // next step's counters
-            cn[g] = nidx < nsubs ? cnt[nidx] : 0;
-        }
-        int cm = max(c[0], c[1]);
+    // entry-major, plane-major pools: plane p of level e of all sub-pools is one contiguous run of 16-byte words -> coalesced
+    // reads of the few levels in use.  One group of 64 sub-pools x LV entry levels per step.
+    const uint4* base = pool + q * (int64_t)kPoolCap * kPoolPlanes * nsubs;
+    // One group of 64 sub-pools per step, one entry level per iteration with the next level's record in flight (a single
+    // feed site: the selector's compaction is inlined there once).
+    for (int s0 = 0; s0 < nsubs; s0 += kPoolSelThreads) {
+        const int sidx = s0 + lane;
+        over |= cn > kPoolCap;
+        const int c = cn < kPoolCap ? cn : kPoolCap;
+        if (sidx < nsubs) cnt[sidx] = 0;
+        cn = sidx + kPoolSelThreads < nsubs ? cnt[sidx + kPoolSelThreads] : 0;   // next step's counters
+        int cm = c;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cm = max(cm, __shfl_xor(cm, o));
         if (dbg & 1) cm = 0;
-        for (int e0 = 0; e0 < cm; e0 += LV) {
-            sel.reserve(2 * LV * kPoolSelThreads);
-            uint2 v[2][LV];
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int u = 0; u < LV; ++u)
-                    v[g][u] = (e0 + u < c[g])
-                                  ? base[(int64_t)(e0 + u) * nsubs + s0 + g * kPoolSelThreads + lane]
-                                  : make_uint2(0u, 0u);
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int u = 0; u < LV; ++u) sel.push(make_key(__uint_as_float(v[g][u].x), v[g][u].y), e0 + u < c[g]);
+        uint4 n0, n1;
+        int32_t nr;
+        auto fetch = [&](int e) {
+            const uint4* rec = base + (int64_t)e * kPoolPlanes * nsubs + sidx;
+            const bool have = e < c;
+            n0 = have ? rec[0] : make_uint4(0u, 0u, 0u, 0u);
+            n1 = have ? rec[nsubs] : make_uint4(0u, 0u, 0u, 0u);
+            nr = have ? (int32_t)rec[2 * nsubs].x : row_end;
+        };
+        if (cm > 0) fetch(0);
+        for (int e = 0; e < cm; ++e) {
+            const uint4 p0 = n0, p1 = n1;
+            const int32_t r0 = nr;
+            if (e + 1 < cm) fetch(e + 1);
+            sel.reserve(8 * kPoolSelThreads);
+            sel.push(make_key(__uint_as_float(p0.x), (uint32_t)(r0 + 0)), r0 + 0 < row_end);
+            sel.push(make_key(__uint_as_float(p0.y), (uint32_t)(r0 + 1)), r0 + 1 < row_end);
+            sel.push(make_key(__uint_as_float(p0.z), (uint32_t)(r0 + 2)), r0 + 2 < row_end);
+            sel.push(make_key(__uint_as_float(p0.w), (uint32_t)(r0 + 3)), r0 + 3 < row_end);
+            sel.push(make_key(__uint_as_float(p1.x), (uint32_t)(r0 + 8)), r0 + 8 < row_end);
+            sel.push(make_key(__uint_as_float(p1.y), (uint32_t)(r0 + 9)), r0 + 9 < row_end);
+            sel.push(make_key(__uint_as_float(p1.z), (uint32_t)(r0 + 10)), r0 + 10 < row_end);
+            sel.push(make_key(__uint_as_float(p1.w), (uint32_t)(r0 + 11)), r0 + 11 < row_end);
         }
     }
     const bool any_over = __any(over);
@@ -525,9 +529,9 @@ __global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(con
 // Few queries (<= one query block, the serving shape): one 256-thread workgroup per query instead of one wave, so that
 // the counters and entry levels of 512 sub-pools are in flight per step (the one-wave walk is a chain of dependent
 // global round trips when there is nothing else on the chip to hide them).
-__global__ __launch_bounds__(kSelThreads) void select_pools_block_kernel(const uint2* __restrict__ pool,
+__global__ __launch_bounds__(kSelThreads) void select_pools_block_kernel(const uint4* __restrict__ pool,
                                                                          int32_t* __restrict__ pool_cnt, int nsubs,
-                                                                         float* __restrict__ list_s,
+                                                                         int32_t row_end, float* __restrict__ list_s,
                                                                          int32_t* __restrict__ list_i, int kp, int cap,
                                                                          float* __restrict__ tau,
                                                                          int32_t* __restrict__ overflow) {
@@ -538,12 +542,12 @@ __global__ __launch_bounds__(kSelThreads) void select_pools_block_kernel(const u
     sel.init(keys, &count, kp, cap);
     float* ls = list_s + q * kp;
     int32_t* li = list_i + q * kp;
-    const uint2* base = pool + q * (int64_t)kPoolCap * nsubs;
+    const uint4* base = pool + q * (int64_t)kPoolCap * kPoolPlanes * nsubs;
     int32_t* cnt = pool_cnt + q * (int64_t)nsubs;
     bool over = false;
     // a lone workgroup pays every dependent global round trip in full: the counters of SPT x 256 sub-pools are fetched in one
-    // batch (together with the running list), then four entry levels of all of them in another
-    constexpr int SPT = 4, LV = 4;
+    // batch (together with the running list), then two entry levels of all of them in another
+    constexpr int SPT = 4, LV = 2;
     for (int s0 = 0; s0 < nsubs; s0 += SPT * kSelThreads) {
         int c[SPT];
 #pragma unroll
@@ -562,19 +566,34 @@ __global__ __launch_bounds__(kSelThreads) void select_pools_block_kernel(const u
             cm = max(cm, c[g]);
         }
         for (int e0 = 0; __syncthreads_or(cm > e0); e0 += LV) {
-            uint2 v[SPT][LV];
+            uint4 v[SPT][LV][2];
+            int32_t rb[SPT][LV];
 #pragma unroll
             for (int g = 0; g < SPT; ++g)
 #pragma unroll
-                for (int u = 0; u < LV; ++u)
-                    v[g][u] = (e0 + u < c[g]) ? base[(int64_t)(e0 + u) * nsubs + s0 + g * kSelThreads + threadIdx.x]
-                                              : make_uint2(0u, 0u);
+                for (int u = 0; u < LV; ++u) {
+                    const uint4* rec = base + (int64_t)(e0 + u) * kPoolPlanes * nsubs + s0 + g * kSelThreads + threadIdx.x;
+                    const bool have = e0 + u < c[g];
+                    v[g][u][0] = have ? rec[0] : make_uint4(0u, 0u, 0u, 0u);
+                    v[g][u][1] = have ? rec[nsubs] : make_uint4(0u, 0u, 0u, 0u);
+                    rb[g][u] = have ? (int32_t)rec[2 * nsubs].x : row_end;
+                }
 #pragma unroll
-            for (int u = 0; u < LV; ++u) {
-                sel.reserve(SPT * kSelThreads);
+            for (int u = 0; u < LV; ++u)
 #pragma unroll
-                for (int g = 0; g < SPT; ++g) sel.push(make_key(__uint_as_float(v[g][u].x), v[g][u].y), e0 + u < c[g]);
-            }
+                for (int g = 0; g < SPT; ++g) {
+                    const uint32_t sc[8] = {v[g][u][0].x, v[g][u][0].y, v[g][u][0].z, v[g][u][0].w,
+                                            v[g][u][1].x, v[g][u][1].y, v[g][u][1].z, v[g][u][1].w};
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {   // 4 x 256 keys per reservation (the LDS buffer holds a full list + 1024)
+                        sel.reserve(4 * kSelThreads);
+#pragma unroll
+                        for (int j = 4 * h; j < 4 * h + 4; ++j) {
+                            const int32_t row = rb[g][u] + pool_rec_row(j);
+                            sel.push(make_key(__uint_as_float(sc[j]), (uint32_t)row), row < row_end);
+                        }
+                    }
+                }
         }
     }
     sel.finish(ls, li, tau ? tau + q : nullptr);
@@ -677,13 +696,13 @@ int launch_parts_to_lists(const float* out_s, const int64_t* out_l, int64_t n, f
     return LDOT_OK;
 }
 
-int launch_select_pools(const uint2* pool, const int32_t* pool_cnt, int nsubs, int64_t nq, float* list_s,
+int launch_select_pools(const uint4* pool, const int32_t* pool_cnt, int nsubs, int64_t nq, int32_t row_end, float* list_s,
                         int32_t* list_i, int kp, float* tau, int32_t* overflow_flags, hipStream_t st) {
     if (nq <= 0) return LDOT_OK;
     if (nq <= 256) {   // few queries: block-per-query walk
         const int bcap = select_cap(kp, 2048, 4 * kSelThreads);   // a step appends up to 4 x 256 candidates on top of a full list
         hipLaunchKernelGGL(select_pools_block_kernel, dim3((unsigned)nq), dim3(kSelThreads), (size_t)bcap * 8, st, pool,
-                           (int32_t*)pool_cnt, nsubs, list_s, list_i, kp, bcap, tau, overflow_flags);
+                           (int32_t*)pool_cnt, nsubs, row_end, list_s, list_i, kp, bcap, tau, overflow_flags);
         LDOT_HIP_CHECK(hipGetLastError());
         return LDOT_OK;
     }
@@ -697,10 +716,10 @@ int launch_select_pools(const uint2* pool, const int32_t* pool_cnt, int nsubs, i
         constexpr int QPW = 4;
         hipLaunchKernelGGL((select_pools_kernel<4, QPW>), dim3((unsigned)((nq + QPW - 1) / QPW)),
                            dim3(kPoolSelThreads * QPW), (size_t)cap * 8 * QPW, st, pool, (int32_t*)pool_cnt, nsubs, nq,
-                           list_s, list_i, kp, cap, tau, overflow_flags, dbg);
+                           row_end, list_s, list_i, kp, cap, tau, overflow_flags, dbg);
     } else {   // kp > 512: LDS sort path, one wave per workgroup
         hipLaunchKernelGGL((select_pools_kernel<4, 1>), dim3((unsigned)nq), dim3(kPoolSelThreads), (size_t)cap * 8, st,
-                           pool, (int32_t*)pool_cnt, nsubs, nq, list_s, list_i, kp, cap, tau, overflow_flags, dbg);
+                           pool, (int32_t*)pool_cnt, nsubs, nq, row_end, list_s, list_i, kp, cap, tau, overflow_flags, dbg);
     }
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;

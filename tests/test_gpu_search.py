@@ -142,10 +142,12 @@ def test_fused_adversarial_order_falls_back(L):
     """Rows sorted so that every later row beats all earlier ones for every query: the lane-private pools
     overflow, the library detects it and redoes the search densely — results stay exact."""
     rng = np.random.default_rng(11)
-    n, d, nq = 12000, 64, 2048      # 8 query blocks -> 32 row slices, warm-up 4096 rows, one fused launch
+    # 8 query blocks -> 32 row slices; a sub-pool holds 32 records of 8 rows each, so it takes a launch with 3 tiles per slice
+    # (the third geometric launch, rows 26 624 .. 63 488) to overflow one: 288 winning rows per sub-pool = 36 records
+    n, d, nq = 70000, 64, 2048
     base = rng.standard_normal(d).astype(np.float32)
     base /= np.linalg.norm(base)
-    x = (rng.standard_normal((n, d)) * 0.01).astype(np.float32) + np.outer(np.linspace(0.0, 50.0, n), base).astype(np.float32)
+    x = (rng.standard_normal((n, d)) * 0.01).astype(np.float32) + np.outer(np.linspace(0.0, 300.0, n), base).astype(np.float32)
     q = (np.outer(np.ones(nq), base) + rng.standard_normal((nq, d)) * 0.01).astype(np.float32)
     ix = _index(x, mode=L.MODE_FUSED, warm_rows=2048)
     s, l = ix.search(q, 100)

@@ -1,0 +1,265 @@
+// Power-limited ceilings of the bf16 matrix pipe on MI355X with RANDOM operands (measurement tool, not product code).
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I lightningdot_amd/csrc tools/mfma_ceiling.hip -o tools/bin/mfma_ceiling
+//   tools/bin/mfma_ceiling [ms_per_variant]
+//
+// One workgroup per CU (256 persistent workgroups), v_mfma_f32_32x32x16_bf16 only.  Every variant runs the SAME number of
+// MFMAs per CU and reports executed TFLOP/s, the effective shader clock (s_memtime ticks / s_memrealtime ticks x 100 MHz)
+// and the matrix-pipe issue efficiency (32 cycles per MFMA and SIMD = 100 %).
+//
+//   geometry  W2 : 512 threads = 8 waves (2 x 4), wave tile 192 x 64  (12 accumulator tiles, 2 waves per SIMD)  [score_filter_r6]
+//             W1 : 256 threads = 4 waves (2 x 2), wave tile 192 x 128 (24 accumulator tiles, 1 wave per SIMD, 512 registers)
+//   feed      0  : register-resident fragments (MFMA only: the power ceiling of the pipe itself)
+//             1  : + ds_read_b128 fragment stream from an LDS ring image (no global loads)
+//             2  : + direct-to-LDS slab loads (buffer_load ... lds) through the 4-stage ring, counted vmcnt + one barrier per slab
+//   data      R  : N(0,1) random bf16 operands;  Z: all-zero operands (the DVFS give-back the guide describes)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <random>
+#include <vector>
+
+#include "gemm_ring.h"
+
+using namespace ldot;
+
+#define CK(x)                                                                          \
+    do {                                                                               \
+        hipError_t e_ = (x);                                                           \
+        if (e_ != hipSuccess) {                                                        \
+            fprintf(stderr, "%s: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(1);                                                                   \
+        }                                                                              \
+    } while (0)
+
+constexpr int kStage = 40 * 1024;   // A slab 384 rows x 64 B + B slab 256 rows x 64 B
+constexpr int kAOp = 24 * 1024;
+
+template <int NW>   // waves per workgroup
+struct Geo {
+    static constexpr int MR = 6;
+    static constexpr int NR = NW == 8 ? 2 : 4;
+    static constexpr int WN = NW == 8 ? 4 : 2;     // waves along the query side
+    static constexpr int kLoads = 40 / NW;         // 1 KiB direct-to-LDS loads per wave and slab
+};
+
+// One wave per SIMD: hipcc selects the AGPR form for EVERY MFMA of a kernel that may use more than 256 registers, so 24 accumulator
+// tiles (384 registers) spill.  The tiles are therefore split by hand: row blocks 0..3 (16 tiles) accumulate in AGPRs, row blocks
+// 4..5 (8 tiles) in VGPRs, through inline asm (same-accumulator MFMAs are 24 issues apart; hardware interlocks the rest).
+template <bool AGPR>
+__device__ __forceinline__ void mfma_asm(f32x16& acc, const bf16x8_t& a, const bf16x8_t& b) {
+    if (AGPR)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    else
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
+template <int NW, int FEED>
+__global__ __launch_bounds__(NW * 64, NW / 4) void ceiling_kernel(const char* __restrict__ src, int64_t src_region, int nslab,
+                                                                  float* __restrict__ sink, uint64_t* __restrict__ ticks) {
+    using G = Geo<NW>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    RingCtx c;
+    ring_ctx_init(c);
+    const int wm = c.wave / G::WN, wn = c.wave % G::WN;
+    const int xcd = blockIdx.x & 7;
+    // every workgroup of an XCD streams the same window (one L2 miss per XCD and slab, like 8 query panels sharing a row tile)
+    const char* base = src + (int64_t)xcd * src_region;
+    __amdgpu_buffer_rsrc_t rs = ring_make_rsrc_n(base, src_region);
+    const int vo = c.lane * 16;
+    int issued = 0, so = 0;
+    const int so_end = (int)src_region - kStage;
+    auto issue = [&]() {
+        char* st = smem + (issued & 3) * kStage;
+#pragma unroll
+        for (int j = 0; j < G::kLoads; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (rg_lptr_t)(st + (j * NW + c.wave) * 1024), 16, vo,
+                                                     so + (j * NW + c.wave) * 1024, 0, 0);
+        ++issued;
+        so += kStage;
+        if (so >= so_end) so = 0;
+    };
+    // the same slab issued piece by piece (FEED 5: one piece every few MFMAs instead of a burst after the k-step)
+    auto issue_piece = [&](const int j) {
+        char* st = smem + (issued & 3) * kStage;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (rg_lptr_t)(st + (j * NW + c.wave) * 1024), 16, vo,
+                                                 so + (j * NW + c.wave) * 1024, 0, 0);
+        if (j == G::kLoads - 1) {
+            ++issued;
+            so += kStage;
+            if (so >= so_end) so = 0;
+        }
+    };
+    issue();
+    issue();
+    issue();
+    issue();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    f32x16 acc[6][G::NR];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < G::NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // fragments as in score_filter_r6: the B set is double-buffered, every A fragment register is reloaded in place with the
+    // next k-step's data right after the MFMAs that consume it
+    bf16x8_t a[6], b[2][G::NR];
+    {
+        const char* a_w = smem + wm * (32 * 6 * 64) + c.frag_off0;
+        const char* b_w = smem + kAOp + wn * (32 * G::NR * 64) + c.frag_off0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a[i] = *(const bf16x8_t*)(a_w + i * 2048);
+#pragma unroll
+        for (int j = 0; j < G::NR; ++j) b[0][j] = b[1][j] = *(const bf16x8_t*)(b_w + j * 2048);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" ::: "memory");
+    const uint64_t t0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+
+    // one k-step: MFMAs on (a, b[cur]) while a is reloaded from (nstage, noff) and b[cur ^ 1] is fetched
+    auto step = [&](const int cur, const char* nstage, const int noff) {
+        constexpr bool kDS = FEED != 0;
+        const char* a_w = nstage + wm * (32 * 6 * 64) + noff;
+        const char* b_w = nstage + kAOp + wn * (32 * G::NR * 64) + noff;
+        if (kDS) {
+#pragma unroll
+            for (int j = 0; j < G::NR; ++j) b[cur ^ 1][j] = *(const bf16x8_t*)(b_w + j * 2048);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int j = 0; j < G::NR; ++j) {
+                if (NW == 8)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[cur][j], acc[i][j], 0, 0, 0);
+                else if (i < 4)
+                    mfma_asm<true>(acc[i][j], a[i], b[cur][j]);
+                else
+                    mfma_asm<false>(acc[i][j], a[i], b[cur][j]);
+            }
+            if (kDS) a[i] = *(const bf16x8_t*)(a_w + i * 2048);
+            if (FEED == 5) {
+                // W2: 5 pieces per wave and slab: k-step 1 issues pieces 0,1,2 after row blocks 1,3,5; k-step 0 pieces 3,4 after 1,3
+                // W1: 10 pieces: k-step 1 issues 0..5 (one per row block), k-step 0 issues 6..9 after row blocks 1..4
+                if (NW == 8) {
+                    if (cur == 1 && (i & 1)) issue_piece(i >> 1);
+                    if (cur == 0 && (i == 1 || i == 3)) issue_piece(3 + (i >> 1));
+                } else {
+                    if (cur == 1) issue_piece(i);
+                    if (cur == 0 && i >= 1 && i <= 4) issue_piece(5 + i);
+                }
+            }
+        }
+    };
+
+#pragma unroll 1
+    for (int s = 0; s < nslab; ++s) {
+        const char* st0 = smem + (s & 3) * kStage;
+        const char* st1 = smem + ((s + 1) & 3) * kStage;
+        step(0, st0, c.frag_off0 ^ 32);
+        __builtin_amdgcn_sched_barrier(0);
+        if (FEED == 2 || FEED == 3 || FEED == 5) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (FEED != 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::kLoads) : "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        step(1, st1, c.frag_off0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (FEED == 2 || FEED == 4) issue();
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    const uint64_t t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < G::NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+    if (sum == 12345.678f) sink[blockIdx.x * blockDim.x + threadIdx.x] = sum;
+    if (threadIdx.x == 0) {
+        ticks[blockIdx.x * 2] = t1 - t0;
+        ticks[blockIdx.x * 2 + 1] = r1 - r0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int NW, int FEED>
+static void run(const char* name, const char* src, int64_t region, float* sink, uint64_t* ticks, double target_ms) {
+    auto k = ceiling_kernel<NW, FEED>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kStage));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    // MFMAs per slab and CU: both geometries cover a 384 x 256 x 32 slab = 96 tile-MFMAs x 2 k-steps
+    const double flop_per_slab = 2.0 * 384 * 256 * 32 * 256;   // all 256 CUs
+    int nslab = 2000;
+    float ms = 0.f;
+    for (int it = 0; it < 4; ++it) {   // calibrate, then 3 timed launches (the last two reported)
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k, dim3(256), dim3(NW * 64), 4 * kStage, 0, src, region, nslab, sink, ticks);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (it == 0) nslab = (int)(nslab * target_ms / ms);
+        if (it >= 2) {
+            std::vector<uint64_t> h(512);
+            CK(hipMemcpy(h.data(), ticks, 512 * 8, hipMemcpyDeviceToHost));
+            double cyc = 0, real = 0;
+            for (int i = 0; i < 256; ++i) {
+                cyc += (double)h[2 * i];
+                real += (double)h[2 * i + 1];
+            }
+            const double ghz = cyc / real * 0.1;
+            const double tf = flop_per_slab * nslab / (ms * 1e-3) / 1e12;
+            // issue efficiency: MFMAs per SIMD x 32 cycles / shader cycles of the loop
+            const double mf_per_simd = 96.0 * 2 * nslab / 4;
+            const double eff = mf_per_simd * 32.0 / (cyc / 256);
+            printf("%-34s %8.3f ms  %8.1f TFLOP/s  %5.1f %% of 2500  clock %.3f GHz  pipe-issue %.1f %%\n", name, ms, tf,
+                   tf / 25.0, ghz, eff * 100);
+        }
+    }
+    fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+    const double target_ms = argc > 1 ? atof(argv[1]) : 12.0;
+    const int64_t region = 16ll << 20;   // per XCD window of the slab source (8 x 16 MiB: Infinity-Cache resident)
+    std::vector<uint16_t> h((size_t)region * 8 / 2);
+    std::mt19937 rng(1234);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    for (auto& v : h) v = f32_to_bf16_bits(nd(rng));
+    char *src, *zsrc;
+    float* sink;
+    uint64_t* ticks;
+    CK(hipMalloc((void**)&src, region * 8));
+    CK(hipMalloc((void**)&zsrc, region * 8));
+    CK(hipMalloc((void**)&sink, 256 * 512 * 4));
+    CK(hipMalloc((void**)&ticks, 512 * 8));
+    CK(hipMemcpy(src, h.data(), region * 8, hipMemcpyHostToDevice));
+    CK(hipMemset(zsrc, 0, region * 8));
+    for (int rep = 0; rep < 1; ++rep) {
+        printf("---- repetition %d (target %.1f ms per launch) ----\n", rep, target_ms);
+        run<8, 0>("W2 mfma-only            random", src, region, sink, ticks, target_ms);
+        run<8, 0>("W2 mfma-only            zeros", zsrc, region, sink, ticks, target_ms);
+        run<4, 0>("W1 mfma-only            random", src, region, sink, ticks, target_ms);
+        run<4, 0>("W1 mfma-only            zeros", zsrc, region, sink, ticks, target_ms);
+        run<8, 1>("W2 mfma+ds_read         random", src, region, sink, ticks, target_ms);
+        run<4, 1>("W1 mfma+ds_read         random", src, region, sink, ticks, target_ms);
+        run<8, 2>("W2 mfma+ds_read+lds-dma random", src, region, sink, ticks, target_ms);
+        run<4, 2>("W1 mfma+ds_read+lds-dma random", src, region, sink, ticks, target_ms);
+        run<8, 2>("W2 mfma+ds_read+lds-dma zeros", zsrc, region, sink, ticks, target_ms);
+        run<4, 2>("W1 mfma+ds_read+lds-dma zeros", zsrc, region, sink, ticks, target_ms);
+        run<8, 3>("W2 ds_read+barrier, no dma random", src, region, sink, ticks, target_ms);
+        run<4, 3>("W1 ds_read+barrier, no dma random", src, region, sink, ticks, target_ms);
+        run<8, 4>("W2 ds_read+dma, no barrier random", src, region, sink, ticks, target_ms);
+        run<4, 4>("W1 ds_read+dma, no barrier random", src, region, sink, ticks, target_ms);
+        run<8, 5>("W2 full, dma interleaved   random", src, region, sink, ticks, target_ms);
+        run<4, 5>("W1 full, dma interleaved   random", src, region, sink, ticks, target_ms);
+        run<8, 5>("W2 full, dma interleaved   zeros", zsrc, region, sink, ticks, target_ms);
+        run<4, 5>("W1 full, dma interleaved   zeros", zsrc, region, sink, ticks, target_ms);
+    }
+    return 0;
+}
