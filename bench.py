@@ -127,11 +127,9 @@ def main():
         host_l = torch.empty((Q, K), dtype=torch.int64).pin_memory()
 
         def step():
-            s, l = flat.search_tensors(q_mine, K)
-            host_s.copy_(s, non_blocking=True)
-            host_l.copy_(l, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
-            return host_s, host_l
+            # device-resident queries in, top-k on the host out (pinned buffers: the library overlaps the result copies with the
+            # re-score of the next query chunk and returns when everything has landed)
+            return flat.search_into(q_mine, K, host_s, host_l)
     else:
         from lightningdot_amd.sharded import ShardedFlatIndexer
         sh = ShardedFlatIndexer(D)

@@ -75,6 +75,11 @@ struct ldot_index {
     // the sub-pool counters and overflow flags are all-zero between searches (the pool select resets the counters it
     // reads); they are cleared only after a (re)allocation or an aborted / overflowed search
     bool pools_clean = false, flags_clean = false;
+    // overflow summary: w_over_sum = {number of overflowed queries} on the device, mirrored into pinned host memory by one
+    // 4-byte copy per search
+    DevBuf w_over_sum;
+    int32_t* h_over_sum = nullptr;
+    bool overflow_pending = false;   // a fused scan ran and its overflow summary has not been looked at yet
     // a search in two halves (ldot_index_search_begin / _finish): what _finish needs to know
     int64_t pend_nq = 0;
     int pend_k = 0, pend_kp = 0;
@@ -154,6 +159,8 @@ int ldot_index_destroy(ldot_index_t* ix) {
                       &ix->w_outl, &ix->w_tau, &ix->w_pool, &ix->w_pool_cnt, &ix->w_over,
                       &ix->w_part_s, &ix->w_part_l, &ix->w_mrg_s, &ix->w_mrg_l};
     for (DevBuf* b : bufs) b->release();
+    ix->w_over_sum.release();
+    if (ix->h_over_sum) (void)hipHostFree(ix->h_over_sum);
     delete ix;
     return LDOT_OK;
 }
@@ -449,7 +456,7 @@ static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_p
         prof_end(ix, st);
         if (rc) return rc;
         rc = launch_select_pools((const uint4*)ix->w_pool.p, (const int32_t*)ix->w_pool_cnt.p, (int)nsubs, nq,
-                                 (int32_t)ix->ntotal, ls, li, kp, tau, over, st);
+                                 (int32_t)ix->ntotal, ls, li, kp, tau, over, (int32_t*)ix->w_over_sum.p, st);
         if (rc) return rc;
         ix->stats[3] += len * nq;
         r += len;
@@ -458,41 +465,57 @@ static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_p
     return LDOT_OK;
 }
 
-static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStream_t st, bool* overflowed) {
-    *overflowed = false;
+// Enqueues the whole fused scan WITHOUT synchronising: whether a lane-private pool overflowed (adversarial row orders) is
+// summarised in w_over_sum; fused_overflow_check() fetches it (4 bytes into pinned memory) when the caller has to wait anyway.
+static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStream_t st) {
     int rc;
     const size_t over_bytes = (size_t)nq_pad * 4;
     const bool fresh_flags = over_bytes > ix->w_over.bytes;
     if ((rc = ix->w_over.ensure(over_bytes))) return rc;
+    if ((rc = ix->w_over_sum.ensure(16))) return rc;
+    if (!ix->h_over_sum) LDOT_HIP_CHECK(hipHostMalloc((void**)&ix->h_over_sum, 16));
     if (fresh_flags || !ix->flags_clean) LDOT_HIP_CHECK(hipMemsetAsync(ix->w_over.p, 0, ix->w_over.bytes, st));
+    LDOT_HIP_CHECK(hipMemsetAsync(ix->w_over_sum.p, 0, 16, st));
     ix->flags_clean = false;
     for (int64_t q0 = 0; q0 < nq; q0 += kFusedQueryChunk) {
         const int64_t nqc = std::min(kFusedQueryChunk, nq - q0);
         if ((rc = fused_scan_chunk(ix, q0, nqc, round_up(nqc, kBM), kp, st))) return rc;
     }
-    // any query whose lane-private pool overflowed lost candidates: detect (one small D2H) and let the caller redo
-    std::vector<int32_t> over((size_t)nq);
-    LDOT_HIP_CHECK(hipMemcpyAsync(over.data(), ix->w_over.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-    LDOT_HIP_CHECK(hipStreamSynchronize(st));
-    int64_t n_over = 0;
-    for (int32_t v : over) n_over += (v != 0);
-    ix->stats[1] = n_over;
-    *overflowed = n_over > 0;
-    ix->flags_clean = n_over == 0;
+    LDOT_HIP_CHECK(hipMemcpyAsync(ix->h_over_sum, ix->w_over_sum.p, 4, hipMemcpyDeviceToHost, st));
+    ix->overflow_pending = true;
     return LDOT_OK;
 }
 
-int ldot_index_search_begin(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k,
-                            float* tau_out, void* stream) {
+// after a synchronisation point of `st`: did the last fused scan overflow?  (adversarial row order -> the caller redoes the
+// search with the always-correct dense path)
+static bool fused_overflow_check(ldot_index* ix) {
+    if (!ix->overflow_pending) return false;
+    ix->overflow_pending = false;
+    const int64_t n_over = ix->h_over_sum[0];
+    ix->stats[1] = n_over;
+    ix->flags_clean = n_over == 0;
+    return n_over > 0;
+}
+
+static int dense_redo(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStream_t st) {
+    float* tau = (float*)ix->w_tau.p;
+    int rc;
+    if ((rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, tau, nq, nq_pad, st))) return rc;
+    return dense_scan_all(ix, nq, 0, ix->ntotal, kp, tau, true, st);
+}
+
+// defer_check: enqueue a fused scan speculatively and leave the overflow check to the caller's own synchronisation point
+static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k,
+                             float* tau_out, bool defer_check, hipStream_t st) {
     LDOT_REQUIRE(ix != nullptr, LDOT_EINVAL, "index is NULL");
     LDOT_REQUIRE(nq >= 0, LDOT_EINVAL, "negative query count");
     LDOT_REQUIRE(k >= 1 && k <= kMaxK, LDOT_EINVAL, "k must be in [1, %d] (got %d)", kMaxK, k);
     LDOT_REQUIRE(dtype >= 0 && dtype <= 2, LDOT_EINVAL, "bad dtype %d", dtype);
     LDOT_REQUIRE(mem == LDOT_HOST || mem == LDOT_DEVICE, LDOT_EINVAL, "bad memory space");
     ix->pend_nq = 0;
+    ix->overflow_pending = false;
     if (nq == 0) return LDOT_OK;
     LDOT_REQUIRE(queries != nullptr, LDOT_EINVAL, "NULL buffer");
-    hipStream_t st = (hipStream_t)stream;
     for (int i = 0; i < 4; ++i) ix->stats[i] = 0;
     const int kp = candidate_len(ix, k);
     const int64_t nq_pad = round_up(nq, kBM);
@@ -520,18 +543,17 @@ int ldot_index_search_begin(ldot_index_t* ix, const void* queries, int64_t nq, i
     if (ix->ntotal > 0) {
         // AUTO: the fused scan pays off from ~32k rows (tools/auto_threshold.py); very large batches (COCO-5k sized image->text
         // with the reference's un-deduplicated queries) already from 16k rows, where the dense score matrix is the cost
-        bool fused = ix->mode == LDOT_MODE_FUSED ||
-                     (ix->mode == LDOT_MODE_AUTO && (ix->ntotal >= 32768 || (ix->ntotal >= 16384 && nq >= 16384)));
+        const bool fused = ix->mode == LDOT_MODE_FUSED ||
+                           (ix->mode == LDOT_MODE_AUTO && (ix->ntotal >= 32768 || (ix->ntotal >= 16384 && nq >= 16384)));
         if (fused) {
-            bool overflowed = false;
-            if ((rc = fused_scan(ix, nq, nq_pad, kp, st, &overflowed))) return rc;
-            if (overflowed) {   // adversarial row order: redo everything with the always-correct dense path
-                if ((rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, tau, nq, nq_pad, st)))
-                    return rc;
-                fused = false;
+            if ((rc = fused_scan(ix, nq, nq_pad, kp, st))) return rc;
+            if (!defer_check) {
+                LDOT_HIP_CHECK(hipStreamSynchronize(st));
+                if (fused_overflow_check(ix) && (rc = dense_redo(ix, nq, nq_pad, kp, st))) return rc;
             }
+        } else if ((rc = dense_scan_all(ix, nq, 0, ix->ntotal, kp, tau, true, st))) {
+            return rc;
         }
-        if (!fused && (rc = dense_scan_all(ix, nq, 0, ix->ntotal, kp, tau, true, st))) return rc;
     }
     if (tau_out) LDOT_HIP_CHECK(hipMemcpyAsync(tau_out, tau, (size_t)nq * 4, hipMemcpyDeviceToDevice, st));
     if (mem == LDOT_HOST) LDOT_HIP_CHECK(hipStreamSynchronize(st));   // the staging buffer is reused by the next call
@@ -541,44 +563,82 @@ int ldot_index_search_begin(ldot_index_t* ix, const void* queries, int64_t nq, i
     return LDOT_OK;
 }
 
-int ldot_index_search_finish(ldot_index_t* ix, const float* floor, float* out_scores, int64_t* out_labels, int out_mem,
-                             void* stream) {
+int ldot_index_search_begin(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k,
+                            float* tau_out, void* stream) {
+    return search_begin_impl(ix, queries, nq, dtype, mem, normalize, k, tau_out, false, (hipStream_t)stream);
+}
+
+// re-score + output
+static int search_finish_impl(ldot_index_t* ix, const float* floor, float* out_scores, int64_t* out_labels, int out_mem,
+                              bool keep_pending, hipStream_t st) {
     LDOT_REQUIRE(ix != nullptr, LDOT_EINVAL, "index is NULL");
     LDOT_REQUIRE(out_mem == LDOT_HOST || out_mem == LDOT_DEVICE, LDOT_EINVAL, "bad memory space");
     const int64_t nq = ix->pend_nq;
     if (nq == 0) return LDOT_OK;
     LDOT_REQUIRE(out_scores && out_labels, LDOT_EINVAL, "NULL buffer");
-    hipStream_t st = (hipStream_t)stream;
     const int k = ix->pend_k, kp = ix->pend_kp;
-    ix->pend_nq = 0;
+    if (!keep_pending) ix->pend_nq = 0;
     int rc;
-    if (out_mem == LDOT_HOST) {
-        if ((rc = ix->w_outs.ensure((size_t)nq * k * 4))) return rc;
-        if ((rc = ix->w_outl.ensure((size_t)nq * k * 8))) return rc;
+    if (out_mem == LDOT_DEVICE) {   // device outputs are written by the re-score kernel directly
+        if ((rc = launch_rescore((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, nq, (const float*)ix->w_ls.p,
+                                 (const int32_t*)ix->w_li.p, kp, k, ix->rescore, floor, out_scores, out_labels, st)))
+            return rc;
+        prof_collect(ix, st);
+        return LDOT_OK;
     }
-    // device outputs are written by the re-score kernel directly; host outputs go through the workspace
-    float* dst_s = out_mem == LDOT_DEVICE ? out_scores : (float*)ix->w_outs.p;
-    int64_t* dst_l = out_mem == LDOT_DEVICE ? out_labels : (int64_t*)ix->w_outl.p;
-    if ((rc = launch_rescore((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, nq,
-                             (const float*)ix->w_ls.p, (const int32_t*)ix->w_li.p, kp, k, ix->rescore, floor, dst_s, dst_l,
-                             st)))
-        return rc;
-    if (out_mem == LDOT_HOST) {
-        LDOT_HIP_CHECK(hipMemcpyAsync(out_scores, dst_s, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
-        LDOT_HIP_CHECK(hipMemcpyAsync(out_labels, dst_l, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
+    // Pinned (device-mapped) host buffers: the re-score kernel stores its results straight into host memory — the 12 MB of a
+    // 10k x top-100 result set leave over PCIe while the kernel is still gathering rows, no staging buffer, no copy kernels.
+    void *ms = nullptr, *ml = nullptr;
+    const bool mapped = hipHostGetDevicePointer(&ms, out_scores, 0) == hipSuccess && ms != nullptr &&
+                        hipHostGetDevicePointer(&ml, out_labels, 0) == hipSuccess && ml != nullptr;
+    (void)hipGetLastError();   // (a pageable buffer makes the query fail: not an error of this call)
+    if (mapped) {
+        if ((rc = launch_rescore((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, nq, (const float*)ix->w_ls.p,
+                                 (const int32_t*)ix->w_li.p, kp, k, ix->rescore, floor, (float*)ms, (int64_t*)ml, st)))
+            return rc;
         LDOT_HIP_CHECK(hipStreamSynchronize(st));
+        prof_collect(ix, st);
+        return LDOT_OK;
     }
+    // pageable host buffers: device workspace + two copies (hipMemcpyAsync stages them through the runtime's pinned buffers)
+    if ((rc = ix->w_outs.ensure((size_t)nq * k * 4))) return rc;
+    if ((rc = ix->w_outl.ensure((size_t)nq * k * 8))) return rc;
+    if ((rc = launch_rescore((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, nq, (const float*)ix->w_ls.p,
+                             (const int32_t*)ix->w_li.p, kp, k, ix->rescore, floor, (float*)ix->w_outs.p,
+                             (int64_t*)ix->w_outl.p, st)))
+        return rc;
+    LDOT_HIP_CHECK(hipMemcpyAsync(out_scores, ix->w_outs.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
+    LDOT_HIP_CHECK(hipMemcpyAsync(out_labels, ix->w_outl.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
+    LDOT_HIP_CHECK(hipStreamSynchronize(st));
     prof_collect(ix, st);
     return LDOT_OK;
+}
+
+int ldot_index_search_finish(ldot_index_t* ix, const float* floor, float* out_scores, int64_t* out_labels, int out_mem,
+                             void* stream) {
+    return search_finish_impl(ix, floor, out_scores, out_labels, out_mem, false, (hipStream_t)stream);
 }
 
 int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k,
                       float* out_scores, int64_t* out_labels, int out_mem, void* stream) {
     LDOT_REQUIRE(out_mem == LDOT_HOST || out_mem == LDOT_DEVICE, LDOT_EINVAL, "bad memory space");
     if (nq > 0) LDOT_REQUIRE(out_scores && out_labels, LDOT_EINVAL, "NULL buffer");
-    int rc = ldot_index_search_begin(ix, queries, nq, dtype, mem, normalize, k, nullptr, stream);
+    hipStream_t st = (hipStream_t)stream;
+    // the fused scan is enqueued speculatively and the re-score behind it: ONE synchronisation per search (host outputs need it
+    // anyway; device outputs pay a 4-byte round trip) instead of one in the middle that drains the stream before the re-score
+    int rc = search_begin_impl(ix, queries, nq, dtype, mem, normalize, k, nullptr, true, st);
     if (rc) return rc;
-    return ldot_index_search_finish(ix, nullptr, out_scores, out_labels, out_mem, stream);
+    if (ix->pend_nq == 0) return LDOT_OK;
+    const bool check = ix->overflow_pending;
+    if ((rc = search_finish_impl(ix, nullptr, out_scores, out_labels, out_mem, check, st))) return rc;
+    if (!check) return LDOT_OK;
+    if (out_mem == LDOT_DEVICE) LDOT_HIP_CHECK(hipStreamSynchronize(st));
+    if (fused_overflow_check(ix)) {   // adversarial row order: redo everything with the always-correct dense path
+        if ((rc = dense_redo(ix, nq, round_up(nq, kBM), ix->pend_kp, st))) return rc;
+        return search_finish_impl(ix, nullptr, out_scores, out_labels, out_mem, false, st);
+    }
+    ix->pend_nq = 0;
+    return LDOT_OK;
 }
 
 int ldot_index_last_profile(const ldot_index_t* ix, double out[4]) {

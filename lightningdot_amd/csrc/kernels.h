@@ -51,9 +51,10 @@ int launch_lists_to_parts(const float* list_s, const int32_t* list_i, int64_t n,
                           hipStream_t st);
 int launch_parts_to_lists(const float* out_s, const int64_t* out_l, int64_t n, float* list_s, int32_t* list_i, int kp,
                           float* tau, hipStream_t st);
-// row_end: records may carry rows of the zero padding behind the last index row (>= row_end): dropped here
+// row_end: records may carry rows of the zero padding behind the last index row (>= row_end): dropped here.
+// overflow_flags[q] is set (and *over_sum incremented once per query) when one of q's sub-pools held more than kPoolCap records.
 int launch_select_pools(const uint4* pool, const int32_t* pool_cnt, int nsubs, int64_t nq, int32_t row_end, float* list_s,
-                        int32_t* list_i, int kp, float* tau, int32_t* overflow_flags, hipStream_t st);
+                        int32_t* list_i, int kp, float* tau, int32_t* overflow_flags, int32_t* over_sum, hipStream_t st);
 // generic merge of explicit candidate lists: cand_[sl] is [nq][ncand] (labels int64, -1 = empty) -> [nq][k_out]
 int launch_select_lists(const float* cand_s, const int64_t* cand_l, int64_t part_stride, int nparts, int k_in,
                         int64_t nq, int k_out, float* out_s, int64_t* out_l, hipStream_t st);

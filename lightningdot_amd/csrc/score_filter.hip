@@ -383,6 +383,7 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     if (variant == 48) rk = score_filter_r6_kernel<48>;
     if (variant == 80) rk = score_filter_r6_kernel<80>;
     if (variant == 8) rk = score_filter_r6_kernel<8>;
+    if (variant == 64) rk = score_filter_r6_kernel<64>;
     if (variant == 256) rk = score_filter_r6_kernel<256>;
     if (variant == 128) rk = score_filter_r6_kernel<128>;
     if (variant == 144) rk = score_filter_r6_kernel<144>;

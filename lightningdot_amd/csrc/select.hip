@@ -464,7 +464,8 @@ __global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(con
                                                                        int32_t row_end, float* __restrict__ list_s,
                                                                        int32_t* __restrict__ list_i, int kp, int cap,
                                                                        float* __restrict__ tau,
-                                                                       int32_t* __restrict__ overflow, int dbg) {
+                                                                       int32_t* __restrict__ overflow,
+                                                                       int32_t* __restrict__ over_sum, int dbg) {
     extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
     // QPW independent waves per workgroup, one query each (no workgroup-level synchronisation anywhere): the grid of
     // one-wave workgroups was bound by the workgroup dispatch rate, not by the work
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(con
     const bool any_over = __any(over);
     if (dbg & 2) return;
     sel.finish(ls, li, tau ? tau + q : nullptr);
-    if (lane == 0 && any_over) overflow[q] = 1;
+    if (lane == 0 && any_over && atomicExch(&overflow[q], 1) == 0) atomicAdd(over_sum, 1);   // queries counted once
 }
 
 // Few queries (<= one query block, the serving shape): one 256-thread workgroup per query instead of one wave, so that
@@ -534,7 +535,8 @@ __global__ __launch_bounds__(kSelThreads) void select_pools_block_kernel(const u
                                                                          int32_t row_end, float* __restrict__ list_s,
                                                                          int32_t* __restrict__ list_i, int kp, int cap,
                                                                          float* __restrict__ tau,
-                                                                         int32_t* __restrict__ overflow) {
+                                                                         int32_t* __restrict__ overflow,
+                                                                         int32_t* __restrict__ over_sum) {
     extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
     __shared__ int count;
     const int64_t q = blockIdx.x;
@@ -597,7 +599,7 @@ __global__ __launch_bounds__(kSelThreads) void select_pools_block_kernel(const u
         }
     }
     sel.finish(ls, li, tau ? tau + q : nullptr);
-    if (__syncthreads_or(over) && threadIdx.x == 0) overflow[q] = 1;
+    if (__syncthreads_or(over) && threadIdx.x == 0 && atomicExch(&overflow[q], 1) == 0) atomicAdd(over_sum, 1);
 }
 
 // explicit lists source (sharded merge): parts laid out [nparts][nq][k_in], int64 labels (< 2^32-1), -1 = empty
@@ -697,12 +699,12 @@ int launch_parts_to_lists(const float* out_s, const int64_t* out_l, int64_t n, f
 }
 
 int launch_select_pools(const uint4* pool, const int32_t* pool_cnt, int nsubs, int64_t nq, int32_t row_end, float* list_s,
-                        int32_t* list_i, int kp, float* tau, int32_t* overflow_flags, hipStream_t st) {
+                        int32_t* list_i, int kp, float* tau, int32_t* overflow_flags, int32_t* over_sum, hipStream_t st) {
     if (nq <= 0) return LDOT_OK;
     if (nq <= 256) {   // few queries: block-per-query walk
         const int bcap = select_cap(kp, 2048, 4 * kSelThreads);   // a step appends up to 4 x 256 candidates on top of a full list
         hipLaunchKernelGGL(select_pools_block_kernel, dim3((unsigned)nq), dim3(kSelThreads), (size_t)bcap * 8, st, pool,
-                           (int32_t*)pool_cnt, nsubs, row_end, list_s, list_i, kp, bcap, tau, overflow_flags);
+                           (int32_t*)pool_cnt, nsubs, row_end, list_s, list_i, kp, bcap, tau, overflow_flags, over_sum);
         LDOT_HIP_CHECK(hipGetLastError());
         return LDOT_OK;
     }
@@ -716,10 +718,10 @@ int launch_select_pools(const uint4* pool, const int32_t* pool_cnt, int nsubs, i
         constexpr int QPW = 4;
         hipLaunchKernelGGL((select_pools_kernel<4, QPW>), dim3((unsigned)((nq + QPW - 1) / QPW)),
                            dim3(kPoolSelThreads * QPW), (size_t)cap * 8 * QPW, st, pool, (int32_t*)pool_cnt, nsubs, nq,
-                           row_end, list_s, list_i, kp, cap, tau, overflow_flags, dbg);
+                           row_end, list_s, list_i, kp, cap, tau, overflow_flags, over_sum, dbg);
     } else {   // kp > 512: LDS sort path, one wave per workgroup
         hipLaunchKernelGGL((select_pools_kernel<4, 1>), dim3((unsigned)nq), dim3(kPoolSelThreads), (size_t)cap * 8, st,
-                           pool, (int32_t*)pool_cnt, nsubs, nq, row_end, list_s, list_i, kp, cap, tau, overflow_flags, dbg);
+                           pool, (int32_t*)pool_cnt, nsubs, nq, row_end, list_s, list_i, kp, cap, tau, overflow_flags, over_sum, dbg);
     }
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;

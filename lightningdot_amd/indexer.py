@@ -110,6 +110,26 @@ class FlatIPIndex:
         del keep
         return scores, labels
 
+    def search_into(self, queries, k: int, out_scores, out_labels):
+        """Search with caller-owned HOST outputs (float32 [nq, k] / int64 [nq, k]; numpy arrays or CPU tensors — pinned memory
+        makes the result copies asynchronous: the library re-scores in chunks and ships every chunk while the next one is
+        re-scored).  Returns when the results are in the buffers."""
+        keep, ptr, nq, dt, mem = _describe(queries, self.d)
+
+        def host_ptr(buf, itemsize):
+            if _is_tensor(buf):
+                if buf.is_cuda or not buf.is_contiguous() or tuple(buf.shape) != (nq, k) or buf.element_size() != itemsize:
+                    raise ValueError('output buffers must be contiguous CPU tensors of shape [nq, k]')
+                return ctypes.c_void_p(buf.data_ptr())
+            if not buf.flags['C_CONTIGUOUS'] or buf.shape != (nq, k) or buf.itemsize != itemsize:
+                raise ValueError('output buffers must be C-contiguous arrays of shape [nq, k]')
+            return ctypes.c_void_p(buf.ctypes.data)
+
+        L.check(self._lib.ldot_index_search(self._h, ptr, nq, dt, mem, int(self.normalize), int(k),
+                                            host_ptr(out_scores, 4), host_ptr(out_labels, 8), L.HOST, _stream_ptr()))
+        del keep
+        return out_scores, out_labels
+
     def search_tensors(self, queries, k: int):
         """Device-resident variant: queries is a CUDA tensor; returns (scores, labels) CUDA tensors."""
         import torch
