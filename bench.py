@@ -68,6 +68,16 @@ def main():
                     help='second series (SURVEY 8d): rows and queries scaled to unit L2 norm (cosine scores)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher — one rank per GPU under torch.distributed.run
+        import socket
+        sock = socket.socket()
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+                                  f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1', '--master-port', str(port),
+                                  os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -169,10 +179,14 @@ def main():
             prof[k_] += p[k_]
     barrier()
     dt = time.perf_counter() - t0
+    ranks_seen = 1
     if sharded:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        ones = torch.ones(1, device=dev, dtype=torch.int32)
+        dist.all_reduce(ones)                      # every rank that took part in the timed collectives counts itself
+        ranks_seen = int(ones.item())
 
     # ---- quality on the last step's results: Recall@1/5/10 against the planted ground truth ----------------
     s_np, l_np = host_s.numpy(), host_l.numpy()
@@ -199,7 +213,8 @@ def main():
     value = Q * args.steps / dt
     ach = (prof['flops'] / (prof['kernel_ms'] * 1e-3) / 1e12) if prof['kernel_ms'] > 0 else 0.0
     out = {
-        'metric': 'queries/sec', 'value': value, 'unit': 'queries/s', 'n_gpus': world, 'steps': args.steps,
+        'metric': 'queries/sec', 'value': value, 'unit': 'queries/s', 'n_gpus': world, 'ranks_seen': ranks_seen,
+        'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
         'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': f'synthetic {N} x {D} bf16 index (fp32 master for exact re-score), {Q} queries, '

@@ -5,13 +5,18 @@ One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Rank 
     1. all-gather of the query embeddings each rank encoded            (10 000 x 768 fp32 ~ 30 MB in total)
     2. local fused candidate pass of ALL queries against the local shard (libldot.so), all-reduce(MAX) of the per-query
        candidate thresholds (Q x 4 B), exact re-score of the local candidates at or above the global threshold
-    3. exchange of the partial top-k lists by query slice               (all-to-all on RCCL; Q x k x 12 B per rank)
+    3. exchange of the partial top-k lists by query slice               (all-to-all; Q x k x 12 B per rank)
     4. merge of the G partial lists of the local query slice           (ldot_merge_topk, HIP)
 so every rank ends with the final global top-k of the queries it contributed.  The scores against disjoint row
 shards are independent, so there is no other data-path collective.
 
+External ids stay on the rank that owns the rows: ``index_local_shard`` exchanges only the shard SIZES (row offsets); ``search_knn``
+resolves the labels of its final results on their owning ranks (two object collectives sized by the result set, not by the index).
+
 ``local_search`` / ``merge`` are injectable for the CPU (gloo) tests of the collective logic; the defaults are the
-HIP implementations and raise without a GPU.
+HIP implementations and raise without a GPU.  ``exchange`` selects the collective of step 3: 'all_to_all' (default: every
+rank receives only the partial lists of ITS queries) or 'all_gather' (every rank receives everything; for backends without
+all-to-all).
 """
 import ctypes
 from typing import Callable, List, Optional, Tuple
@@ -39,39 +44,79 @@ def _hip_merge(scores: torch.Tensor, labels: torch.Tensor, k: int):
 
 class ShardedFlatIndexer:
     def __init__(self, vector_sz: int, group=None, local_search: Optional[Callable] = None,
-                 merge: Optional[Callable] = None, normalize: bool = False):
+                 merge: Optional[Callable] = None, normalize: bool = False, exchange: str = 'all_to_all'):
+        if exchange not in ('all_to_all', 'all_gather'):
+            raise ValueError("exchange must be 'all_to_all' or 'all_gather'")
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.d = vector_sz
+        self.exchange = exchange
         self._custom = local_search is not None
         self.local = None if self._custom else DenseFlatIndexer(vector_sz, normalize=normalize)
         self._local_search = local_search
         self._merge = merge or _hip_merge
         self.n_local = 0
         self.offsets: List[int] = [0] * (self.world + 1)
-        self.index_id_to_db_id: list = []        # GLOBAL id list (gathered), row label -> external id
+        self.local_ids: list = []                # external ids of THIS rank's rows (local row -> id), extended by every call
+        self.index_id_to_db_id: list = []        # GLOBAL id list, only filled by index_local_shard(..., gather_ids=True)
+
+    def _tensor_device(self):
+        return torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(self.group) == 'nccl' else torch.device('cpu')
 
     # ---- build -------------------------------------------------------------------------------------------
-    def index_local_shard(self, db_ids: list, vectors, n_rows: Optional[int] = None):
-        """Add this rank's rows, then agree on the global row offsets (exclusive scan of shard sizes) and gather
-        the external id lists so that any rank can map a global label."""
+    def index_local_shard(self, db_ids: list, vectors, n_rows: Optional[int] = None, gather_ids: bool = False):
+        """Add rows to this rank's shard (may be called repeatedly), then agree on the global row offsets: an all-gather of the
+        shard sizes (one int64 per rank).  The external ids stay local; ``gather_ids=True`` additionally replicates the full
+        id list on every rank (index_id_to_db_id, the reference's attribute) — O(N) pickled objects per call, meant for small
+        indexes only."""
         n = len(db_ids) if n_rows is None else n_rows
         if self.local is not None:
             self.local.index_tensor(db_ids, vectors)
         self.n_local += n
-        sizes = [None] * self.world
-        dist.all_gather_object(sizes, self.n_local, group=self.group)
+        self.local_ids.extend(db_ids)
+        dev = self._tensor_device()
+        mine = torch.tensor([self.n_local], dtype=torch.int64, device=dev)
+        sizes = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(sizes, mine, group=self.group)
         self.offsets = [0]
-        for s in sizes:
-            self.offsets.append(self.offsets[-1] + int(s))
-        all_ids = [None] * self.world
-        dist.all_gather_object(all_ids, list(db_ids), group=self.group)
-        self.index_id_to_db_id = [i for part in all_ids for i in part]
+        for t in sizes:
+            self.offsets.append(self.offsets[-1] + int(t.item()))
+        if gather_ids:
+            all_ids = [None] * self.world
+            dist.all_gather_object(all_ids, self.local_ids, group=self.group)   # the WHOLE local list: earlier calls included
+            self.index_id_to_db_id = [i for part in all_ids for i in part]
 
     @property
     def ntotal(self) -> int:
         return self.offsets[-1]
+
+    def resolve_ids(self, labels) -> list:
+        """Global row labels (nested lists / array, -1 = padding) -> external ids, resolved on the ranks that own the rows.
+        Collective: every rank must call it (with its own, possibly empty, labels)."""
+        import bisect
+        rows = [list(map(int, r)) for r in labels]
+        if self.index_id_to_db_id:
+            ids = self.index_id_to_db_id
+            return [[ids[i] for i in r] for r in rows]      # (label -1 -> last id: the reference's behaviour, faiss_indexers.py:85)
+        last_owner = max(r for r in range(self.world) if self.offsets[r + 1] > self.offsets[r]) if self.ntotal else 0
+        want = [set() for _ in range(self.world)]
+        for r in rows:
+            for g in r:
+                if g < 0:
+                    want[last_owner].add(self.ntotal - 1)
+                else:
+                    want[bisect.bisect_right(self.offsets, g) - 1].add(g)
+        req = [None] * self.world
+        dist.all_gather_object(req, [sorted(w) for w in want], group=self.group)
+        lo = self.offsets[self.rank]
+        answer = {g: self.local_ids[g - lo] for peer in req for g in peer[self.rank]}
+        ans = [None] * self.world
+        dist.all_gather_object(ans, answer, group=self.group)
+        table = {}
+        for a in ans:
+            table.update(a)
+        return [[table[g if g >= 0 else self.ntotal - 1] for g in r] for r in rows]
 
     # ---- search ------------------------------------------------------------------------------------------
     def _gather_queries(self, q: torch.Tensor) -> Tuple[torch.Tensor, List[int]]:
@@ -98,6 +143,18 @@ class ShardedFlatIndexer:
         dist.all_gather(bufs, pad.contiguous(), group=self.group)
         return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0), counts
 
+    def _all_to_all(self, send: torch.Tensor) -> torch.Tensor:
+        """send[r] goes to rank r; returns recv with recv[r] = what rank r sent here.  RCCL moves device tensors over xGMI; a
+        backend without device all-to-all (gloo, the one-GPU test rig) exchanges host copies."""
+        if send.is_cuda and dist.get_backend(self.group) != 'nccl':
+            h = send.cpu()
+            r = torch.empty_like(h)
+            dist.all_to_all_single(r, h, group=self.group)
+            return r.to(send.device)
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)
+        return recv
+
     def search(self, local_queries: torch.Tensor, k: int):
         """-> (scores [nq_local, k] fp32, GLOBAL row labels [nq_local, k] int64) for the local queries."""
         q_all, counts = self._gather_queries(local_queries.float())
@@ -117,8 +174,7 @@ class ShardedFlatIndexer:
             starts.append(starts[-1] + c)
         mine = slice(starts[self.rank], starts[self.rank + 1])
         nq_mine = counts[self.rank]
-        backend = dist.get_backend(self.group)
-        if backend == 'nccl':
+        if self.exchange == 'all_to_all':
             # all-to-all by query slice: rank r receives, from every rank, the partial lists of ITS queries
             mx = max(counts)
             if min(counts) == mx:                    # equal query slices: the send buffers are plain views
@@ -129,9 +185,7 @@ class ShardedFlatIndexer:
                 for r in range(self.world):
                     send_s[r, :counts[r]] = s[starts[r]:starts[r + 1]]
                     send_l[r, :counts[r]] = l[starts[r]:starts[r + 1]]
-            recv_s, recv_l = torch.empty_like(send_s), torch.empty_like(send_l)
-            dist.all_to_all_single(recv_s, send_s.contiguous(), group=self.group)
-            dist.all_to_all_single(recv_l, send_l.contiguous(), group=self.group)
+            recv_s, recv_l = self._all_to_all(send_s.contiguous()), self._all_to_all(send_l.contiguous())
             part_s, part_l = recv_s[:, :nq_mine], recv_l[:, :nq_mine]
         else:
             gs = [torch.empty_like(s) for _ in range(self.world)]
@@ -148,5 +202,5 @@ class ShardedFlatIndexer:
         """DenseIndexer-style result for the local queries: [(ids, scores ndarray)]."""
         s, l = self.search(local_queries, top_docs)
         s, l = s.cpu().numpy(), l.cpu().tolist()
-        ids = self.index_id_to_db_id
-        return [([ids[i] for i in row], s[j]) for j, row in enumerate(l)]
+        ids = self.resolve_ids(l)
+        return [(ids[j], s[j]) for j in range(len(l))]
