@@ -255,48 +255,72 @@ def main():
     if not args.no_cpu_baseline and not sharded:
         out['cpu_baseline'], out['parity_vs_cpu_fp32'] = cpu_baseline(x_local, q_all, K, args.cpu_sample_queries,
                                                                       s_np, l_np)
+        out['cpu_baseline_s2'] = cpu_baseline_s2(K)
     print(json.dumps(out), flush=True)
     if sharded:
         dist.destroy_process_group()
 
 
 def cpu_baseline(x_dev, q_dev, k, nsample, gpu_scores, gpu_labels):
-    """The reference's CPU scorer is faiss IndexFlatIP (fp32 sgemm + heap); faiss is not installable here, so the
-    timed leg is the oracle's restatement of the same structure (oracle.search_fast: blocked fp32 sgemm +
-    selection) on a bounded sample: the first `nsample` queries against the FULL index, all host cores, plus a
-    one-thread figure on a smaller sample.  The same sample is the parity check of the GPU results (SURVEY 8d:
-    rank-1 mismatches and max |delta score| against the fp32 CPU path)."""
-    from oracle import oracle_np as O      # checker / baseline only — never on the product path
-    from threadpoolctl import threadpool_info, threadpool_limits
-    cores = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
-    x = x_dev.cpu().numpy()
-    q = q_dev[:nsample].cpu().numpy()
-    O.search_fast(q[:8], x[:4096], k)                      # warm the BLAS threads
-    runs = []
-    for _ in range(3):                                     # median of 3 (about 20 s of CPU work in all)
-        t0 = time.perf_counter()
-        cs, cl = O.search_fast(q, x, k)
-        runs.append(time.perf_counter() - t0)
-    dt = sorted(runs)[1]
-    n1 = min(32, len(q))
-    with threadpool_limits(limits=1):
-        t1 = time.perf_counter()
-        O.search_fast(q[:n1], x, k)
-        dt1 = time.perf_counter() - t1
-    base = {'value': len(q) / dt, 'unit': 'queries/s', 'cores': int(cores), 'kind': 'port',
-            'sample': f'first {len(q)} queries x full {x.shape[0]} x {x.shape[1]} fp32 index, top-{k}, '
-                      f'oracle.search_fast (blocked numpy sgemm + argpartition), median of 3 runs after warm-up, {dt:.2f} s',
-            'value_1thread': n1 / dt1, 'sample_1thread': f'first {n1} queries, 1 BLAS thread, {dt1:.2f} s'}
-    gs, gl = gpu_scores[:len(q)], gpu_labels[:len(q)]
+    """The reference's CPU scorer is faiss IndexFlatIP (fp32 sgemm + per-query selection on the host cores).  faiss is used when it
+    is importable on the box; otherwise the stand-in SURVEY 8d prescribes (oracle.oracle_torch.search_blocked: torch.matmul over
+    4096-query x 131072-row tiles + torch.topk(sorted), torch.set_num_threads(all cores)).  Bounded sample: the first `nsample`
+    queries against the FULL index, median of 5 runs after a warm-up, all cores; plus a one-thread figure on 32 queries.  The same
+    sample is the parity check of the GPU results (rank-1 mismatches and max |delta score| against the fp32 CPU path)."""
+    from oracle import oracle_torch as OT      # checker / baseline only — never on the product path
+    cores = os.cpu_count() or 1
+    x = x_dev.cpu()
+    q = q_dev[:nsample].cpu()
+    scorer = 'oracle_torch.search_blocked (torch.matmul 4096 x 131072 tiles + torch.topk, fp32)'
+    if OT.have_faiss():
+        import faiss
+        faiss.omp_set_num_threads(cores)
+        xn, qn = x.numpy(), q.numpy()
+        OT.faiss_search(qn[:8], xn[:4096], k)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            cs, cl = OT.faiss_search(qn, xn, k)
+            ts.append(time.perf_counter() - t0)
+        dt, scorer = sorted(ts)[2], 'faiss.IndexFlatIP (the reference scorer)'
+    else:
+        dt, cs, cl = OT.timed(q, x, k, cores, runs=5)
+        cs, cl = cs.numpy(), cl.numpy()
+    n1 = min(32, q.shape[0])
+    dt1, _, _ = OT.timed(q[:n1], x, k, 1, runs=3)
+    base = {'value': q.shape[0] / dt, 'unit': 'queries/s', 'cores': int(cores), 'kind': 'port',
+            'sample': f'first {q.shape[0]} queries x full {x.shape[0]} x {x.shape[1]} fp32 index, top-{k}, {scorer}, '
+                      f'{cores} threads, median of 5 runs after warm-up, {dt:.2f} s per run',
+            'value_1thread': n1 / dt1, 'sample_1thread': f'first {n1} queries, 1 thread, median of 3 runs, {dt1:.2f} s per run'}
+    gs, gl = gpu_scores[:q.shape[0]], gpu_labels[:q.shape[0]]
     scale = float(np.abs(cs).max()) or 1.0
     # positions where the label differs but the two fp32 scores agree to 1e-4 relative are summation-order ties
     diff = gl != cl
     tie = np.abs(gs.astype(np.float64) - cs.astype(np.float64)) <= 1e-4 * scale
-    parity = {'queries': int(len(q)), 'rank1_mismatches': int((gl[:, 0] != cl[:, 0]).sum()),
+    parity = {'queries': int(q.shape[0]), 'rank1_mismatches': int((gl[:, 0] != cl[:, 0]).sum()),
               'topk_label_mismatches': int(diff.sum()), 'topk_label_mismatches_not_ties': int((diff & ~tie).sum()),
               'max_abs_dscore': float(np.abs(gs.astype(np.float64) - cs.astype(np.float64)).max()),
               'score_scale': scale, 'tolerance': '1e-3 on scores, exact rank-1 (BASELINE.json north_star)'}
     return base, parity
+
+
+def cpu_baseline_s2(k):
+    """CPU figures at the S2 shapes (Flickr-1k and COCO-5k stand-ins, both directions with the reference's
+    un-deduplicated image queries), same scorer and protocol as cpu_baseline; a few seconds of CPU work in all."""
+    from oracle import oracle_torch as OT
+    from lightningdot_amd.synthetic import s2_embeddings
+    cores = os.cpu_count() or 1
+    out = {'unit': 'queries/s', 'cores': int(cores), 'kind': 'port',
+           'scorer': 'faiss.IndexFlatIP' if OT.have_faiss() else 'oracle_torch.search_blocked', 'runs': 5, 'shapes': {}}
+    for name, n_img in (('flickr', 1000), ('coco', 5000)):
+        img, txt = s2_embeddings(n_img, 768, seed=7)
+        img_q = img.repeat_interleave(5, 0)                     # the reference queries once per caption (dvl/trainer.py:130-154)
+        for direction, qq, xx in (('t2i', txt, img), ('i2t', img_q, txt)):
+            dt, _, _ = OT.timed(qq, xx, k, cores, runs=5)
+            dt1, _, _ = OT.timed(qq[:256], xx, k, 1, runs=3)
+            out['shapes'][f'{name}_{direction}'] = {'queries': int(qq.shape[0]), 'rows': int(xx.shape[0]),
+                                                    'value': qq.shape[0] / dt, 'value_1thread': 256 / dt1}
+    return out
 
 
 if __name__ == '__main__':

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDOT_ABI_VERSION 1
+#define LDOT_ABI_VERSION 2
 
 /* status codes */
 #define LDOT_OK 0
@@ -52,7 +52,7 @@ extern "C" {
 
 /* search-mode flags (ldot_index_set_option(LDOT_OPT_MODE, ...)) */
 #define LDOT_MODE_AUTO 0   /* dense below 32768 rows, fused filter above */
-#define LDOT_MODE_DENSE 1  /* materialise score chunks + radix select */
+#define LDOT_MODE_DENSE 1  /* materialise score chunks + streaming top-k' select */
 #define LDOT_MODE_FUSED 2  /* fused MFMA score + threshold filter (never materialises Q x N) */
 
 #define LDOT_OPT_MODE 1
@@ -66,6 +66,11 @@ extern "C" {
 #define LDOT_OPT_PRECISION 8    /* candidate generation: 0 (default) bf16 operands; 1 split-bf16 operands (x ~ hi + lo, three
                                  * MFMA products per element: ~16 mantissa bits, 3x the MFMA work and 3x the shadow) for
                                  * data whose scores crowd closer than bf16 resolves; reported scores are fp32-exact in both */
+
+#define LDOT_OPT_VERIFY 10      /* 1: after every search flag the queries whose top-k is not PROVEN exact (k-th exact score above the
+                                 * candidate threshold by a bf16 error bound), see ldot_index_last_unproven.  The default bf16
+                                 * candidate pass is exact whenever the true top-k lies inside the bf16 top-k' (k' = k + margin);
+                                 * scores that crowd closer than bf16 resolves need a larger LDOT_OPT_MARGIN or LDOT_OPT_PRECISION 1 */
 
 typedef struct ldot_index ldot_index_t;
 
@@ -94,6 +99,7 @@ int ldot_index_destroy(ldot_index_t* ix);
 int ldot_index_add(ldot_index_t* ix, const void* rows, int64_t n, int dtype, int mem, int normalize, void* stream);
 int64_t ldot_index_ntotal(const ldot_index_t* ix);
 int ldot_index_dim(const ldot_index_t* ix);
+/* reset and the storage-changing options (PRECISION, RESERVE_ROWS) take no stream: they synchronise the device before and after */
 int ldot_index_reset(ldot_index_t* ix);
 int ldot_index_set_option(ldot_index_t* ix, int option, int64_t value);
 /* out_scores: [nq*k] float, out_labels: [nq*k] int64, both in `out_mem` space. */
@@ -114,9 +120,13 @@ int ldot_index_save(ldot_index_t* ix, const char* path);
 int ldot_index_load(const char* path, ldot_index_t** out);
 /* copy rows [row0,row0+n) of the fp32 master copy to a caller buffer (inspection / resharding) */
 int ldot_index_get_rows(ldot_index_t* ix, int64_t row0, int64_t n, float* out, int out_mem, void* stream);
-/* statistics of the last search on this index: [0]=candidates appended by the fused filter, [1]=queries that
- * overflowed their candidate pools and were redone densely, [2]=rows scored densely, [3]=rows scored fused */
+/* statistics of the last search on this index: [0]=candidate records appended by the fused filter (8 scores each), [1]=queries
+ * that overflowed their candidate pools and were redone densely, [2]=(query,row) pairs scored densely, [3]=pairs scored fused */
 int ldot_index_last_stats(const ldot_index_t* ix, int64_t out[4]);
+/* LDOT_OPT_VERIFY = 1: flags_out [nq of the last search] (host, may be NULL) receives 1 for every query whose result is not proven
+ * exact, *count_out their number.  No reference counterpart (faiss IndexFlatIP is fp32 end to end); this is how the bf16 candidate
+ * pass reports that its margin may have been too small for a query. */
+int ldot_index_last_unproven(ldot_index_t* ix, int32_t* flags_out, int64_t* count_out);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Partial top-k merge (sharded retrieval; no reference counterpart — the reference is single

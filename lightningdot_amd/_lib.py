@@ -14,6 +14,9 @@ F32, BF16, F16 = 0, 1, 2
 HOST, DEVICE = 0, 1
 MODE_AUTO, MODE_DENSE, MODE_FUSED = 0, 1, 2
 OPT_MODE, OPT_RESCORE, OPT_CHUNK_ROWS, OPT_MARGIN, OPT_PROFILE, OPT_WARM_ROWS, OPT_GROWTH_PCT, OPT_PRECISION, OPT_RESERVE_ROWS = 1, 2, 3, 4, 5, 6, 7, 8, 9
+OPT_VERIFY = 10
+ABI_VERSION = 2
+MAX_MARGIN = 1024
 PAD_LABEL = -1
 PAD_SCORE = -3.4028234663852886e+38
 MAX_K = 2048
@@ -39,6 +42,7 @@ SYMBOLS = {
     'ldot_index_load': (_i, [_c.c_char_p, _c.POINTER(_vp)]),
     'ldot_index_get_rows': (_i, [_vp, _i64, _i64, _vp, _i, _vp]),
     'ldot_index_last_stats': (_i, [_vp, _c.POINTER(_i64)]),
+    'ldot_index_last_unproven': (_i, [_vp, _vp, _c.POINTER(_i64)]),
     'ldot_index_last_profile': (_i, [_vp, _c.POINTER(_c.c_double)]),
     'ldot_merge_topk': (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _i, _vp]),
     'ldot_cls_pool': (_i, [_vp, _i, _i64, _i64, _i64, _i, _vp, _vp, _vp]),
@@ -79,8 +83,8 @@ def load_library():
             fn = getattr(lib, name)     # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.ldot_abi_version() != 1:
-            raise LdotError(-5, f'ABI version mismatch: library {lib.ldot_abi_version()}, binding 1')
+        if lib.ldot_abi_version() != ABI_VERSION:
+            raise LdotError(-5, f'ABI version mismatch: library {lib.ldot_abi_version()}, binding {ABI_VERSION}')
         _lib = lib
         return lib
 

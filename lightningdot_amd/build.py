@@ -25,10 +25,19 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> str:
+    """ablation=True (or `--ablation`): compile the profiling variants of the kernels and their LDOT_DEBUG_* environment hooks
+    (-DLDOT_ABLATION) — a measurement build; the product library has no such hooks.  The two builds use separate object
+    directories and the ablation build always relinks, so a product build after it restores the product library."""
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     objs = []
-    bdir = os.path.join(PKG, 'build')
+    bdir = os.path.join(PKG, 'build_ablation' if ablation else 'build')
+    flags = FLAGS + (['-DLDOT_ABLATION'] if ablation else [])
+    marker = os.path.join(PKG, 'build', '.ablation_linked')
+    if ablation or os.path.exists(marker):
+        force_link = True
+    else:
+        force_link = False
     os.makedirs(bdir, exist_ok=True)
     procs = []
     for s in SOURCES:
@@ -36,7 +45,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(bdir, s.replace('.hip', '.o'))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+            cmd = [HIPCC] + flags + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -50,11 +59,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
             sys.stderr.write(f'hipcc failed on {s}\n' + (out.decode(errors='replace') if not verbose else ''))
     if failed:
         raise RuntimeError('libldot.so build failed')
-    if force or _stale(LIB, objs):
+    if force or force_link or _stale(LIB, objs):
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
+    os.makedirs(os.path.dirname(marker), exist_ok=True)
+    if ablation:
+        open(marker, 'w').write('libldot.so currently holds the ablation build\n')
+    elif os.path.exists(marker):
+        os.remove(marker)
     # a device-side compile error can leave host stubs without their kernels: refuse a library that does not load.
     # (checked in a child process: loading it here would map the system HIP runtime before torch maps its own)
     subprocess.check_call([sys.executable, '-c',
@@ -63,5 +77,5 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
+    build(force='--force' in sys.argv, ablation='--ablation' in sys.argv)
     print(LIB)

@@ -45,7 +45,20 @@ struct DevBuf {
 
 using namespace ldot;
 
+// every entry point that takes an index runs on the device the index was created on, whatever the caller's current device is
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (dev >= 0 && hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
 struct ldot_index {
+    int device = -1;
     int d = 0, dpad = 0;
     int64_t ntotal = 0, cap_rows = 0;
     float* x32 = nullptr;      // [cap_rows][dpad] fp32 master copy (zero padded)
@@ -80,6 +93,15 @@ struct ldot_index {
     DevBuf w_over_sum;
     int32_t* h_over_sum = nullptr;
     bool overflow_pending = false;   // a fused scan ran and its overflow summary has not been looked at yet
+    // stats[0] (records appended by the fused filter): per-query counts accumulated on the device by the pool selects, summed on
+    // the host only when ldot_index_last_stats is called
+    DevBuf w_qcnt;
+    int64_t qcnt_n = 0;
+    // LDOT_OPT_VERIFY: per-query "not proven exact" flags of the last search (see ldot_index_last_unproven)
+    int verify = 0;
+    DevBuf w_unproven;
+    int64_t unproven_n = 0;
+    DevBuf w_norm;                   // device scalar: largest L2 norm of an indexed row
     // a search in two halves (ldot_index_search_begin / _finish): what _finish needs to know
     int64_t pend_nq = 0;
     int pend_k = 0, pend_kp = 0;
@@ -147,6 +169,7 @@ int ldot_index_create(int d, ldot_index_t** out) {
     LDOT_REQUIRE(ix != nullptr, LDOT_ENOMEM, "out of host memory");
     ix->d = d;
     ix->dpad = (int)round_up(d, kBK);
+    (void)hipGetDevice(&ix->device);
     *out = ix;
     return LDOT_OK;
 }
@@ -158,8 +181,12 @@ int ldot_index_destroy(ldot_index_t* ix) {
     DevBuf* bufs[] = {&ix->w_q16b, &ix->w_stage, &ix->w_q32, &ix->w_ls, &ix->w_li, &ix->w_S, &ix->w_outs,
                       &ix->w_outl, &ix->w_tau, &ix->w_pool, &ix->w_pool_cnt, &ix->w_over,
                       &ix->w_part_s, &ix->w_part_l, &ix->w_mrg_s, &ix->w_mrg_l};
+    DeviceGuard guard(ix->device);
     for (DevBuf* b : bufs) b->release();
     ix->w_over_sum.release();
+    ix->w_qcnt.release();
+    ix->w_unproven.release();
+    ix->w_norm.release();
     if (ix->h_over_sum) (void)hipHostFree(ix->h_over_sum);
     delete ix;
     return LDOT_OK;
@@ -168,19 +195,30 @@ int ldot_index_destroy(ldot_index_t* ix) {
 int64_t ldot_index_ntotal(const ldot_index_t* ix) { return ix ? ix->ntotal : LDOT_EINVAL; }
 int ldot_index_dim(const ldot_index_t* ix) { return ix ? ix->d : LDOT_EINVAL; }
 
+// (reset and the storage-changing options take no stream argument: they drain the DEVICE first and when done, so they are ordered
+// against work on any stream, blocking or not)
 int ldot_index_reset(ldot_index_t* ix) {
     LDOT_REQUIRE(ix != nullptr, LDOT_EINVAL, "index is NULL");
+    DeviceGuard guard(ix->device);
     if (ix->cap_rows > 0) {
+        LDOT_HIP_CHECK(hipDeviceSynchronize());
         LDOT_HIP_CHECK(hipMemset(ix->x32, 0, (size_t)ix->cap_rows * ix->dpad * 4));
         LDOT_HIP_CHECK(hipMemset(ix->x16b, 0, (size_t)ix->cap_rows * ix->ld16() * 2));
+        LDOT_HIP_CHECK(hipDeviceSynchronize());
     }
     ix->ntotal = 0;
+    if (ix->w_norm.p) LDOT_HIP_CHECK(hipMemset(ix->w_norm.p, 0, 16));
     return LDOT_OK;
 }
 
 int ldot_index_set_option(ldot_index_t* ix, int option, int64_t value) {
     LDOT_REQUIRE(ix != nullptr, LDOT_EINVAL, "index is NULL");
+    DeviceGuard guard(ix->device);
     switch (option) {
+        case LDOT_OPT_VERIFY:
+            LDOT_REQUIRE(value == 0 || value == 1, LDOT_EINVAL, "verify must be 0 or 1");
+            ix->verify = (int)value;
+            return LDOT_OK;
         case LDOT_OPT_MODE:
             LDOT_REQUIRE(value >= 0 && value <= 2, LDOT_EINVAL, "bad mode %lld", (long long)value);
             ix->mode = (int)value;
@@ -209,6 +247,7 @@ int ldot_index_set_option(ldot_index_t* ix, int option, int64_t value) {
             if ((int)value == ix->precision) return LDOT_OK;
             ix->precision = (int)value;
             if (ix->cap_rows == 0) return LDOT_OK;
+            LDOT_HIP_CHECK(hipDeviceSynchronize());
             // rebuild the shadow from the fp32 master copy in the new layout
             uint16_t* n16b = nullptr;
             const size_t b16 = (size_t)ix->cap_rows * ix->ld16() * sizeof(uint16_t);
@@ -221,7 +260,7 @@ int ldot_index_set_option(ldot_index_t* ix, int option, int64_t value) {
             LDOT_HIP_CHECK(hipMemsetAsync(n16b, 0, b16, nullptr));
             int rc = launch_convert_rows(ix->x32, LDOT_F32, ix->dpad, ix->ntotal, ix->ntotal, ix->d, ix->dpad, 0, nullptr,
                                          nullptr, ix->precision ? 1 : 0, n16b, 0, nullptr);
-            LDOT_HIP_CHECK(hipStreamSynchronize(nullptr));
+            LDOT_HIP_CHECK(hipDeviceSynchronize());
             if (rc) {
                 (void)hipFree(n16b);
                 return rc;
@@ -234,6 +273,7 @@ int ldot_index_set_option(ldot_index_t* ix, int option, int64_t value) {
             // allocate capacity up front: a large index then never pays the x1.5 growth copies (which transiently need old +
             // new buffers in HBM)
             LDOT_REQUIRE(value >= 0 && value < 0x7ffffff0ll, LDOT_EINVAL, "bad reserve size");
+            LDOT_HIP_CHECK(hipDeviceSynchronize());
             return index_reserve(ix, std::max<int64_t>(value, ix->ntotal), nullptr);
         }
         case LDOT_OPT_GROWTH_PCT:
@@ -254,6 +294,7 @@ int ldot_index_add(ldot_index_t* ix, const void* rows, int64_t n, int dtype, int
     if (n == 0) return LDOT_OK;
     LDOT_REQUIRE(rows != nullptr, LDOT_EINVAL, "rows is NULL");
     LDOT_REQUIRE(ix->ntotal + n < 0x7ffffff0ll, LDOT_EINVAL, "index too large for 31-bit row labels");
+    DeviceGuard guard(ix->device);
     hipStream_t st = (hipStream_t)stream;
     int rc = index_reserve(ix, ix->ntotal + n, st);
     if (rc) return rc;
@@ -268,6 +309,12 @@ int ldot_index_add(ldot_index_t* ix, const void* rows, int64_t n, int dtype, int
     rc = launch_convert_rows(src, dtype, ix->d, n, n, ix->d, ix->dpad, normalize, ix->x32 + ix->ntotal * ix->dpad,
                              nullptr, ix->precision ? 1 : 0, ix->x16b, ix->ntotal, st);
     if (rc) return rc;
+    // largest row norm so far (device scalar; the LDOT_OPT_VERIFY bound reads it)
+    if (ix->w_norm.p == nullptr) {
+        if ((rc = ix->w_norm.ensure(16))) return rc;
+        LDOT_HIP_CHECK(hipMemsetAsync(ix->w_norm.p, 0, 16, st));
+    }
+    if ((rc = launch_row_norm_max(ix->x32 + ix->ntotal * ix->dpad, ix->dpad, n, ix->d, (float*)ix->w_norm.p, st))) return rc;
     if (mem == LDOT_HOST) LDOT_HIP_CHECK(hipStreamSynchronize(st));   // staging buffer is reused by the next call
     ix->ntotal += n;
     return LDOT_OK;
@@ -277,6 +324,7 @@ int ldot_index_get_rows(ldot_index_t* ix, int64_t row0, int64_t n, float* out, i
     LDOT_REQUIRE(ix != nullptr && out != nullptr, LDOT_EINVAL, "NULL argument");
     LDOT_REQUIRE(row0 >= 0 && n >= 0 && row0 + n <= ix->ntotal, LDOT_EINVAL, "row range out of bounds");
     if (n == 0) return LDOT_OK;
+    DeviceGuard guard(ix->device);
     hipStream_t st = (hipStream_t)stream;
     LDOT_HIP_CHECK(hipMemcpy2DAsync(out, (size_t)ix->d * 4, ix->x32 + row0 * ix->dpad, (size_t)ix->dpad * 4,
                                     (size_t)ix->d * 4, (size_t)n,
@@ -285,9 +333,35 @@ int ldot_index_get_rows(ldot_index_t* ix, int64_t row0, int64_t n, float* out, i
     return LDOT_OK;
 }
 
-int ldot_index_last_stats(const ldot_index_t* ix, int64_t out[4]) {
-    LDOT_REQUIRE(ix != nullptr && out != nullptr, LDOT_EINVAL, "NULL argument");
+int ldot_index_last_stats(const ldot_index_t* cix, int64_t out[4]) {
+    LDOT_REQUIRE(cix != nullptr && out != nullptr, LDOT_EINVAL, "NULL argument");
+    ldot_index* ix = const_cast<ldot_index*>(cix);
+    if (ix->qcnt_n > 0) {   // per-query record counts of the last fused scan: summed here, not on the search path
+        DeviceGuard guard(ix->device);
+        std::vector<int32_t> h((size_t)ix->qcnt_n);
+        LDOT_HIP_CHECK(hipDeviceSynchronize());
+        LDOT_HIP_CHECK(hipMemcpy(h.data(), ix->w_qcnt.p, h.size() * 4, hipMemcpyDeviceToHost));
+        int64_t tot = 0;
+        for (int32_t v : h) tot += v;
+        ix->stats[0] = tot;
+        ix->qcnt_n = 0;
+    }
     for (int i = 0; i < 4; ++i) out[i] = ix->stats[i];
+    return LDOT_OK;
+}
+
+int ldot_index_last_unproven(ldot_index_t* ix, int32_t* flags_out, int64_t* count_out) {
+    LDOT_REQUIRE(ix != nullptr, LDOT_EINVAL, "index is NULL");
+    LDOT_REQUIRE(ix->verify, LDOT_ESTATE, "LDOT_OPT_VERIFY is off");
+    DeviceGuard guard(ix->device);
+    const int64_t n = ix->unproven_n;
+    int32_t cnt = 0;
+    if (n > 0) {
+        LDOT_HIP_CHECK(hipDeviceSynchronize());
+        LDOT_HIP_CHECK(hipMemcpy(&cnt, (int32_t*)ix->w_unproven.p + n, 4, hipMemcpyDeviceToHost));
+        if (flags_out) LDOT_HIP_CHECK(hipMemcpy(flags_out, ix->w_unproven.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    }
+    if (count_out) *count_out = cnt;
     return LDOT_OK;
 }
 
@@ -456,7 +530,8 @@ static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_p
         prof_end(ix, st);
         if (rc) return rc;
         rc = launch_select_pools((const uint4*)ix->w_pool.p, (const int32_t*)ix->w_pool_cnt.p, (int)nsubs, nq,
-                                 (int32_t)ix->ntotal, ls, li, kp, tau, over, (int32_t*)ix->w_over_sum.p, st);
+                                 (int32_t)ix->ntotal, ls, li, kp, tau, over, (int32_t*)ix->w_over_sum.p,
+                                 (int32_t*)ix->w_qcnt.p + q0, st);
         if (rc) return rc;
         ix->stats[3] += len * nq;
         r += len;
@@ -473,6 +548,9 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
     const bool fresh_flags = over_bytes > ix->w_over.bytes;
     if ((rc = ix->w_over.ensure(over_bytes))) return rc;
     if ((rc = ix->w_over_sum.ensure(16))) return rc;
+    if ((rc = ix->w_qcnt.ensure((size_t)nq_pad * 4))) return rc;
+    LDOT_HIP_CHECK(hipMemsetAsync(ix->w_qcnt.p, 0, (size_t)nq_pad * 4, st));
+    ix->qcnt_n = nq;
     if (!ix->h_over_sum) LDOT_HIP_CHECK(hipHostMalloc((void**)&ix->h_over_sum, 16));
     if (fresh_flags || !ix->flags_clean) LDOT_HIP_CHECK(hipMemsetAsync(ix->w_over.p, 0, ix->w_over.bytes, st));
     LDOT_HIP_CHECK(hipMemsetAsync(ix->w_over_sum.p, 0, 16, st));
@@ -514,8 +592,11 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
     LDOT_REQUIRE(mem == LDOT_HOST || mem == LDOT_DEVICE, LDOT_EINVAL, "bad memory space");
     ix->pend_nq = 0;
     ix->overflow_pending = false;
+    ix->qcnt_n = 0;
+    ix->unproven_n = 0;
     if (nq == 0) return LDOT_OK;
     LDOT_REQUIRE(queries != nullptr, LDOT_EINVAL, "NULL buffer");
+    DeviceGuard guard(ix->device);
     for (int i = 0; i < 4; ++i) ix->stats[i] = 0;
     const int kp = candidate_len(ix, k);
     const int64_t nq_pad = round_up(nq, kBM);
@@ -578,11 +659,23 @@ static int search_finish_impl(ldot_index_t* ix, const float* floor, float* out_s
     LDOT_REQUIRE(out_scores && out_labels, LDOT_EINVAL, "NULL buffer");
     const int k = ix->pend_k, kp = ix->pend_kp;
     if (!keep_pending) ix->pend_nq = 0;
+    DeviceGuard guard(ix->device);
     int rc;
+    // LDOT_OPT_VERIFY (plain searches only: a sharded search compares against the GLOBAL threshold, which this shard cannot judge)
+    auto verify = [&](const float* dev_s, const int64_t* dev_l) -> int {
+        if (!ix->verify || floor != nullptr || !ix->rescore || ix->w_norm.p == nullptr) return LDOT_OK;
+        int vrc = ix->w_unproven.ensure((size_t)(nq + 1) * 4);
+        if (vrc) return vrc;
+        LDOT_HIP_CHECK(hipMemsetAsync((int32_t*)ix->w_unproven.p + nq, 0, 4, st));
+        ix->unproven_n = nq;
+        return launch_verify_exact((const float*)ix->w_q32.p, ix->dpad, ix->d, nq, dev_s, dev_l, k, (const float*)ix->w_tau.p,
+                                   (const float*)ix->w_norm.p, (int32_t*)ix->w_unproven.p, (int32_t*)ix->w_unproven.p + nq, st);
+    };
     if (out_mem == LDOT_DEVICE) {   // device outputs are written by the re-score kernel directly
         if ((rc = launch_rescore((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, nq, (const float*)ix->w_ls.p,
                                  (const int32_t*)ix->w_li.p, kp, k, ix->rescore, floor, out_scores, out_labels, st)))
             return rc;
+        if ((rc = verify(out_scores, out_labels))) return rc;
         prof_collect(ix, st);
         return LDOT_OK;
     }
@@ -596,6 +689,7 @@ static int search_finish_impl(ldot_index_t* ix, const float* floor, float* out_s
         if ((rc = launch_rescore((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, nq, (const float*)ix->w_ls.p,
                                  (const int32_t*)ix->w_li.p, kp, k, ix->rescore, floor, (float*)ms, (int64_t*)ml, st)))
             return rc;
+        if ((rc = verify((const float*)ms, (const int64_t*)ml))) return rc;
         LDOT_HIP_CHECK(hipStreamSynchronize(st));
         prof_collect(ix, st);
         return LDOT_OK;
@@ -607,6 +701,7 @@ static int search_finish_impl(ldot_index_t* ix, const float* floor, float* out_s
                              (const int32_t*)ix->w_li.p, kp, k, ix->rescore, floor, (float*)ix->w_outs.p,
                              (int64_t*)ix->w_outl.p, st)))
         return rc;
+    if ((rc = verify((const float*)ix->w_outs.p, (const int64_t*)ix->w_outl.p))) return rc;
     LDOT_HIP_CHECK(hipMemcpyAsync(out_scores, ix->w_outs.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
     LDOT_HIP_CHECK(hipMemcpyAsync(out_labels, ix->w_outl.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
     LDOT_HIP_CHECK(hipStreamSynchronize(st));
@@ -650,7 +745,14 @@ int ldot_index_last_profile(const ldot_index_t* ix, double out[4]) {
 // ---- serialisation: "LDOTIDX1" | int32 d | int64 ntotal | ntotal*d fp32 (row-major, unpadded) -------------
 int ldot_index_save(ldot_index_t* ix, const char* path) {
     LDOT_REQUIRE(ix != nullptr && path != nullptr, LDOT_EINVAL, "NULL argument");
-    std::vector<float> host((size_t)ix->ntotal * ix->d);
+    DeviceGuard guard(ix->device);
+    std::vector<float> host;
+    try {
+        host.resize((size_t)ix->ntotal * ix->d);
+    } catch (const std::bad_alloc&) {
+        set_error("out of host memory staging %lld rows", (long long)ix->ntotal);
+        return LDOT_ENOMEM;
+    }
     if (ix->ntotal > 0) {
         int rc = ldot_index_get_rows(ix, 0, ix->ntotal, host.data(), LDOT_HOST, nullptr);
         if (rc) return rc;
@@ -681,7 +783,27 @@ int ldot_index_load(const char* path, ldot_index_t** out) {
         set_error("%s is not an LDOTIDX1 file", path);
         return LDOT_EIO;
     }
-    std::vector<float> host((size_t)n * d);
+    // the header is untrusted: the payload must be exactly n * d floats (a corrupt count must not size an allocation)
+    bool size_ok = d <= 65536 && n < 0x7ffffff0ll;
+    if (size_ok) {
+        const long here = ftell(f);
+        size_ok = here >= 0 && fseek(f, 0, SEEK_END) == 0;
+        const long end = size_ok ? ftell(f) : -1;
+        size_ok = size_ok && end >= here && (uint64_t)(end - here) == (uint64_t)n * (uint64_t)d * 4u && fseek(f, here, SEEK_SET) == 0;
+    }
+    if (!size_ok) {
+        fclose(f);
+        set_error("%s: header (d = %d, n = %lld) does not match the file size", path, d, (long long)n);
+        return LDOT_EIO;
+    }
+    std::vector<float> host;
+    try {
+        host.resize((size_t)n * d);
+    } catch (const std::bad_alloc&) {
+        fclose(f);
+        set_error("out of host memory loading %s", path);
+        return LDOT_ENOMEM;
+    }
     ok = host.empty() || fread(host.data(), sizeof(float), host.size(), f) == host.size();
     fclose(f);
     LDOT_REQUIRE(ok, LDOT_EIO, "%s is truncated", path);
@@ -707,13 +829,19 @@ int ldot_merge_topk(const float* scores, const int64_t* labels, int nparts, int6
         return launch_select_lists(scores, labels, nq * k_in, nparts, k_in, nq, k_out, out_scores, out_labels, st);
     LDOT_REQUIRE(mem == LDOT_HOST, LDOT_EINVAL, "bad mem");
     const size_t n_in = (size_t)nparts * nq * k_in, n_out = (size_t)nq * k_out;
-    void *ds = nullptr, *dl = nullptr, *os = nullptr, *ol = nullptr;
+    // host-side callers: a grow-only per-thread device workspace (released when the thread exits), no hipMalloc/hipFree per call
+    struct Ws {
+        DevBuf b[4];
+        ~Ws() {
+            for (DevBuf& x : b) x.release();
+        }
+    };
+    static thread_local Ws ws;
     int rc = LDOT_OK;
-    if (hipMalloc(&ds, n_in * 4) != hipSuccess || hipMalloc(&dl, n_in * 8) != hipSuccess ||
-        hipMalloc(&os, n_out * 4) != hipSuccess || hipMalloc(&ol, n_out * 8) != hipSuccess) {
-        set_error("device allocation failed in ldot_merge_topk");
-        rc = LDOT_ENOMEM;
-    }
+    if ((rc = ws.b[0].ensure(n_in * 4)) || (rc = ws.b[1].ensure(n_in * 8)) || (rc = ws.b[2].ensure(n_out * 4)) ||
+        (rc = ws.b[3].ensure(n_out * 8)))
+        return rc;
+    void *ds = ws.b[0].p, *dl = ws.b[1].p, *os = ws.b[2].p, *ol = ws.b[3].p;
     if (!rc && (hipMemcpyAsync(ds, scores, n_in * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
                 hipMemcpyAsync(dl, labels, n_in * 8, hipMemcpyHostToDevice, st) != hipSuccess)) {
         set_error("H2D copy failed in ldot_merge_topk");
@@ -728,10 +856,6 @@ int ldot_merge_topk(const float* scores, const int64_t* labels, int nparts, int6
         set_error("D2H copy failed in ldot_merge_topk");
         rc = LDOT_EDEVICE;
     }
-    (void)hipFree(ds);
-    (void)hipFree(dl);
-    (void)hipFree(os);
-    (void)hipFree(ol);
     return rc;
 }
 

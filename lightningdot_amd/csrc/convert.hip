@@ -77,6 +77,27 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(const void* __restric
     }
 }
 
+// largest L2 norm among rows [0, n) of the padded fp32 master copy (one wave per row; atomicMax on the non-negative float's bits)
+__global__ __launch_bounds__(256) void row_norm_max_kernel(const float* __restrict__ x32, int64_t ld, int64_t n, int d,
+                                                           float* __restrict__ out_max) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* r = x32 + row * ld;
+    float acc = 0.f;
+    for (int c = lane; c < d; c += 64) acc = fmaf(r[c], r[c], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) atomicMax((int*)out_max, __float_as_int(sqrtf(acc)));
+}
+
+int launch_row_norm_max(const float* x32, int64_t ld, int64_t n, int d, float* out_max, hipStream_t st) {
+    if (n <= 0) return LDOT_OK;
+    hipLaunchKernelGGL(row_norm_max_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, x32, ld, n, d, out_max);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
 int launch_convert_rows(const void* src, int dtype, int64_t ld_src, int64_t n, int64_t n_pad, int d, int dpad,
                         int normalize, float* dst32, uint16_t* dst16, int split, uint16_t* dst16b, int64_t row0b,
                         hipStream_t st) {

@@ -52,9 +52,10 @@ int launch_lists_to_parts(const float* list_s, const int32_t* list_i, int64_t n,
 int launch_parts_to_lists(const float* out_s, const int64_t* out_l, int64_t n, float* list_s, int32_t* list_i, int kp,
                           float* tau, hipStream_t st);
 // row_end: records may carry rows of the zero padding behind the last index row (>= row_end): dropped here.
-// overflow_flags[q] is set (and *over_sum incremented once per query) when one of q's sub-pools held more than kPoolCap records.
+// qcnt[q] (optional) += the number of records read for q.  overflow_flags[q] is set (and *over_sum incremented once per query) when one of q's sub-pools held more than kPoolCap records.
 int launch_select_pools(const uint4* pool, const int32_t* pool_cnt, int nsubs, int64_t nq, int32_t row_end, float* list_s,
-                        int32_t* list_i, int kp, float* tau, int32_t* overflow_flags, int32_t* over_sum, hipStream_t st);
+                        int32_t* list_i, int kp, float* tau, int32_t* overflow_flags, int32_t* over_sum, int32_t* qcnt,
+                        hipStream_t st);
 // generic merge of explicit candidate lists: cand_[sl] is [nq][ncand] (labels int64, -1 = empty) -> [nq][k_out]
 int launch_select_lists(const float* cand_s, const int64_t* cand_l, int64_t part_stride, int nparts, int k_in,
                         int64_t nq, int k_out, float* out_s, int64_t* out_l, hipStream_t st);
@@ -63,6 +64,12 @@ int launch_select_lists(const float* cand_s, const int64_t* cand_l, int64_t part
 int launch_rescore(const float* q32, int64_t ldq, const float* x32, int64_t ldx, int dpad, int64_t nq,
                    const float* list_s, const int32_t* list_i, int kp, int k, int do_rescore, const float* floor,
                    float* out_s, int64_t* out_l, hipStream_t st);
+
+// running maximum of the L2 norms of the rows of a padded fp32 matrix (atomicMax into *out_max, a non-negative float)
+int launch_row_norm_max(const float* x32, int64_t ld, int64_t n, int d, float* out_max, hipStream_t st);
+// LDOT_OPT_VERIFY: flags[q] = 1 when the top-k of query q is not proven exact (see rescore.hip); *count += number flagged
+int launch_verify_exact(const float* q32, int64_t ldq, int d, int64_t nq, const float* out_s, const int64_t* out_l, int k,
+                        const float* tau, const float* max_norm, int32_t* flags, int32_t* count, hipStream_t st);
 
 int fused_tile_rows();
 int fused_query_group(int64_t nq_pad);   // 8 / 4 / 2 / 1 -> 1024 / qg sub-pools per query, 256 / qg row slices

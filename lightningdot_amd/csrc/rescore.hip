@@ -110,6 +110,44 @@ __global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __rest
     }
 }
 
+// LDOT_OPT_VERIFY: is the reported top-k PROVEN to be the exact fp32 top-k?  A row that is not among the k' candidates has a bf16
+// candidate score <= tau (the k'-th best candidate score), hence an exact score <= tau + E where E bounds the bf16 input-rounding
+// error of one score.  If the k-th reported exact score is >= tau + E no such row can displace it.  E is the statistical bound
+// c * 2^-8 * |q| * max|x| / sqrt(d) with c = 4 (input roundings treated as independent, relative error <= 2^-9 each, 8 standard
+// deviations for vectors whose mass is spread over the d coordinates); a query that fails it is FLAGGED, not wrong — the caller
+// re-searches the flagged queries with a larger margin (FlatIPIndex.search(..., verify=True)).
+__global__ __launch_bounds__(256) void verify_exact_kernel(const float* __restrict__ q32, int64_t ldq, int d, int64_t nq,
+                                                           const float* __restrict__ out_s, const int64_t* __restrict__ out_l,
+                                                           int k, const float* __restrict__ tau,
+                                                           const float* __restrict__ max_norm, float c,
+                                                           int32_t* __restrict__ flags, int32_t* __restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const float* r = q32 + q * ldq;
+    float acc = 0.f;
+    for (int i = lane; i < d; i += 64) acc = fmaf(r[i], r[i], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) {
+        const float t = tau[q];
+        const bool full = out_l[q * k + k - 1] >= 0;     // fewer than k rows: everything there is was reported
+        const float E = c * 0.00390625f * sqrtf(acc) * max_norm[0] * rsqrtf((float)d);
+        const bool proven = !full || t == -INFINITY || out_s[q * k + k - 1] >= t + E;
+        flags[q] = proven ? 0 : 1;
+        if (!proven) atomicAdd(count, 1);
+    }
+}
+
+int launch_verify_exact(const float* q32, int64_t ldq, int d, int64_t nq, const float* out_s, const int64_t* out_l, int k,
+                        const float* tau, const float* max_norm, int32_t* flags, int32_t* count, hipStream_t st) {
+    if (nq <= 0) return LDOT_OK;
+    hipLaunchKernelGGL(verify_exact_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, q32, ldq, d, nq, out_s, out_l, k,
+                       tau, max_norm, 4.0f, flags, count);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
 int launch_rescore(const float* q32, int64_t ldq, const float* x32, int64_t ldx, int dpad, int64_t nq,
                    const float* list_s, const int32_t* list_i, int kp, int k, int do_rescore, const float* floor,
                    float* out_s, int64_t* out_l, hipStream_t st) {

@@ -354,12 +354,14 @@ int fused_tile_rows() { return RingGeom<6>::kBM; }
 // has 256 / qg row slices and 1024 / qg sub-pools per query
 int fused_query_group(int64_t nq_pad) {
     const int64_t nqb = nq_pad / kRBN;
-    static int force = -1;   // LDOT_DEBUG_QG: experiment override (1, 2, 4 or 8)
+#ifdef LDOT_ABLATION
+    static int force = -1;   // LDOT_DEBUG_QG: experiment override (1, 2, 4 or 8) — ablation builds only
     if (force < 0) {
         const char* e = getenv("LDOT_DEBUG_QG");
         force = e ? atoi(e) : 0;
     }
     if (force == 1 || force == 2 || force == 4 || force == 8) return force;
+#endif
     return nqb >= 8 ? 8 : nqb >= 4 ? 4 : nqb >= 2 ? 2 : 1;
 }
 
@@ -368,25 +370,28 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
                         hipStream_t st) {
     if (nrows <= 0 || nq_pad <= 0) return LDOT_OK;
     LDOT_REQUIRE(ldx_elems == ldq_elems, LDOT_EINVAL, "index and query shadows must have the same row stride");
-    // LDOT_DEBUG_VARIANT selects an ablation build of the kernel (profiling only; results are then meaningless):
-    //   16 tau = +inf (epilogue fast path only), 18 = 16 + no global loads after the prologue, 20 = 16 + no MFMA/ds_read
+    auto rk = score_filter_r6_kernel<0>;
+#ifdef LDOT_ABLATION
+    // Ablation builds only (python -m lightningdot_amd.build --ablation; tools/ablate.sh): LDOT_DEBUG_VARIANT selects a profiling
+    // variant of the kernel.  Results are meaningless under most of them, so the product library does not contain this hook.
+    //   16 tau = +inf (epilogue fast path only), 18 = 16 + no global loads after the prologue, 17 no epilogue at all,
+    //   64 every row tile aliased onto the first 32 (A panel always L2-resident), 128 slab loads piece by piece between the MFMAs,
+    //   256 no deferral of the slab-load burst around the filter
     static int variant = -1;
     if (variant < 0) {
         const char* e = getenv("LDOT_DEBUG_VARIANT");
         variant = e ? atoi(e) : 0;
     }
-    auto rk = score_filter_r6_kernel<0>;
     if (variant == 16) rk = score_filter_r6_kernel<16>;
     if (variant == 18) rk = score_filter_r6_kernel<18>;
-    if (variant == 20) rk = score_filter_r6_kernel<20>;
-    if (variant == 17) rk = score_filter_r6_kernel<17>;   // no epilogue at all (upper bound of hiding it)
+    if (variant == 17) rk = score_filter_r6_kernel<17>;
     if (variant == 48) rk = score_filter_r6_kernel<48>;
-    if (variant == 80) rk = score_filter_r6_kernel<80>;
-    if (variant == 8) rk = score_filter_r6_kernel<8>;
     if (variant == 64) rk = score_filter_r6_kernel<64>;
-    if (variant == 256) rk = score_filter_r6_kernel<256>;
+    if (variant == 80) rk = score_filter_r6_kernel<80>;
     if (variant == 128) rk = score_filter_r6_kernel<128>;
     if (variant == 144) rk = score_filter_r6_kernel<144>;
+    if (variant == 256) rk = score_filter_r6_kernel<256>;
+#endif
     LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<6>::kLds));
     const int qg = fused_query_group(nq_pad);
     const int qg_log2 = qg == 8 ? 3 : qg == 4 ? 2 : qg == 2 ? 1 : 0;

@@ -465,7 +465,8 @@ __global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(con
                                                                        int32_t* __restrict__ list_i, int kp, int cap,
                                                                        float* __restrict__ tau,
                                                                        int32_t* __restrict__ overflow,
-                                                                       int32_t* __restrict__ over_sum, int dbg) {
+                                                                       int32_t* __restrict__ over_sum,
+                                                                       int32_t* __restrict__ qcnt, int dbg) {
     extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
     // QPW independent waves per workgroup, one query each (no workgroup-level synchronisation anywhere): the grid of
     // one-wave workgroups was bound by the workgroup dispatch rate, not by the work
@@ -481,6 +482,7 @@ __global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(con
     int cn = lane < nsubs ? cnt[lane] : 0;
     if (!(dbg & 4)) sel.load_list(ls, li);
     bool over = false;
+    int nrec = 0;   // records of this query in this launch (statistics)
     // entry-major, plane-major pools: plane p of level e of all sub-pools is one contiguous run of 16-byte words -> coalesced
     // reads of the few levels in use.  One group of 64 sub-pools x LV entry levels per step.
     const uint4* base = pool + q * (int64_t)kPoolCap * kPoolPlanes * nsubs;
@@ -490,6 +492,7 @@ __global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(con
         const int sidx = s0 + lane;
         over |= cn > kPoolCap;
         const int c = cn < kPoolCap ? cn : kPoolCap;
+        nrec += c;
         if (sidx < nsubs) cnt[sidx] = 0;
         cn = sidx + kPoolSelThreads < nsubs ? cnt[sidx + kPoolSelThreads] : 0;   // next step's counters
         int cm = c;
@@ -524,6 +527,11 @@ __global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(con
     const bool any_over = __any(over);
     if (dbg & 2) return;
     sel.finish(ls, li, tau ? tau + q : nullptr);
+    if (qcnt) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nrec += __shfl_xor(nrec, o);
+        if (lane == 0) qcnt[q] += nrec;   // (one wave per query: no atomics)
+    }
     if (lane == 0 && any_over && atomicExch(&overflow[q], 1) == 0) atomicAdd(over_sum, 1);   // queries counted once
 }
 
@@ -536,7 +544,8 @@ __global__ __launch_bounds__(kSelThreads) void select_pools_block_kernel(const u
                                                                          int32_t* __restrict__ list_i, int kp, int cap,
                                                                          float* __restrict__ tau,
                                                                          int32_t* __restrict__ overflow,
-                                                                         int32_t* __restrict__ over_sum) {
+                                                                         int32_t* __restrict__ over_sum,
+                                                                         int32_t* __restrict__ qcnt) {
     extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
     __shared__ int count;
     const int64_t q = blockIdx.x;
@@ -547,6 +556,7 @@ __global__ __launch_bounds__(kSelThreads) void select_pools_block_kernel(const u
     const uint4* base = pool + q * (int64_t)kPoolCap * kPoolPlanes * nsubs;
     int32_t* cnt = pool_cnt + q * (int64_t)nsubs;
     bool over = false;
+    int nrec = 0;
     // a lone workgroup pays every dependent global round trip in full: the counters of SPT x 256 sub-pools are fetched in one
     // batch (together with the running list), then two entry levels of all of them in another
     constexpr int SPT = 4, LV = 2;
@@ -565,6 +575,7 @@ __global__ __launch_bounds__(kSelThreads) void select_pools_block_kernel(const u
             if (sidx < nsubs) cnt[sidx] = 0;
             over |= c[g] > kPoolCap;
             c[g] = c[g] < kPoolCap ? c[g] : kPoolCap;
+            nrec += c[g];
             cm = max(cm, c[g]);
         }
         for (int e0 = 0; __syncthreads_or(cm > e0); e0 += LV) {
@@ -599,6 +610,14 @@ __global__ __launch_bounds__(kSelThreads) void select_pools_block_kernel(const u
         }
     }
     sel.finish(ls, li, tau ? tau + q : nullptr);
+    if (qcnt) {
+        __shared__ int nrec_sh;
+        if (threadIdx.x == 0) nrec_sh = 0;
+        __syncthreads();
+        atomicAdd(&nrec_sh, nrec);
+        __syncthreads();
+        if (threadIdx.x == 0) qcnt[q] += nrec_sh;
+    }
     if (__syncthreads_or(over) && threadIdx.x == 0 && atomicExch(&overflow[q], 1) == 0) atomicAdd(over_sum, 1);
 }
 
@@ -699,29 +718,34 @@ int launch_parts_to_lists(const float* out_s, const int64_t* out_l, int64_t n, f
 }
 
 int launch_select_pools(const uint4* pool, const int32_t* pool_cnt, int nsubs, int64_t nq, int32_t row_end, float* list_s,
-                        int32_t* list_i, int kp, float* tau, int32_t* overflow_flags, int32_t* over_sum, hipStream_t st) {
+                        int32_t* list_i, int kp, float* tau, int32_t* overflow_flags, int32_t* over_sum, int32_t* qcnt,
+                        hipStream_t st) {
     if (nq <= 0) return LDOT_OK;
     if (nq <= 256) {   // few queries: block-per-query walk
         const int bcap = select_cap(kp, 2048, 4 * kSelThreads);   // a step appends up to 4 x 256 candidates on top of a full list
         hipLaunchKernelGGL(select_pools_block_kernel, dim3((unsigned)nq), dim3(kSelThreads), (size_t)bcap * 8, st, pool,
-                           (int32_t*)pool_cnt, nsubs, row_end, list_s, list_i, kp, bcap, tau, overflow_flags, over_sum);
+                           (int32_t*)pool_cnt, nsubs, row_end, list_s, list_i, kp, bcap, tau, overflow_flags, over_sum, qcnt);
         LDOT_HIP_CHECK(hipGetLastError());
         return LDOT_OK;
     }
     const int cap = select_cap(kp, 1024, 8 * kPoolSelThreads);   // a step appends up to 8 x 64 candidates on top of a full list
-    static int dbg = -1;   // LDOT_DEBUG_SEL: ablation bits (profiling only; results are then meaningless)
-    if (dbg < 0) {
+    int dbg = 0;
+#ifdef LDOT_ABLATION
+    static int dbg_env = -1;   // LDOT_DEBUG_SEL: ablation bits (ablation builds only; results are then meaningless)
+    if (dbg_env < 0) {
         const char* e = getenv("LDOT_DEBUG_SEL");
-        dbg = e ? atoi(e) : 0;
+        dbg_env = e ? atoi(e) : 0;
     }
+    dbg = dbg_env;
+#endif
     if (cap <= WaveSelector::kRegKeys * 64) {   // register selection path: 4 independent query-waves per workgroup
         constexpr int QPW = 4;
         hipLaunchKernelGGL((select_pools_kernel<4, QPW>), dim3((unsigned)((nq + QPW - 1) / QPW)),
                            dim3(kPoolSelThreads * QPW), (size_t)cap * 8 * QPW, st, pool, (int32_t*)pool_cnt, nsubs, nq,
-                           row_end, list_s, list_i, kp, cap, tau, overflow_flags, over_sum, dbg);
+                           row_end, list_s, list_i, kp, cap, tau, overflow_flags, over_sum, qcnt, dbg);
     } else {   // kp > 512: LDS sort path, one wave per workgroup
         hipLaunchKernelGGL((select_pools_kernel<4, 1>), dim3((unsigned)nq), dim3(kPoolSelThreads), (size_t)cap * 8, st,
-                           pool, (int32_t*)pool_cnt, nsubs, nq, row_end, list_s, list_i, kp, cap, tau, overflow_flags, over_sum, dbg);
+                           pool, (int32_t*)pool_cnt, nsubs, nq, row_end, list_s, list_i, kp, cap, tau, overflow_flags, over_sum, qcnt, dbg);
     }
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;

@@ -27,15 +27,16 @@ def _is_tensor(x):
     return type(x).__module__.startswith('torch') and hasattr(x, 'data_ptr')
 
 
-def _stream_ptr(device_tensor=None):
+def _stream_ptr(device=None):
     import torch
     if torch.cuda.is_available():
-        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     return ctypes.c_void_p(0)
 
 
-def _describe(x, d):
-    """-> (keepalive, pointer, n_rows, dtype_code, mem_code) for a [n, d] array / tensor."""
+def _describe(x, d, device=None):
+    """-> (keepalive, pointer, n_rows, dtype_code, mem_code) for a [n, d] array / tensor (device tensors must live on the
+    index's device: the library runs every call there, whatever the caller's current device is)."""
     if _is_tensor(x):
         import torch
         t = x.detach()
@@ -48,6 +49,8 @@ def _describe(x, d):
             t = t.float()
             code = L.F32
         t = t.contiguous()
+        if t.is_cuda and device is not None and t.device.index != device:
+            raise ValueError(f'tensor on cuda:{t.device.index} but the index lives on cuda:{device}')
         return t, ctypes.c_void_p(t.data_ptr()), t.shape[0], code, (L.DEVICE if t.is_cuda else L.HOST)
     a = np.asarray(x)
     if a.ndim == 1:
@@ -72,6 +75,12 @@ class FlatIPIndex:
             L.check(self._lib.ldot_index_create(int(d), ctypes.byref(h)))
             self._h = h
         self.d = int(self._lib.ldot_index_dim(self._h))
+        self._pending = None
+        try:
+            import torch
+            self.device = torch.cuda.current_device() if torch.cuda.is_available() else None   # where the library created it
+        except Exception:  # pragma: no cover
+            self.device = None
 
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None
@@ -92,29 +101,71 @@ class FlatIPIndex:
         L.check(self._lib.ldot_index_reset(self._h))
 
     def add(self, vectors):
-        keep, ptr, n, dt, mem = _describe(vectors, self.d)
-        L.check(self._lib.ldot_index_add(self._h, ptr, n, dt, mem, int(self.normalize), _stream_ptr()))
+        keep, ptr, n, dt, mem = _describe(vectors, self.d, self.device)
+        L.check(self._lib.ldot_index_add(self._h, ptr, n, dt, mem, int(self.normalize), _stream_ptr(self.device)))
         if mem == L.DEVICE:
             import torch
             torch.cuda.current_stream().synchronize()   # `keep` may be a temporary
         del keep
 
-    def search(self, queries, k: int):
-        """faiss-style: (scores [nq, k] float32, labels [nq, k] int64) as numpy arrays."""
-        keep, ptr, nq, dt, mem = _describe(queries, self.d)
+    def search(self, queries, k: int, verify: bool = False):
+        """faiss-style: (scores [nq, k] float32, labels [nq, k] int64) as numpy arrays.
+
+        ``verify=True``: the bf16 candidate pass is exact whenever the true top-k lies inside the bf16 top-k' (k' = k + margin).
+        With verification the library flags every query for which that is not PROVEN (LDOT_OPT_VERIFY: k-th exact score above the
+        candidate threshold by a bf16 error bound) and the flagged queries are searched again with a 4x larger margin, repeatedly,
+        up to the library's maximum; ``last_unproven`` then holds the number of queries that still could not be proven."""
+        keep, ptr, nq, dt, mem = _describe(queries, self.d, self.device)
         scores = np.empty((nq, k), dtype=np.float32)
         labels = np.empty((nq, k), dtype=np.int64)
-        L.check(self._lib.ldot_index_search(self._h, ptr, nq, dt, mem, int(self.normalize), int(k),
-                                            ctypes.c_void_p(scores.ctypes.data), ctypes.c_void_p(labels.ctypes.data),
-                                            L.HOST, _stream_ptr()))
+        if verify:
+            self.set_option(L.OPT_VERIFY, 1)
+        try:
+            L.check(self._lib.ldot_index_search(self._h, ptr, nq, dt, mem, int(self.normalize), int(k),
+                                                ctypes.c_void_p(scores.ctypes.data), ctypes.c_void_p(labels.ctypes.data),
+                                                L.HOST, _stream_ptr(self.device)))
+            if verify and nq:
+                self._escalate(keep, k, scores, labels)
+        finally:
+            if verify:
+                self.set_option(L.OPT_VERIFY, 0)
+                self.set_option(L.OPT_MARGIN, -1)
         del keep
         return scores, labels
+
+    def unproven(self, nq: int):
+        """(flags [nq] int32, count) of the last search made with LDOT_OPT_VERIFY = 1."""
+        flags = np.zeros((nq,), dtype=np.int32)
+        cnt = ctypes.c_int64(0)
+        L.check(self._lib.ldot_index_last_unproven(self._h, ctypes.c_void_p(flags.ctypes.data), ctypes.byref(cnt)))
+        return flags, int(cnt.value)
+
+    def _escalate(self, queries, k, scores, labels):
+        flags, cnt = self.unproven(scores.shape[0])
+        todo = np.nonzero(flags)[0]
+        margin = max(28, k // 4)
+        self.last_escalations = []
+        while len(todo) and margin < L.MAX_MARGIN:
+            margin = min(4 * margin, L.MAX_MARGIN)
+            self.set_option(L.OPT_MARGIN, margin)
+            sub = queries[todo] if not _is_tensor(queries) else queries[todo.tolist()]
+            keep, ptr, n, dt, mem = _describe(sub, self.d, self.device)
+            s2 = np.empty((n, k), dtype=np.float32)
+            l2 = np.empty((n, k), dtype=np.int64)
+            L.check(self._lib.ldot_index_search(self._h, ptr, n, dt, mem, int(self.normalize), int(k),
+                                                ctypes.c_void_p(s2.ctypes.data), ctypes.c_void_p(l2.ctypes.data), L.HOST,
+                                                _stream_ptr(self.device)))
+            scores[todo], labels[todo] = s2, l2
+            f2, _ = self.unproven(n)
+            self.last_escalations.append((margin, int(n)))
+            todo = todo[np.nonzero(f2)[0]]
+        self.last_unproven = int(len(todo))
 
     def search_into(self, queries, k: int, out_scores, out_labels):
         """Search with caller-owned HOST outputs (float32 [nq, k] / int64 [nq, k]; numpy arrays or CPU tensors — pinned memory
         makes the result copies asynchronous: the library re-scores in chunks and ships every chunk while the next one is
         re-scored).  Returns when the results are in the buffers."""
-        keep, ptr, nq, dt, mem = _describe(queries, self.d)
+        keep, ptr, nq, dt, mem = _describe(queries, self.d, self.device)
 
         def host_ptr(buf, itemsize):
             if _is_tensor(buf):
@@ -126,33 +177,33 @@ class FlatIPIndex:
             return ctypes.c_void_p(buf.ctypes.data)
 
         L.check(self._lib.ldot_index_search(self._h, ptr, nq, dt, mem, int(self.normalize), int(k),
-                                            host_ptr(out_scores, 4), host_ptr(out_labels, 8), L.HOST, _stream_ptr()))
+                                            host_ptr(out_scores, 4), host_ptr(out_labels, 8), L.HOST, _stream_ptr(self.device)))
         del keep
         return out_scores, out_labels
 
     def search_tensors(self, queries, k: int):
         """Device-resident variant: queries is a CUDA tensor; returns (scores, labels) CUDA tensors."""
         import torch
-        keep, ptr, nq, dt, mem = _describe(queries, self.d)
+        keep, ptr, nq, dt, mem = _describe(queries, self.d, self.device)
         if mem != L.DEVICE:
             raise ValueError('search_tensors expects a CUDA tensor')
         scores = torch.empty((nq, k), dtype=torch.float32, device=keep.device)
         labels = torch.empty((nq, k), dtype=torch.int64, device=keep.device)
         L.check(self._lib.ldot_index_search(self._h, ptr, nq, dt, mem, int(self.normalize), int(k),
                                             ctypes.c_void_p(scores.data_ptr()), ctypes.c_void_p(labels.data_ptr()),
-                                            L.DEVICE, _stream_ptr()))
+                                            L.DEVICE, _stream_ptr(self.device)))
         return scores, labels
 
     def search_begin(self, queries, k: int):
         """First half of a sharded search (CUDA tensors): generates this shard's candidates and returns their thresholds,
         a float32 CUDA tensor [nq] (the k'-th best candidate score per query, -inf while fewer than k' candidates)."""
         import torch
-        keep, ptr, nq, dt, mem = _describe(queries, self.d)
+        keep, ptr, nq, dt, mem = _describe(queries, self.d, self.device)
         if mem != L.DEVICE:
             raise ValueError('search_begin expects a CUDA tensor')
         tau = torch.empty((nq,), dtype=torch.float32, device=keep.device)
         L.check(self._lib.ldot_index_search_begin(self._h, ptr, nq, dt, mem, int(self.normalize), int(k),
-                                                  ctypes.c_void_p(tau.data_ptr()), _stream_ptr()))
+                                                  ctypes.c_void_p(tau.data_ptr()), _stream_ptr(self.device)))
         self._pending = (nq, int(k), keep.device)
         return tau
 
@@ -160,7 +211,9 @@ class FlatIPIndex:
         """Second half: re-scores the candidates at or above ``floor`` ([nq] float32 CUDA tensor, e.g. the all-reduce MAX of
         the shards' thresholds; None = all) and returns this shard's partial top-k (scores, labels) as CUDA tensors."""
         import torch
-        nq, k, dev = self._pending
+        if self._pending is None:
+            raise L.LdotError(-5, 'search_finish without a pending search_begin')
+        (nq, k, dev), self._pending = self._pending, None
         scores = torch.empty((nq, k), dtype=torch.float32, device=dev)
         labels = torch.empty((nq, k), dtype=torch.int64, device=dev)
         fptr = ctypes.c_void_p(0)
@@ -169,13 +222,13 @@ class FlatIPIndex:
             assert floor.shape == (nq,)
             fptr = ctypes.c_void_p(floor.data_ptr())
         L.check(self._lib.ldot_index_search_finish(self._h, fptr, ctypes.c_void_p(scores.data_ptr()),
-                                                   ctypes.c_void_p(labels.data_ptr()), L.DEVICE, _stream_ptr()))
+                                                   ctypes.c_void_p(labels.data_ptr()), L.DEVICE, _stream_ptr(self.device)))
         return scores, labels
 
     def get_rows(self, row0: int, n: int) -> np.ndarray:
         out = np.empty((n, self.d), dtype=np.float32)
         L.check(self._lib.ldot_index_get_rows(self._h, int(row0), int(n), ctypes.c_void_p(out.ctypes.data), L.HOST,
-                                              _stream_ptr()))
+                                              _stream_ptr(self.device)))
         return out
 
     def last_stats(self):

@@ -201,7 +201,7 @@ class _AllGatherCat(torch.autograd.Function):
         import torch.distributed as dist
         # every rank holds the gradient of ITS loss w.r.t. ALL gathered rows; the gradient of the summed loss
         # w.r.t. the local rows is the sum over ranks of the corresponding slice -> all-reduce, then slice.
-        g = g.contiguous()
+        g = g.contiguous().clone()      # autograd may share the incoming buffer (retain_graph, hooks): never reduce in place
         dist.all_reduce(g)
         start = sum(ctx.sizes[:ctx.rank])
         return g[start:start + ctx.sizes[ctx.rank]]

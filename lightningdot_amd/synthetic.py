@@ -48,3 +48,13 @@ def synthetic_itm_batches(n_img: int, caps_per_img: int = 5, batch_size: int = 8
             'sample_size': bs, 'pos_ctx_indices': list(range(bs)), 'neg_ctx_indices': list(range(bs, n)),
             'txt_index': [c[0] for c in allc], 'img_fname': [c[1] for c in allc]})
     return batches, img2txt
+
+
+def s2_embeddings(n_img: int, d: int = 768, caps_per_img: int = 5, noise: float = 0.9, seed: int = 7, device='cpu'):
+    """SURVEY §8d S2 stand-in for the Flickr-1k / COCO-5k embedding sets (the real checkpoints and LMDBs are absent):
+    ``n_img`` image rows N(0,1) and ``caps_per_img`` captions per image, caption = image + noise * N(0,1).
+    -> (img [n_img, d], txt [n_img * caps_per_img, d]) fp32; caption j belongs to image j // caps_per_img."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(n_img, d, generator=g)
+    txt = img.repeat_interleave(caps_per_img, 0) + noise * torch.randn(n_img * caps_per_img, d, generator=g)
+    return img.to(device), txt.to(device)

@@ -63,7 +63,8 @@ def broadcast_parameters(model: nn.Module, src: int = 0):
 
 def allreduce_gradients(params: Iterable[nn.Parameter], bucket_bytes: int = 256 << 20, average: bool = True):
     """Flat-bucket gradient all-reduce (C1).  Parameters without a gradient contribute zeros so that every rank issues
-    the same collectives."""
+    the same collectives; a parameter that had no gradient on ANY rank (e.g. the unused bert.pooler) keeps ``grad = None``
+    afterwards, so the optimizer skips it exactly as in a single-process run (no weight decay on untouched parameters)."""
     dist = _dist()
     if dist is None:
         return
@@ -75,15 +76,20 @@ def allreduce_gradients(params: Iterable[nn.Parameter], bucket_bytes: int = 256 
         if not bucket:
             return
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
-        dist.all_reduce(flat)
+        # one extra element per parameter: "some rank had a gradient" (summed with the payload in the same collective)
+        had = torch.tensor([0.0 if p.grad is None else 1.0 for p in bucket], dtype=flat.dtype, device=flat.device)
+        both = torch.cat([flat, had])
+        dist.all_reduce(both)
+        flat, had = both[:flat.numel()], both[flat.numel():].tolist()
         if average:
             flat.div_(ws)
         o = 0
-        for p in bucket:
+        for p, h in zip(bucket, had):
             n = p.numel()
-            if p.grad is None:
-                p.grad = torch.empty_like(p)
-            p.grad.copy_(flat[o:o + n].view_as(p))
+            if h > 0:
+                if p.grad is None:
+                    p.grad = torch.empty_like(p)
+                p.grad.copy_(flat[o:o + n].view_as(p))
             o += n
         bucket, size = [], 0
 

@@ -448,3 +448,39 @@ def test_two_handles_from_two_threads(L):
     for i in range(2):
         np.testing.assert_array_equal(out[i][1], ref[i][1])
         np.testing.assert_array_equal(out[i][0], ref[i][0])
+
+
+def test_verify_flags_crowded_scores_and_escalates(L):
+    """LDOT_OPT_VERIFY: well separated data is proven exact; scores that crowd closer than bf16 resolves are FLAGGED, the flagged
+    queries are re-searched with a larger margin (FlatIPIndex.search(verify=True)) and what remains unproven is reported."""
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((20000, 256)).astype(np.float32)
+    q, g = planted_queries(x, 300)
+    ix = _index(x)
+    s, l = ix.search(q, 10, verify=True)
+    assert ix.last_unproven == 0 and ix.last_escalations == []
+    assert_topk_matches(q, x, s, l, 10)
+    # crowded: every row = the same large vector + small noise -> all scores within bf16 noise of each other
+    base = (rng.standard_normal(256) * 8).astype(np.float32)
+    xc = (base[None, :] + 0.002 * rng.standard_normal((20000, 256))).astype(np.float32)
+    qc = (base[None, :] + 0.002 * rng.standard_normal((40, 256))).astype(np.float32)
+    ixc = _index(xc)
+    ixc.set_option(L.OPT_VERIFY, 1)
+    ixc.search(qc, 10)
+    flags, cnt = ixc.unproven(40)
+    assert cnt == 40 and flags.all()                      # nothing can be proven on this data with the default margin
+    ixc.set_option(L.OPT_VERIFY, 0)
+    ixc.search(qc, 10, verify=True)
+    assert ixc.last_escalations and ixc.last_escalations[0][1] == 40       # all 40 were re-searched with a larger margin
+
+
+def test_last_stats_counts_filter_records(L):
+    rng = np.random.default_rng(22)
+    x = rng.standard_normal((60000, 128)).astype(np.float32)
+    q, g = planted_queries(x, 600)
+    ix = _index(x, mode=L.MODE_FUSED, warm_rows=2048)
+    ix.search(q, 10)
+    st = ix.last_stats()
+    assert st['fused_pairs'] > 0 and st['overflowed_queries'] == 0
+    # every query needs at least k' - (warm-up hits) records to fill its list; far fewer than one per scored pair
+    assert 600 * 5 < st['fused_candidates'] < st['fused_pairs'] // 20, st
