@@ -64,6 +64,9 @@ def main():
                                                       'bookkeeping on a one-GPU box together with --all-on-device0)')
     ap.add_argument('--all-on-device0', action='store_true', help='debug: every rank uses cuda:0')
     ap.add_argument('--cpu-sample-queries', type=int, default=2048)
+    ap.add_argument('--workload', default='synthetic1m', choices=['synthetic1m', 'flickr', 'coco'],
+                    help='synthetic1m: BASELINE.json configs[3] (the headline); flickr / coco: the retrieval evaluation of configs[1] / '
+                         'configs[2] at the SURVEY 8d S2 stand-in shapes (1 000 / 5 000 images x 5 captions, both directions)')
     ap.add_argument('--normalised', action='store_true',
                     help='second series (SURVEY 8d): rows and queries scaled to unit L2 norm (cosine scores)')
     args = ap.parse_args()
@@ -99,6 +102,8 @@ def main():
     from lightningdot_amd import _lib as L
     from lightningdot_amd.indexer import DenseFlatIndexer
     L.require_gpu()
+    if args.workload != 'synthetic1m':
+        return main_s2(args, world, rank, dev, sharded)
 
     N, Q, D, K = args.rows, args.queries, args.dim, args.k
     # ---- build this rank's shard -------------------------------------------------------------------------
@@ -256,6 +261,149 @@ def main():
         out['cpu_baseline'], out['parity_vs_cpu_fp32'] = cpu_baseline(x_local, q_all, K, args.cpu_sample_queries,
                                                                       s_np, l_np)
         out['cpu_baseline_s2'] = cpu_baseline_s2(K)
+    print(json.dumps(out), flush=True)
+    if sharded:
+        dist.destroy_process_group()
+
+
+def main_s2(args, world, rank, dev, sharded):
+    """Retrieval evaluation at the Flickr30k-1k / MSCOCO-5k shapes (BASELINE.json configs[1] / [2]; synthetic stand-in embeddings,
+    SURVEY 8d S2).  A step = the two searches of dvl/trainer.py:160-170: every caption against the image index (top-k) and every
+    image — queried once per caption like the reference does — against the caption index; embeddings resident in HBM, results on
+    the host.  With N > 1 both indexes are row-sharded and every rank owns 1/N of the queries."""
+    import torch.distributed as dist
+    from lightningdot_amd import _lib as L
+    from lightningdot_amd.indexer import DenseFlatIndexer
+    from lightningdot_amd.synthetic import s2_embeddings
+    n_img = 1000 if args.workload == 'flickr' else 5000
+    D, K, cpi = args.dim, args.k, 5
+    img, txt = s2_embeddings(n_img, D, cpi, seed=7, device=dev)
+    img_q = img.repeat_interleave(cpi, 0)
+    nq = txt.shape[0]
+    qper = (nq + world - 1) // world
+    qs = slice(rank * qper, min((rank + 1) * qper, nq))
+
+    def make(rows):
+        if not sharded:
+            ix = DenseFlatIndexer(D)
+            ix.index.set_option(L.OPT_PROFILE, 1)
+            ix.index.add(rows)
+            return ix, ix.index
+        from lightningdot_amd.sharded import ShardedFlatIndexer
+        per = (rows.shape[0] + world - 1) // world
+        lo, hi = min(rank * per, rows.shape[0]), min((rank + 1) * per, rows.shape[0])
+        sh = ShardedFlatIndexer(D)
+        sh.local.index.set_option(L.OPT_PROFILE, 1)
+        sh.index_local_shard(list(range(lo, hi)), rows[lo:hi].contiguous())
+        return sh, sh.local.index
+
+    ix_img, flat_img = make(img)
+    ix_txt, flat_txt = make(txt)
+    q_t, q_i = txt[qs].contiguous(), img_q[qs].contiguous()
+    n_mine = q_t.shape[0]
+    hs = [torch.empty((n_mine, K), dtype=torch.float32).pin_memory() for _ in range(2)]
+    hl = [torch.empty((n_mine, K), dtype=torch.int64).pin_memory() for _ in range(2)]
+
+    def one(ix, flat, q, s_out, l_out):
+        if not sharded:
+            flat.search_into(q, K, s_out, l_out)
+        else:
+            s, l = ix.search(q, K)
+            s_out.copy_(s, non_blocking=True)
+            l_out.copy_(l, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+
+    def step():
+        one(ix_img, flat_img, q_t, hs[0], hl[0])
+        one(ix_txt, flat_txt, q_i, hs[1], hl[1])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if sharded:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    prof = dict(launches=0.0, kernel_ms=0.0, flops=0.0, bytes=0.0)
+    per_dir = [0.0, 0.0]
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ta = time.perf_counter()
+        one(ix_img, flat_img, q_t, hs[0], hl[0])
+        tb = time.perf_counter()
+        p = flat_img.last_profile()
+        one(ix_txt, flat_txt, q_i, hs[1], hl[1])
+        tc = time.perf_counter()
+        per_dir[0] += tb - ta
+        per_dir[1] += tc - tb
+        for pp in (p, flat_txt.last_profile()):
+            for k_ in prof:
+                prof[k_] += pp[k_]
+    barrier()
+    dt = time.perf_counter() - t0
+    ranks_seen = 1
+    if sharded:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        ones = torch.ones(1, device=dev, dtype=torch.int32)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+    # Recall@1/5/10 against the planted pairs (dvl/trainer.py:173-188 semantics: text hit iff its image is in the top-k; image hit
+    # iff ANY of its captions is)
+    gq = torch.arange(qs.start, qs.start + n_mine)
+    gt_img = (gq // cpi).numpy()
+    l_t, l_i = hl[0].numpy(), hl[1].numpy()
+    hits = []
+    for t in (1, 5, 10):
+        hits.append(float((l_t[:, :t] == gt_img[:, None]).any(axis=1).sum()))
+        hits.append(float(((l_i[:, :t] // cpi) == gt_img[:, None]).any(axis=1).sum()))
+    th = torch.tensor(hits + [float(n_mine)], dtype=torch.float64, device=dev)
+    if sharded:
+        dist.all_reduce(th)
+    th = th.cpu().numpy()
+    if rank != 0:
+        dist.destroy_process_group()
+        return
+    tot = th[6]
+    recall = {f'recall_t2i@{t}': th[2 * i] / tot for i, t in enumerate((1, 5, 10))}
+    recall.update({f'recall_i2t@{t}': th[2 * i + 1] / tot for i, t in enumerate((1, 5, 10))})
+    flops_step = 2.0 * nq * (img.shape[0] + txt.shape[0]) * D
+    ach = (prof['flops'] / (prof['kernel_ms'] * 1e-3) / 1e12) if prof['kernel_ms'] > 0 else 0.0
+    out = {
+        'metric': 'queries/sec', 'value': 2 * nq * args.steps / dt, 'unit': 'queries/s', 'n_gpus': world, 'ranks_seen': ranks_seen,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+        'scaling': 'strong', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': f'{args.workload} retrieval evaluation shape (SURVEY S2 stand-in for BASELINE.json configs'
+                               f'[{1 if args.workload == "flickr" else 2}]): {n_img} images x {cpi} captions, {D}-d, text->image '
+                               f'({nq} queries x {img.shape[0]} rows) + image->text ({nq} un-deduplicated queries x {txt.shape[0]} '
+                               f'rows), top-{K}, exact fp32 re-score',
+                   'images': n_img, 'captions': int(txt.shape[0]), 'dim': D, 'k': K,
+                   'parallelism': f'row-sharded indexes x{world}' if world > 1 else 'single GPU'},
+        'ms_text_to_image': per_dir[0] / args.steps * 1e3, 'ms_image_to_text': per_dir[1] / args.steps * 1e3,
+        **recall,
+        'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
+                     'traffic': None, 'kernel': 'score kernels of rank 0 (both searches)',
+                     'launches_per_step': prof['launches'] / max(args.steps, 1),
+                     'kernel_ms_per_step': prof['kernel_ms'] / max(args.steps, 1),
+                     'flops_per_step': flops_step,
+                     'note': 'latency-class problem (a step is 0.05 - 1 TFLOP): the score kernels are a minority of the step, '
+                             'the exact fp32 re-score gather (HBM/L2-bound) is the largest part'},
+    }
+    if not args.no_cpu_baseline and not sharded:
+        from oracle import oracle_torch as OT
+        cores = os.cpu_count() or 1
+        cpu = {}
+        for name, qq, xx in (('t2i', txt, img), ('i2t', img_q, txt)):
+            dtc, cs, cl = OT.timed(qq.cpu(), xx.cpu(), K, cores, runs=5)
+            gl = (hl[0] if name == 't2i' else hl[1]).numpy()
+            cpu[name] = {'seconds': dtc, 'rank1_mismatches_vs_gpu': int((gl[:, 0] != cl.numpy()[:, 0]).sum())}
+        out['cpu_baseline'] = {'value': 2 * nq / (cpu['t2i']['seconds'] + cpu['i2t']['seconds']), 'unit': 'queries/s',
+                               'cores': int(cores), 'kind': 'port',
+                               'sample': 'the whole step (both searches), oracle_torch.search_blocked (torch.matmul + torch.topk, '
+                                         'fp32), median of 5 runs after warm-up', 'detail': cpu}
     print(json.dumps(out), flush=True)
     if sharded:
         dist.destroy_process_group()

@@ -2,6 +2,8 @@
 // optional L2 normalisation.  One wave per row.  Serves index add (dvl/indexer/faiss_indexers.py:77
 // IndexFlatIP.add), query ingest for search (:83) and [CLS] pooling (dvl/models/bi_encoder.py:120,188:
 // pooled = sequence_output[:, 0, :] is a strided row gather, ld_src = L*D).
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace ldot {
@@ -77,23 +79,28 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(const void* __restric
     }
 }
 
-// largest L2 norm among rows [0, n) of the padded fp32 master copy (one wave per row; atomicMax on the non-negative float's bits)
+// largest L2 norm among rows [0, n) of the padded fp32 master copy: a wave walks a strided set of rows and publishes ONE
+// atomicMax (on the non-negative float's bits) — one atomic per row serialised a 1M-row add on a single address
 __global__ __launch_bounds__(256) void row_norm_max_kernel(const float* __restrict__ x32, int64_t ld, int64_t n, int d,
                                                            float* __restrict__ out_max) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n) return;
-    const float* r = x32 + row * ld;
-    float acc = 0.f;
-    for (int c = lane; c < d; c += 64) acc = fmaf(r[c], r[c], acc);
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    float best = 0.f;
+    for (int64_t row = wave; row < n; row += nwaves) {
+        const float* r = x32 + row * ld;
+        float acc = 0.f;
+        for (int c = lane; c < d; c += 64) acc = fmaf(r[c], r[c], acc);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) atomicMax((int*)out_max, __float_as_int(sqrtf(acc)));
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        best = fmaxf(best, acc);
+    }
+    if (lane == 0 && best > 0.f) atomicMax((int*)out_max, __float_as_int(sqrtf(best)));
 }
 
 int launch_row_norm_max(const float* x32, int64_t ld, int64_t n, int d, float* out_max, hipStream_t st) {
     if (n <= 0) return LDOT_OK;
-    hipLaunchKernelGGL(row_norm_max_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, x32, ld, n, d, out_max);
+    const int64_t blocks = std::min<int64_t>((n + 3) / 4, 2048);
+    hipLaunchKernelGGL(row_norm_max_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x32, ld, n, d, out_max);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }
