@@ -9,8 +9,10 @@ search (:138-139), index sides are de-duplicated by dict key with last-write-win
 numbers of unique query ids (:179,188), ``recall_txt`` is text-query -> image retrieval (:190).
 
 What changed underneath: embeddings never leave the device (the per-vector ``.detach().cpu().numpy()`` of
-:135,138,151-152 is gone), both indexes are built from device tensors and searched by the fused HIP path.
+:135,138,151-152 is gone), both indexes are built from device tensors and searched by the fused HIP path, the searches return
+device label tensors, Recall@k is a device reduction over them and the rank dicts are lazy views (``RankDict``).
 """
+from collections.abc import Mapping
 from typing import Dict, Optional
 
 import numpy as np
@@ -26,6 +28,40 @@ def _dedup_last(ids):
     for i, k in enumerate(ids):
         pos[k] = i
     return list(pos.keys()), list(pos.values())
+
+
+class RankDict(Mapping):
+    """The reference's ``rank_*_res`` dict ({query id: [db ids of its top results]}, dvl/trainer.py:168,171) over a device label
+    tensor: key order = first occurrence of a query id, value = the result row of its LAST occurrence (dict-comprehension
+    semantics).  Id lists are materialised per key on access; ``labels`` / ``rows_of`` give the tensor view for device-side
+    consumers (recall above, hard-negative mining in hn.py)."""
+
+    def __init__(self, query_ids, labels: torch.Tensor, db_ids: list):
+        self._pos = {}
+        for i, q in enumerate(query_ids):
+            self._pos[q] = i
+        self.labels = labels                 # [nq, k] int64 row labels on the device (-1 = padding)
+        self.db_ids = db_ids
+        self._host = None
+
+    def last_rows(self, query_ids):
+        """result row (= position of the last occurrence) of every id in ``query_ids``"""
+        return [self._pos[q] for q in query_ids]
+
+    def _host_labels(self):
+        if self._host is None:
+            self._host = self.labels.cpu().numpy()      # one D2H, on the first id lookup
+        return self._host
+
+    def __getitem__(self, q):
+        ids = self.db_ids
+        return [ids[i] for i in self._host_labels()[self._pos[q]].tolist()]
+
+    def __iter__(self):
+        return iter(self._pos)
+
+    def __len__(self):
+        return len(self._pos)
 
 
 def get_indexer(bi_encoder, eval_dataloader, args, hnsw_index, img_retrieval=True):
@@ -93,23 +129,38 @@ def eval_model_on_dataloader(bi_encoder, eval_dataloader, args, img2txt: Optiona
     if no_eval:
         return total_loss, correct_ratio, (indexer_img, indexer_txt), (None, None), (None, None)
 
-    res_txt = indexer_img.search_knn(query_txt_t, num_tops)
-    rank_txt_res = {query_txt_id[i]: r[0] for i, r in enumerate(res_txt)}
-    res_img = indexer_txt.search_knn(query_img_t, num_tops)
-    rank_img_res = {query_img_id[i]: r[0] for i, r in enumerate(res_img)}
+    # Both searches stay on the device (scores / row labels [nq, num_tops]); the reference's per-result Python objects (:167-170:
+    # nq x num_tops ids per direction) are built lazily, only for the ids a caller actually indexes (RankDict).
+    _, lab_txt = indexer_img.search_knn_tensors(query_txt_t, num_tops)     # text query -> image rows
+    _, lab_img = indexer_txt.search_knn_tensors(query_img_t, num_tops)     # image query -> text rows
+    rank_txt_res = RankDict(query_txt_id, lab_txt, indexer_img.index_id_to_db_id)
+    rank_img_res = RankDict(query_img_id, lab_img, indexer_txt.index_id_to_db_id)
 
-    recall_txt = {1: 0, 5: 0, 10: 0}
-    for i, q in enumerate(query_txt_id):
-        for top in recall_txt:
-            recall_txt[top] += labels_img_name[i] in rank_txt_res[q][:top]
-    for top in recall_txt:
-        recall_txt[top] = recall_txt[top] / len(rank_txt_res)
+    # Recall@{1,5,10} (:173-188) as device reductions over the label tensors.  A result list belongs to a query ID (dict
+    # semantics, last occurrence wins); ids are unique per index, so "id in list[:top]" is "row label in labels[:, :top]"; a padding
+    # label (-1, fewer than num_tops rows) reads as the LAST id through the reference's negative indexing (faiss_indexers.py:85).
+    tops = (1, 5, 10)
+    img_row = {k: r for r, k in enumerate(img_keys)}
+    want = torch.as_tensor([img_row.get(n, -2) for n in labels_img_name], device=dev)
+    used = lab_txt[torch.as_tensor(rank_txt_res.last_rows(query_txt_id), device=dev)]
+    used = torch.where(used < 0, used.new_tensor(len(img_keys) - 1), used)
+    hit_pos = (used == want[:, None]).int().argmax(dim=1)                  # first matching position (0 when there is none)
+    hit_any = (used == want[:, None]).any(dim=1)
+    recall_txt = {top: int((hit_any & (hit_pos < top)).sum().item()) / len(rank_txt_res) for top in tops}
 
-    recall_img = {1: 0, 5: 0, 10: 0}
-    for i, q in enumerate(np.unique(query_img_id)):
-        for top in recall_img:
-            recall_img[top] += any([txt_id in rank_img_res[q][:top] for txt_id in img2txt[q]])
-    for top in recall_img:
-        recall_img[top] = recall_img[top] / len(rank_img_res)
+    uniq_img = list(np.unique(query_img_id))
+    txt_row = {k: r for r, k in enumerate(txt_keys)}
+    ncap = max([len(img2txt[q]) for q in uniq_img] + [1])
+    caps = torch.full((len(uniq_img), ncap), -2, dtype=torch.int64)
+    for i, q in enumerate(uniq_img):
+        rows = [txt_row.get(t, -2) for t in img2txt[q]]
+        caps[i, :len(rows)] = torch.as_tensor(rows, dtype=torch.int64)
+    caps = caps.to(dev)
+    used = lab_img[torch.as_tensor(rank_img_res.last_rows(uniq_img), device=dev)]
+    used = torch.where(used < 0, used.new_tensor(len(txt_keys) - 1), used)
+    recall_img = {}
+    for top in tops:
+        m = (used[:, :top, None] == caps[:, None, :]).any(dim=2).any(dim=1)
+        recall_img[top] = int(m.sum().item()) / len(rank_img_res)
 
     return total_loss, correct_ratio, (indexer_img, indexer_txt), (recall_txt, recall_img), (rank_txt_res, rank_img_res)

@@ -3,7 +3,10 @@
     sampled_hard_negatives   <- dvl/hn.py:45-66   (num_tops = min(max(2*nh+10, 50), 1000), :53)
 
 The mining search (the largest retrieval in the reference: every train caption x every train image and back, top-k
-up to 1000, every epoch) runs through ``eval_model_on_dataloader`` -> DenseFlatIndexer -> fused HIP search.
+up to 1000, every epoch) runs through ``eval_model_on_dataloader`` -> DenseFlatIndexer -> fused HIP search; the results stay
+on the device as label tensors, positives are stripped with masks and the nh negatives per query are drawn there
+(``device_hard_negatives``) — the reference's per-id Python lists (145k x 1000 objects per direction at Flickr-train scale) are
+only built when a host sampler is requested.
 """
 import collections
 import random
@@ -28,18 +31,72 @@ def postprocess_hard_negatives(hard_neg_img: Dict, hard_neg_txt: Dict, train_img
     return hard_negs_txt, hard_negs_img
 
 
-def sampled_hard_negatives(train_dataloaders_hn: Iterable, args, bi_encoder, train_img2txt, train_txt2img):
+def device_hard_negatives(rank_txt_res, rank_img_res, train_img2txt: Dict, train_txt2img: Dict, num_hard_negatives: int,
+                          generator=None):
+    """dvl/hn.py:57-63 on the device label tensors of the two mining searches (RankDict.labels):
+      * text query k: drop the positive image train_txt2img[k] from its ranked images (:57), sample nh of the rest (:63);
+      * image query k: drop its own captions train_img2txt[k] from its ranked texts (:58), sample nh of the rest (:62).
+    Sampling is uniform without replacement like random.sample — iid keys on the admissible positions, the nh largest win — from a
+    seeded device generator (the reference draws from Python's global RNG; pass ``sample=`` to sampled_hard_negatives for a
+    host-side draw in the reference's order).  Only the nh winners per query become Python objects."""
+    import torch
+    nh = num_hard_negatives
+
+    def draw(labels, banned, n_rows):
+        # labels [n, k] (-1 = padding), banned [n, m] rows that must not be drawn (-2 = unused slot)
+        ok = (labels >= 0) & ~(labels[:, :, None] == banned[:, None, :]).any(dim=2)
+        if int(ok.sum(dim=1).min().item()) < nh:
+            raise ValueError('Sample larger than population or is negative')      # what random.sample raises (dvl/hn.py:62-63)
+        keys = torch.rand(labels.shape, device=labels.device, generator=generator)
+        keys = torch.where(ok, keys, keys.new_full((), -1.0))
+        pick = keys.topk(nh, dim=1).indices
+        return torch.gather(labels, 1, pick).cpu().tolist()
+
+    dev = rank_txt_res.labels.device
+    # text side: one banned row (the positive image)
+    txt_ids = list(rank_txt_res)
+    img_row = {k: r for r, k in enumerate(rank_txt_res.db_ids)}
+    lab = rank_txt_res.labels[torch.as_tensor(rank_txt_res.last_rows(txt_ids), device=dev)]
+    banned = torch.as_tensor([[img_row.get(train_txt2img[t], -2)] for t in txt_ids], dtype=torch.int64, device=dev)
+    won = draw(lab, banned, len(img_row))
+    ids = rank_txt_res.db_ids
+    hard_negs_img = {t: [ids[r] for r in w] for t, w in zip(txt_ids, won)}
+    # image side: the image's own captions are banned
+    img_ids = list(rank_img_res)
+    txt_row = {k: r for r, k in enumerate(rank_img_res.db_ids)}
+    ncap = max([len(train_img2txt[i]) for i in img_ids] + [1])
+    banned = torch.full((len(img_ids), ncap), -2, dtype=torch.int64)
+    for j, i in enumerate(img_ids):
+        rows = [txt_row.get(t, -2) for t in train_img2txt[i]]
+        banned[j, :len(rows)] = torch.as_tensor(rows, dtype=torch.int64)
+    lab = rank_img_res.labels[torch.as_tensor(rank_img_res.last_rows(img_ids), device=dev)]
+    won = draw(lab, banned.to(dev), len(txt_row))
+    ids = rank_img_res.db_ids
+    hard_negs_txt = {i: [ids[r] for r in w] for i, w in zip(img_ids, won)}
+    return hard_negs_txt, hard_negs_img
+
+
+def sampled_hard_negatives(train_dataloaders_hn: Iterable, args, bi_encoder, train_img2txt, train_txt2img, sample: Callable = None,
+                           generator=None):
     """dvl/hn.py:45-66.  ``train_dataloaders_hn`` yields one evaluation-style dataloader per training set (the
     reference builds them itself from LMDB paths at :46-50; dataset construction is outside the hot path).
     Returns ({img_fname: [txt_id]*nh}, {txt_id: [img_fname]*nh}) exactly as consumed by ItmFastDataset.new_epoch
-    (dvl/data/itm.py:60-62)."""
+    (dvl/data/itm.py:60-62).
+
+    Default: positive stripping and sampling run on the device over the searches' label tensors (device_hard_negatives).  With
+    ``sample=`` (e.g. ``random.sample``) the reference's host-side post-processing runs instead, in the reference's order, on id
+    lists materialised from the same searches (golden G4 pins that path)."""
     hard_negs_txt_all, hard_negs_img_all = [], []
     for loader in train_dataloaders_hn:
         n_top = num_hard_sampled(args.num_hard_negatives)
         loss_hard, correct_ratio_hard, indexer_hard, recall_hard, (hard_neg_img, hard_neg_txt) = \
             eval_model_on_dataloader(bi_encoder, loader, args, train_img2txt, n_top)
-        hn_txt, hn_img = postprocess_hard_negatives(hard_neg_img, hard_neg_txt, train_img2txt, train_txt2img,
-                                                    args.num_hard_negatives)
+        if sample is None:
+            hn_txt, hn_img = device_hard_negatives(hard_neg_img, hard_neg_txt, train_img2txt, train_txt2img,
+                                                   args.num_hard_negatives, generator=generator)
+        else:
+            hn_txt, hn_img = postprocess_hard_negatives(dict(hard_neg_img), dict(hard_neg_txt), train_img2txt, train_txt2img,
+                                                        args.num_hard_negatives, sample=sample)
         hard_negs_txt_all.append(hn_txt)
         hard_negs_img_all.append(hn_img)
     hard_negs_txt_all = dict(collections.ChainMap(*hard_negs_txt_all))
