@@ -213,7 +213,7 @@ class Backbone(nn.Module):
             if gather_index is not None:
                 x = torch.gather(x, 1, gather_index.unsqueeze(-1).expand(-1, -1, x.shape[-1]))
         if torch.is_autocast_enabled():
-            bias = bias.to(torch.get_autocast_gpu_dtype())
+            bias = bias.to(torch.get_autocast_dtype('cuda'))
         return self.encoder(x, bias)
 
 

@@ -57,3 +57,91 @@ def test_train_step_with_hard_negatives_reduces_loss():
     sch = get_schedule_linear(opt, 2, 400)
     losses = [train_step(be, batches[0], args, opt, sch)[0] for _ in range(80)]
     assert np.isfinite(losses).all() and min(losses[-5:]) < losses[0] - 1.0, losses[::8]
+
+
+def test_small_tower_on_gpu_matches_reference_golden(golden_dir):
+    """a3 on the device: the seeded small UniterEncoder of golden G5 (outputs of the REFERENCE's own module) run on cuda — image
+    path and text-only path, fp32 (incl. the HIP [CLS] pooling branch taken under no_grad) and under bf16 autocast."""
+    import json
+    import os
+    from lightningdot_amd.towers import TowerConfig, TowerEncoder
+    g = np.load(os.path.join(golden_dir, 'g5_tower_small.npz'))
+    cfg = TowerConfig(**{('vocab_size' if k == 'vocab_size_or_config_json_file' else k): v
+                         for k, v in json.loads(str(g['cfg'])).items()})
+    enc = TowerEncoder(cfg, project_dim=int(g['project_dim']), with_image=True)
+    enc.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd__')}, strict=True)
+    enc = enc.cuda().eval()
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    with torch.no_grad():                                   # -> pool_cls (ldot_cls_pool) is the pooling that runs
+        seq, pooled, _ = enc(t('img_input_ids'), t('img_attn'), t('img_position_ids'), t('img_feat'), t('img_pos_feat'),
+                             None, t('gather_index'))
+        tseq, tpooled, _ = enc(t('txt_input_ids'), t('txt_attn'), t('txt_position_ids'))
+    np.testing.assert_allclose(seq.cpu().numpy(), g['img_seq'], rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(pooled.cpu().numpy(), g['img_pooled'], rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(tseq.cpu().numpy(), g['txt_seq'], rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(tpooled.cpu().numpy(), g['txt_pooled'], rtol=1e-4, atol=5e-5)
+    # with autograd on, the plain slice pools (training path): same numbers
+    seq2, pooled2, _ = enc(t('img_input_ids'), t('img_attn'), t('img_position_ids'), t('img_feat'), t('img_pos_feat'),
+                           None, t('gather_index'))
+    np.testing.assert_allclose(pooled2.detach().cpu().numpy(), g['img_pooled'], rtol=1e-4, atol=5e-5)
+    # bf16 autocast (the reference evaluates under apex fp16): loose tolerance, same ranking signal
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+        _, pooled_bf, _ = enc(t('img_input_ids'), t('img_attn'), t('img_position_ids'), t('img_feat'), t('img_pos_feat'),
+                              None, t('gather_index'))
+    ref = g['img_pooled']
+    err = np.abs(pooled_bf.float().cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err < 0.05, err
+
+
+class _StubTokenizer:
+    """whitespace tokenizer with the BERT [CLS]/[SEP] framing (the real vocabulary file is not available offline)"""
+
+    def encode(self, text):
+        return [101] + [1000 + (hash(w) % 20000) for w in text.lower().split()] + [102]
+
+
+def test_retrieve_query_single_string_over_demo_sized_index():
+    """a13 (dvl/utils.py:204-211): one string -> tokenizer -> text tower -> top-100 over an index of the demo's size
+    (123 287 rows), checked against the exact fp64 top-100 of the same query vector."""
+    from lightningdot_amd.indexer import DenseFlatIndexer
+    from lightningdot_amd.serving import retrieve_query
+    be = _tiny().eval()
+    n = 123287
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(n, 48, generator=g)
+    ix = DenseFlatIndexer(48)
+    ix.index_tensor([f'coco_{i}.npz' for i in range(n)], x.cuda())
+    args = types.SimpleNamespace(tokenizer=_StubTokenizer(), device=torch.device('cuda'))
+    res = retrieve_query(be, 'two dogs play in the snow', ix, args, top=10)
+    assert len(res) == 1 and len(res[0][0]) == 100 and res[0][1].shape == (100,)
+    ids = args.tokenizer.encode('two dogs play in the snow')
+    inp = torch.LongTensor(ids).cuda().unsqueeze(0)
+    with torch.no_grad():
+        _, qv, _ = be.txt_model(input_ids=inp, attention_mask=torch.ones_like(inp), position_ids=torch.arange(len(ids)).cuda().unsqueeze(0))
+    full = (x.double() @ qv[0].double().cpu())
+    top = torch.topk(full, 100)
+    assert res[0][0] == [f'coco_{i}.npz' for i in top.indices.tolist()]
+    np.testing.assert_allclose(res[0][1], top.values.float().numpy(), rtol=0, atol=1e-4)
+
+
+def test_eval_model_entry_point_synthetic(tmp_path, capsys):
+    """f1 (eval_itm.py:40-152): EVAL_MODEL end to end on synthetic batches — config surface, tower construction from the JSON
+    configs, both partitions, the reference's prints; small towers so that the test stays in seconds."""
+    import json
+    from lightningdot_amd.eval_itm import EVAL_MODEL
+    small = dict(vocab_size=28996, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                 max_position_embeddings=512, type_vocab_size=2, hidden_act='gelu', hidden_dropout_prob=0.1,
+                 attention_probs_dropout_prob=0.1, initializer_range=0.02)
+    (tmp_path / 'img_small.json').write_text(json.dumps(small))
+    cfg = dict(txt_model_config='bert-base-cased', img_model_config=str(tmp_path / 'img_small.json'), itm_global_file='unused.json',
+               seed=42, output_dir=str(tmp_path / 'out'), max_txt_len=60, conf_th=0.2, max_bb=100, min_bb=10, num_bb=36,
+               project_dim=64, val_txt_db='val.db', val_img_db='img/', test_txt_db='test.db', test_img_db='img/',
+               project_name='itm-debug', n_workers=0, fp16=True)
+    (tmp_path / 'eval.json').write_text(json.dumps(cfg))
+    res = EVAL_MODEL(str(tmp_path / 'eval.json'), '', synthetic_images=40)
+    out = capsys.readouterr().out
+    assert set(res) == {'dev', 'test'}
+    for part in res.values():
+        assert set(part['recall_img']) == {1, 5, 10} and set(part['recall_txt']) == {1, 5, 10}
+        assert 0.0 <= part['recall_mean'] <= 1.0 and np.isfinite(part['loss'])
+    assert 'image retrieval recall =' in out and 'txt retrieval recall =' in out and 'indexed  40 data' in out
