@@ -58,3 +58,68 @@ def s2_embeddings(n_img: int, d: int = 768, caps_per_img: int = 5, noise: float 
     img = torch.randn(n_img, d, generator=g)
     txt = img.repeat_interleave(caps_per_img, 0) + noise * torch.randn(n_img * caps_per_img, d, generator=g)
     return img.to(device), txt.to(device)
+
+
+class SyntheticItmDataset(torch.utils.data.Dataset):
+    """Stand-in for data.ItmFastDataset when the LMDB-derived databases are absent: the same item tuple (so data.itm_fast_collate
+    and the training loop run unchanged), the same ``new_epoch(hard_negatives_img, hard_negatives_txt)`` contract
+    (dvl/data/itm.py:51-68), random region features / token ids.  Caption j belongs to image j // caps_per_img and — so that a
+    model can actually learn the pairing — shares its first tokens with the other captions of that image and its regions carry an
+    image-specific offset."""
+
+    def __init__(self, n_img: int, caps_per_img: int = 2, txt_len: int = 12, num_bb: int = 10, vocab_size: int = 28996,
+                 img_dim: int = 2048, num_hard_negatives: int = 0, seed: int = 0):
+        g = torch.Generator().manual_seed(seed)
+        self.num_hard_negatives = num_hard_negatives
+        self.img_names = [f'img{i:05d}.npz' for i in range(n_img)]
+        self.ids = [f'txt{i:05d}_{c}' for i in range(n_img) for c in range(caps_per_img)]
+        self.ids_2_idx = {t: j for j, t in enumerate(self.ids)}
+        self._img_of = [self.img_names[j // caps_per_img] for j in range(len(self.ids))]
+        base = torch.randn(n_img, 1, img_dim, generator=g)
+        self._feat = {n: (base[i] + 0.5 * torch.randn(num_bb, img_dim, generator=g)) for i, n in enumerate(self.img_names)}
+        self._pos = {n: torch.rand(num_bb, 7, generator=g) for n in self.img_names}
+        key = torch.randint(1000, vocab_size, (n_img, txt_len // 2), generator=g)
+        self._tok = {}
+        for j, t in enumerate(self.ids):
+            tail = torch.randint(1000, vocab_size, (txt_len - 1 - key.shape[1],), generator=g)
+            self._tok[t] = torch.cat([torch.tensor([101]), key[j // caps_per_img], tail])
+        self.img2txts = {n: [t for t, f in zip(self.ids, self._img_of) if f == n] for n in self.img_names}
+        self.txt2img = dict(zip(self.ids, self._img_of))
+        self.datasets = [self]                    # the reference iterates train_dataset.datasets (train_itm.py:188-190)
+        self.lens = [txt_len + num_bb] * len(self.ids)
+        self.new_epoch()
+
+    def __len__(self):
+        return len(self.ids)
+
+    def new_epoch(self, hard_negatives_img=None, hard_negatives_txt=None):
+        nh = self.num_hard_negatives
+        self.neg_imgs, self.neg_txts = [], []
+        for t, f in zip(self.ids, self._img_of):
+            if hard_negatives_img is not None and nh > 0:
+                self.neg_imgs.append(hard_negatives_img[t][:nh])
+                self.neg_txts.append(hard_negatives_txt[f][:nh])
+            else:
+                self.neg_imgs.append(None)
+                self.neg_txts.append(None)
+
+    def __getitem__(self, i):
+        t, f = self.ids[i], self._img_of[i]
+        input_ids = self._tok[t]
+        nb = self._feat[f].shape[0]
+        neg_imgs = neg_txts = None
+        if self.neg_imgs[i] is not None:
+            neg_imgs = {'img_input_ids': [], 'img_feat': [], 'img_pos_feat': [], 'num_bb': [], 'attn_masks_img': [],
+                        'caption_ids': [], 'attn_masks_captions': []}
+            for n in self.neg_imgs[i]:
+                neg_imgs['img_input_ids'].append(torch.tensor([101]))
+                neg_imgs['img_feat'].append(self._feat[n])
+                neg_imgs['img_pos_feat'].append(self._pos[n])
+                neg_imgs['num_bb'].append(self._feat[n].shape[0])
+                neg_imgs['attn_masks_img'].append(torch.ones(self._feat[n].shape[0] + 1, dtype=torch.long))
+            neg_txts = {'input_ids': [], 'position_ids': [], 'attention_mask': []}
+            for n in self.neg_txts[i]:
+                neg_txts['input_ids'].append(self._tok[n])
+                neg_txts['attention_mask'].append(torch.ones(len(self._tok[n]), dtype=torch.long))
+        return (input_ids, self._feat[f], self._pos[f], torch.tensor([101]), torch.ones(len(input_ids), dtype=torch.long),
+                torch.ones(nb + 1, dtype=torch.long), t, f, neg_imgs, neg_txts, None, None)
