@@ -434,7 +434,9 @@ static int dense_scan(ldot_index* ix, int64_t q0, int64_t nqb, int64_t nqb_pad, 
 // launch over up to 4M rows (only the valid query rows are stored), a segmented select with (query, segment)
 // parallelism and one merge.  HBM-bound: the index is streamed once.
 static int dense_scan_wide(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, int kp, float* tau, hipStream_t st) {
-    const int64_t wide = (int64_t)1 << 22, seg_cols = 16384;
+    const int64_t wide = (int64_t)1 << 22;
+    // segments of 16384 columns; a short scan (the warm-up of a few-query fused search) still gets ~16 segments in flight
+    const int64_t seg_cols = std::max<int64_t>(1024, std::min<int64_t>(16384, round_up((r1 - r0 + 15) / 16, 256)));
     float* ls = (float*)ix->w_ls.p;
     int32_t* li = (int32_t*)ix->w_li.p;
     for (int64_t r = r0; r < r1; r += wide) {
@@ -442,10 +444,8 @@ static int dense_scan_wide(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, i
         const int64_t nseg = (nrows + seg_cols - 1) / seg_cols;
         int rc;
         if ((rc = ix->w_S.ensure((size_t)nq * nrows_pad * sizeof(float)))) return rc;
-        if ((rc = ix->w_part_s.ensure((size_t)(nseg + 1) * nq * kp * 4))) return rc;
-        if ((rc = ix->w_part_l.ensure((size_t)(nseg + 1) * nq * kp * 8))) return rc;
-        if ((rc = ix->w_mrg_s.ensure((size_t)nq * kp * 4))) return rc;
-        if ((rc = ix->w_mrg_l.ensure((size_t)nq * kp * 8))) return rc;
+        if ((rc = ix->w_part_s.ensure((size_t)nseg * nq * kp * 4))) return rc;
+        if ((rc = ix->w_part_l.ensure((size_t)nseg * nq * kp * 8))) return rc;
         prof_begin(ix, st, 2.0 * nq * nrows * ix->d,
                    (double)nrows * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * nrows * 4);
         rc = launch_score_dense(ix->w_q16b.p, ix->ld16(), kBM, ix->x16b, ix->ld16(), r, nrows_pad, (int)ix->ld16(),
@@ -456,13 +456,8 @@ static int dense_scan_wide(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, i
         int64_t* pl = (int64_t*)ix->w_part_l.p;
         if ((rc = launch_select_dense_parts((const float*)ix->w_S.p, nrows_pad, nq, nrows, seg_cols, r, kp, ps, pl, st)))
             return rc;
-        // the running list (earlier wide chunks) joins the merge as one more part
-        if ((rc = launch_lists_to_parts(ls, li, nq * kp, ps + nseg * nq * kp, pl + nseg * nq * kp, st))) return rc;
-        if ((rc = launch_select_lists(ps, pl, nq * kp, (int)nseg + 1, kp, nq, kp, (float*)ix->w_mrg_s.p,
-                                      (int64_t*)ix->w_mrg_l.p, st)))
-            return rc;
-        if ((rc = launch_parts_to_lists((const float*)ix->w_mrg_s.p, (const int64_t*)ix->w_mrg_l.p, nq * kp, ls, li, kp, tau, st)))
-            return rc;
+        // the segments' partial lists join the running list (earlier wide chunks) in one merge
+        if ((rc = launch_merge_parts_into_lists(ps, pl, (int)nseg, nq, kp, ls, li, tau, st))) return rc;
         ix->stats[2] += nrows * nq;
     }
     return LDOT_OK;
@@ -471,7 +466,7 @@ static int dense_scan_wide(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, i
 // (tau is always maintained: the fused scan continues from it, a sharded search exchanges it)
 static int dense_scan_all(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, int kp, float* tau, bool allow_wide,
                           hipStream_t st, int64_t q_base = 0) {
-    if (allow_wide && q_base == 0 && nq <= kBM && r1 - r0 > 2 * ix->chunk_rows)
+    if (allow_wide && q_base == 0 && nq <= kBM && (r1 - r0 > 2 * ix->chunk_rows || (nq <= 64 && r1 - r0 >= 2048)))
         return dense_scan_wide(ix, nq, r0, r1, kp, tau, st);
     // query blocks bound the dense score workspace (<= ~2 GiB at the default chunk)
     const int64_t qb_max = std::max<int64_t>(kBM, ((int64_t)1 << 29) / ix->chunk_rows / kBM * kBM);
@@ -496,15 +491,19 @@ static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_p
     int32_t* over = (int32_t*)ix->w_over.p + q0;
     int rc;
     // Pool sizing rule: a launch over `len` rows after `r` scanned rows admits ~kp*len/r candidates per query,
-    // spread over lane-private sub-pools of kPoolCap records.  Keeping the expectation <= 1024 per query
-    // (8 per sub-pool, overflow probability ~1e-11 each) bounds len <= r*1024/kp; the smallest launch is one tile
-    // per row slice, hence the warm-up covers at least 8*kp rows.
+    // spread over nsubs lane-private sub-pools of kPoolCap records.  Keeping the expectation <= 8 per sub-pool
+    // (overflow probability ~1e-11 each) bounds len <= r * 8 * nsubs / kp (1024 r / kp at 128 sub-pools; 8x that for the
+    // 1024 sub-pools of a single query block, whose search is then ONE fused launch); the smallest launch is one tile
+    // per row slice, hence the warm-up covers at least bm * nslices * kp / (8 * nsubs) rows.
     const int64_t bm = fused_tile_rows();
     const int qg = fused_query_group(nq_pad);
     const int64_t nslices = 256 / qg, nsubs = 4 * nslices;
-    const int64_t warm =
-        std::min(ix->ntotal, std::max<int64_t>(ix->warm_rows, round_up(bm * nslices * (int64_t)kp / 1024, 256)));
-    if ((rc = dense_scan_all(ix, nq, 0, warm, kp, (float*)ix->w_tau.p, false, st, q0))) return rc;
+    int64_t warm = std::max<int64_t>(ix->warm_rows, round_up(bm * nslices * (int64_t)kp / (8 * nsubs), 256));
+    // few queries (serving): launches and selects cost more than dense rows -> warm up over just enough rows for ONE fused launch
+    // to cover the rest within the pool bound (len <= r * 8 * nsubs / kp)
+    if (nq <= 64) warm = std::max(warm, round_up(ix->ntotal * kp / (kp + 8 * nsubs) + 1, 256));
+    warm = std::min(ix->ntotal, warm);
+    if ((rc = dense_scan_all(ix, nq, 0, warm, kp, (float*)ix->w_tau.p, nq <= 64, st, q0))) return rc;
     if (warm >= ix->ntotal) return LDOT_OK;
     if ((rc = ix->w_pool.ensure((size_t)nq_pad * nsubs * kPoolCap * kPoolRecBytes))) return rc;
     const size_t cnt_bytes = (size_t)nq_pad * nsubs * 4;
@@ -514,10 +513,10 @@ static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_p
     ix->pools_clean = false;   // until this scan has completed
     // (the pad queries' thresholds are +inf since init_lists: they never produce candidates)
     // few query blocks: admissions are cheap, launches are not -> let the launch length grow up to the pool bound
-    const int64_t growth = nq_pad <= kBM ? std::max<int64_t>(ix->growth_pct, 1600) : ix->growth_pct;
+    const int64_t growth = nq_pad <= kBM ? std::max<int64_t>(ix->growth_pct, 100000) : ix->growth_pct;
     int64_t r = warm;
     while (r < ix->ntotal) {
-        int64_t len = std::min<int64_t>(r * growth / 100, r * 1024 / kp);
+        int64_t len = std::min<int64_t>(r * growth / 100, r * 8 * nsubs / kp);
         len = std::max<int64_t>(len, bm * nslices);
         // whole tiles for every row slice (a launch is as slow as its busiest slice); rounding DOWN keeps the pool bound
         len = len / (bm * nslices) * (bm * nslices);
@@ -529,10 +528,24 @@ static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_p
                                  (uint4*)ix->w_pool.p, (int32_t*)ix->w_pool_cnt.p, st);
         prof_end(ix, st);
         if (rc) return rc;
-        rc = launch_select_pools((const uint4*)ix->w_pool.p, (const int32_t*)ix->w_pool_cnt.p, (int)nsubs, nq,
-                                 (int32_t)ix->ntotal, ls, li, kp, tau, over, (int32_t*)ix->w_over_sum.p,
-                                 (int32_t*)ix->w_qcnt.p + q0, st);
-        if (rc) return rc;
+        if (nq <= 64 && nsubs >= 512 && kp + 512 <= 1024) {
+            // few queries: G waves per query fold the sub-pools into partial lists, one merge joins them with the running list
+            const int G = 16;
+            if ((rc = ix->w_part_s.ensure((size_t)G * nq * kp * 4))) return rc;
+            if ((rc = ix->w_part_l.ensure((size_t)G * nq * kp * 8))) return rc;
+            float* ps = (float*)ix->w_part_s.p;
+            int64_t* pl = (int64_t*)ix->w_part_l.p;
+            if ((rc = launch_select_pools_parts((const uint4*)ix->w_pool.p, (const int32_t*)ix->w_pool_cnt.p, (int)nsubs, nq, G,
+                                                (int32_t)ix->ntotal, kp, tau, ps, pl, over, (int32_t*)ix->w_over_sum.p,
+                                                (int32_t*)ix->w_qcnt.p + q0, st)))
+                return rc;
+            if ((rc = launch_merge_parts_into_lists(ps, pl, G, nq, kp, ls, li, tau, st))) return rc;
+        } else {
+            rc = launch_select_pools((const uint4*)ix->w_pool.p, (const int32_t*)ix->w_pool_cnt.p, (int)nsubs, nq,
+                                     (int32_t)ix->ntotal, ls, li, kp, tau, over, (int32_t*)ix->w_over_sum.p,
+                                     (int32_t*)ix->w_qcnt.p + q0, st);
+            if (rc) return rc;
+        }
         ix->stats[3] += len * nq;
         r += len;
     }

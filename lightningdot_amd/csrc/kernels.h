@@ -56,6 +56,14 @@ int launch_parts_to_lists(const float* out_s, const int64_t* out_l, int64_t n, f
 int launch_select_pools(const uint4* pool, const int32_t* pool_cnt, int nsubs, int64_t nq, int32_t row_end, float* list_s,
                         int32_t* list_i, int kp, float* tau, int32_t* overflow_flags, int32_t* over_sum, int32_t* qcnt,
                         hipStream_t st);
+// few queries x many sub-pools: G waves per query write partial top-kp lists part_[sl][g][q][kp] (merged by launch_select_lists
+// together with the running list); kp + 512 <= 1024
+int launch_select_pools_parts(const uint4* pool, const int32_t* pool_cnt, int nsubs, int64_t nq, int G, int32_t row_end, int kp,
+                              const float* tau, float* part_s, int64_t* part_l, int32_t* overflow_flags, int32_t* over_sum,
+                              int32_t* qcnt, hipStream_t st);
+// parts [nparts][nq][kp] + the running list -> the new running list (+ tau), in place
+int launch_merge_parts_into_lists(const float* part_s, const int64_t* part_l, int nparts, int64_t nq, int kp, float* list_s,
+                                  int32_t* list_i, float* tau, hipStream_t st);
 // generic merge of explicit candidate lists: cand_[sl] is [nq][ncand] (labels int64, -1 = empty) -> [nq][k_out]
 int launch_select_lists(const float* cand_s, const int64_t* cand_l, int64_t part_stride, int nparts, int k_in,
                         int64_t nq, int k_out, float* out_s, int64_t* out_l, hipStream_t st);

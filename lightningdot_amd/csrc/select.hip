@@ -535,6 +535,89 @@ __global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(con
     if (lane == 0 && any_over && atomicExch(&overflow[q], 1) == 0) atomicAdd(over_sum, 1);   // queries counted once
 }
 
+// Few queries (the serving shape), many sub-pools: G waves per query, wave g folds sub-pools [g * nsubs / G, (g + 1) * nsubs / G)
+// into a partial top-kp list part_[sl][g][q][kp] (int64 labels, -1 = empty); candidates that cannot enter the running list (below
+// the query's current threshold) are dropped at the push.  select_lists_kernel then merges the G partial lists with the running
+// list.  (A single 256-thread workgroup per query walked 1024 sub-pools with a chain of dependent round trips and LDS bitonic
+// sorts: 83 us per launch at one query; this split takes the walk to one step per wave.)
+__global__ __launch_bounds__(kPoolSelThreads) void select_pools_parts_kernel(const uint4* __restrict__ pool,
+                                                                             int32_t* __restrict__ pool_cnt, int nsubs, int64_t nq,
+                                                                             int G, int32_t row_end, int kp, int cap,
+                                                                             const float* __restrict__ tau,
+                                                                             float* __restrict__ part_s, int64_t* __restrict__ part_l,
+                                                                             int32_t* __restrict__ overflow,
+                                                                             int32_t* __restrict__ over_sum,
+                                                                             int32_t* __restrict__ qcnt) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
+    const int lane = threadIdx.x & 63;
+    const int64_t q = blockIdx.x;
+    const int g = blockIdx.y;
+    WaveSelector sel;
+    sel.init(keys, kp, cap);
+    // nothing below the running list's threshold can enter it: start from that threshold (ties at the threshold score are kept,
+    // the merge orders them by row)
+    const float t0 = tau[q];
+    if (t0 > -INFINITY) sel.tau = make_key(t0, 0xfffffffeu);
+    const int per = nsubs / G, s_beg = g * per, s_end = s_beg + per;
+    int32_t* cnt = pool_cnt + q * (int64_t)nsubs;
+    const uint4* base = pool + q * (int64_t)kPoolCap * kPoolPlanes * nsubs;
+    bool over = false;
+    int nrec = 0;
+    for (int s0 = s_beg; s0 < s_end; s0 += kPoolSelThreads) {
+        const int sidx = s0 + lane;
+        int cn = sidx < s_end ? cnt[sidx] : 0;
+        if (sidx < s_end) cnt[sidx] = 0;
+        over |= cn > kPoolCap;
+        const int c = cn < kPoolCap ? cn : kPoolCap;
+        nrec += c;
+        int cm = c;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cm = max(cm, __shfl_xor(cm, o));
+        uint4 n0, n1;
+        int32_t nr;
+        auto fetch = [&](int e) {
+            const uint4* rec = base + (int64_t)e * kPoolPlanes * nsubs + sidx;
+            const bool have = e < c;
+            n0 = have ? rec[0] : make_uint4(0u, 0u, 0u, 0u);
+            n1 = have ? rec[nsubs] : make_uint4(0u, 0u, 0u, 0u);
+            nr = have ? (int32_t)rec[2 * nsubs].x : row_end;
+        };
+        if (cm > 0) fetch(0);
+        for (int e = 0; e < cm; ++e) {
+            const uint4 p0 = n0, p1 = n1;
+            const int32_t r0 = nr;
+            if (e + 1 < cm) fetch(e + 1);
+            sel.reserve(8 * kPoolSelThreads);
+            sel.push(make_key(__uint_as_float(p0.x), (uint32_t)(r0 + 0)), r0 + 0 < row_end);
+            sel.push(make_key(__uint_as_float(p0.y), (uint32_t)(r0 + 1)), r0 + 1 < row_end);
+            sel.push(make_key(__uint_as_float(p0.z), (uint32_t)(r0 + 2)), r0 + 2 < row_end);
+            sel.push(make_key(__uint_as_float(p0.w), (uint32_t)(r0 + 3)), r0 + 3 < row_end);
+            sel.push(make_key(__uint_as_float(p1.x), (uint32_t)(r0 + 8)), r0 + 8 < row_end);
+            sel.push(make_key(__uint_as_float(p1.y), (uint32_t)(r0 + 9)), r0 + 9 < row_end);
+            sel.push(make_key(__uint_as_float(p1.z), (uint32_t)(r0 + 10)), r0 + 10 < row_end);
+            sel.push(make_key(__uint_as_float(p1.w), (uint32_t)(r0 + 11)), r0 + 11 < row_end);
+        }
+    }
+    sel.compact();
+    WaveSelector::wave_sync();
+    float* ps = part_s + ((int64_t)g * nq + q) * kp;
+    int64_t* pl = part_l + ((int64_t)g * nq + q) * kp;
+    for (int e = lane; e < kp; e += 64) {
+        if (e < sel.n) {
+            const uint64_t k = sel.keys[e];
+            ps[e] = desc_key_to_float((uint32_t)(k >> 32));
+            pl[e] = (int64_t)(uint32_t)(k & 0xffffffffu);
+        } else {
+            ps[e] = LDOT_PAD_SCORE;
+            pl[e] = LDOT_PAD_LABEL;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nrec += __shfl_xor(nrec, o);
+    if (lane == 0 && qcnt) atomicAdd(&qcnt[q], nrec);
+    if (__any(over) && lane == 0 && atomicExch(&overflow[q], 1) == 0) atomicAdd(over_sum, 1);
+}
+
 // Few queries (<= one query block, the serving shape): one 256-thread workgroup per query instead of one wave, so that
 // the counters and entry levels of 512 sub-pools are in flight per step (the one-wave walk is a chain of dependent
 // global round trips when there is nothing else on the chip to hide them).
@@ -661,6 +744,47 @@ __global__ __launch_bounds__(kSelThreads) void select_lists_kernel(const float* 
     }
 }
 
+// parts [nparts][nq][kp] (int64 labels, -1 = empty) + the running list (int32 rows, -1 = empty) -> the new running list and its
+// threshold, in place: lists_to_parts + select_lists + parts_to_lists of the few-query paths in one launch
+__global__ __launch_bounds__(kSelThreads) void merge_parts_into_lists_kernel(const float* __restrict__ part_s,
+                                                                             const int64_t* __restrict__ part_l, int nparts,
+                                                                             int64_t nq, int kp, int cap, float* __restrict__ list_s,
+                                                                             int32_t* __restrict__ list_i, float* __restrict__ tau) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
+    __shared__ int count;
+    const int64_t q = blockIdx.x;
+    Selector sel;
+    sel.init(keys, &count, kp, cap);
+    float* ls = list_s + q * kp;
+    int32_t* li = list_i + q * kp;
+    sel.load_list(ls, li);
+    const int total = nparts * kp;
+    for (int s0 = 0; s0 < total; s0 += kSelThreads) {
+        sel.reserve(kSelThreads);
+        const int sl = s0 + threadIdx.x;
+        bool valid = sl < total;
+        uint64_t key = kEmptyKey;
+        if (valid) {
+            const int64_t off = ((int64_t)(sl / kp) * nq + q) * kp + sl % kp;
+            const int64_t l = part_l[off];
+            valid = l >= 0;
+            if (valid) key = make_key(part_s[off], (uint32_t)l);
+        }
+        sel.push(key, valid);
+    }
+    sel.finish(ls, li, tau ? tau + q : nullptr);
+}
+
+int launch_merge_parts_into_lists(const float* part_s, const int64_t* part_l, int nparts, int64_t nq, int kp, float* list_s,
+                                  int32_t* list_i, float* tau, hipStream_t st) {
+    if (nq <= 0) return LDOT_OK;
+    const int cap = select_cap(kp, 1024, kSelThreads);
+    hipLaunchKernelGGL(merge_parts_into_lists_kernel, dim3((unsigned)nq), dim3(kSelThreads), (size_t)cap * 8, st, part_s, part_l,
+                       nparts, nq, kp, cap, list_s, list_i, tau);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
 int launch_init_lists(float* list_s, int32_t* list_i, int64_t n, float* tau, int64_t nq, int64_t nq_pad, hipStream_t st) {
     const int64_t m = std::max(n, tau ? nq_pad : (int64_t)0);
     if (m <= 0) return LDOT_OK;
@@ -747,6 +871,18 @@ int launch_select_pools(const uint4* pool, const int32_t* pool_cnt, int nsubs, i
         hipLaunchKernelGGL((select_pools_kernel<4, 1>), dim3((unsigned)nq), dim3(kPoolSelThreads), (size_t)cap * 8, st,
                            pool, (int32_t*)pool_cnt, nsubs, nq, row_end, list_s, list_i, kp, cap, tau, overflow_flags, over_sum, qcnt, dbg);
     }
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+int launch_select_pools_parts(const uint4* pool, const int32_t* pool_cnt, int nsubs, int64_t nq, int G, int32_t row_end, int kp,
+                              const float* tau, float* part_s, int64_t* part_l, int32_t* overflow_flags, int32_t* over_sum,
+                              int32_t* qcnt, hipStream_t st) {
+    if (nq <= 0) return LDOT_OK;
+    const int cap = select_cap(kp, 1024, 8 * kPoolSelThreads);
+    LDOT_REQUIRE(cap <= WaveSelector::kRegKeys * 64 && nsubs % G == 0, LDOT_EINVAL, "select_pools_parts: unsupported shape");
+    hipLaunchKernelGGL(select_pools_parts_kernel, dim3((unsigned)nq, (unsigned)G), dim3(kPoolSelThreads), (size_t)cap * 8, st, pool,
+                       (int32_t*)pool_cnt, nsubs, nq, G, row_end, kp, cap, tau, part_s, part_l, overflow_flags, over_sum, qcnt);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }
