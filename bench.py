@@ -63,7 +63,7 @@ def main():
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to exercise the N > 1 '
                                                       'bookkeeping on a one-GPU box together with --all-on-device0)')
     ap.add_argument('--all-on-device0', action='store_true', help='debug: every rank uses cuda:0')
-    ap.add_argument('--cpu-sample-queries', type=int, default=2048)
+    ap.add_argument('--cpu-sample-queries', type=int, default=512)
     ap.add_argument('--workload', default='synthetic1m', choices=['synthetic1m', 'flickr', 'coco'],
                     help='synthetic1m: BASELINE.json configs[3] (the headline); flickr / coco: the retrieval evaluation of configs[1] / '
                          'configs[2] at the SURVEY 8d S2 stand-in shapes (1 000 / 5 000 images x 5 captions, both directions)')
@@ -244,6 +244,7 @@ def main():
         try:
             t = json.load(open(tpath))
             out['roofline']['traffic'] = t['hbm_bytes_per_launch']
+            out['roofline']['traffic_source'] = 'offline constant: measured with rocprofv3 PMC passes of this command (profiles/traffic.json), not in this run'
             out['roofline']['traffic_note'] = t['note']
         except Exception:
             pass
@@ -260,7 +261,7 @@ def main():
     if not args.no_cpu_baseline and not sharded:
         out['cpu_baseline'], out['parity_vs_cpu_fp32'] = cpu_baseline(x_local, q_all, K, args.cpu_sample_queries,
                                                                       s_np, l_np)
-        out['cpu_baseline_s2'] = cpu_baseline_s2(K)
+        # (the CPU figures at the S2 shapes are part of `bench.py --workload flickr|coco`: each of those lines carries its own)
     print(json.dumps(out), flush=True)
     if sharded:
         dist.destroy_process_group()
@@ -397,13 +398,13 @@ def main_s2(args, world, rank, dev, sharded):
         cores = os.cpu_count() or 1
         cpu = {}
         for name, qq, xx in (('t2i', txt, img), ('i2t', img_q, txt)):
-            dtc, cs, cl = OT.timed(qq.cpu(), xx.cpu(), K, cores, runs=5)
+            dtc, cs, cl = OT.timed(qq.cpu(), xx.cpu(), K, cores, runs=3)
             gl = (hl[0] if name == 't2i' else hl[1]).numpy()
             cpu[name] = {'seconds': dtc, 'rank1_mismatches_vs_gpu': int((gl[:, 0] != cl.numpy()[:, 0]).sum())}
         out['cpu_baseline'] = {'value': 2 * nq / (cpu['t2i']['seconds'] + cpu['i2t']['seconds']), 'unit': 'queries/s',
                                'cores': int(cores), 'kind': 'port',
                                'sample': 'the whole step (both searches), oracle_torch.search_blocked (torch.matmul + torch.topk, '
-                                         'fp32), median of 5 runs after warm-up', 'detail': cpu}
+                                         'fp32), median of 3 runs after warm-up', 'detail': cpu}
     print(json.dumps(out), flush=True)
     if sharded:
         dist.destroy_process_group()
@@ -450,25 +451,6 @@ def cpu_baseline(x_dev, q_dev, k, nsample, gpu_scores, gpu_labels):
               'max_abs_dscore': float(np.abs(gs.astype(np.float64) - cs.astype(np.float64)).max()),
               'score_scale': scale, 'tolerance': '1e-3 on scores, exact rank-1 (BASELINE.json north_star)'}
     return base, parity
-
-
-def cpu_baseline_s2(k):
-    """CPU figures at the S2 shapes (Flickr-1k and COCO-5k stand-ins, both directions with the reference's
-    un-deduplicated image queries), same scorer and protocol as cpu_baseline; a few seconds of CPU work in all."""
-    from oracle import oracle_torch as OT
-    from lightningdot_amd.synthetic import s2_embeddings
-    cores = os.cpu_count() or 1
-    out = {'unit': 'queries/s', 'cores': int(cores), 'kind': 'port',
-           'scorer': 'faiss.IndexFlatIP' if OT.have_faiss() else 'oracle_torch.search_blocked', 'runs': 5, 'shapes': {}}
-    for name, n_img in (('flickr', 1000), ('coco', 5000)):
-        img, txt = s2_embeddings(n_img, 768, seed=7)
-        img_q = img.repeat_interleave(5, 0)                     # the reference queries once per caption (dvl/trainer.py:130-154)
-        for direction, qq, xx in (('t2i', txt, img), ('i2t', img_q, txt)):
-            dt, _, _ = OT.timed(qq, xx, k, cores, runs=5)
-            dt1, _, _ = OT.timed(qq[:256], xx, k, 1, runs=3)
-            out['shapes'][f'{name}_{direction}'] = {'queries': int(qq.shape[0]), 'rows': int(xx.shape[0]),
-                                                    'value': qq.shape[0] / dt, 'value_1thread': 256 / dt1}
-    return out
 
 
 if __name__ == '__main__':

@@ -1,11 +1,19 @@
 #!/bin/bash
-# Round evidence: GPU tests, bench JSON, rocprofv3 kernel stats, PMC passes (no TA_* counters), vendor GEMM reference.
+# Round evidence in ONE gpurun call: GPU tests, smoke, headline bench (+ CPU baselines), S2-shape benches, serving latency, MFMA ceiling
+# microbenchmark, rocprofv3 kernel stats of the bench command, PMC passes (separate --pmc runs, --kernel-trace only), per-pass timeline,
+# 2-rank dry run on one GPU, vendor GEMM reference.
 # usage (GPU box): tools/evidence.sh <tag>   -> gpurun_out/ev_<tag>/
 T=${1:-ev}; O=$GRAFT_REPO_ROOT/gpurun_out/ev_$T; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
 timeout 300 python -c 'import __graft_entry__ as g; g.smoke(); print("smoke ok")' > $O/smoke.log 2>&1
-timeout 600 python bench.py --steps 5 --warmup 2 > $O/bench.json 2> $O/bench.err
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+timeout 600 python bench.py --steps 20 --warmup 5 --normalised --no-cpu-baseline > $O/bench_normalised.json 2>> $O/bench.err
+timeout 600 python bench.py --workload flickr --steps 50 --warmup 5 > $O/bench_flickr.json 2>> $O/bench.err
+timeout 600 python bench.py --workload coco --steps 20 --warmup 3 > $O/bench_coco.json 2>> $O/bench.err
+timeout 600 python bench.py --gpus 2 --all-on-device0 --backend gloo --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_2ranks_gloo_one_gpu.json 2>> $O/bench.err
+timeout 300 python tools/serving_latency.py > $O/serving_latency.jsonl 2>> $O/bench.err
+[ -x tools/bin/mfma_ceiling ] && timeout 300 tools/bin/mfma_ceiling 12 > $O/mfma_ceiling.txt 2>&1
 timeout 300 python tools/gemm_ref.py > $O/vendor_gemm.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt
@@ -15,4 +23,5 @@ cd $GRAFT_REPO_ROOT
 for g in "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES" "TCC_HIT TCC_MISS TCC_REQ"; do
   bash tools/pmc2.sh "$g" >> $O/pmc.txt 2>&1
 done
-tail -3 $O/pytest_gpu.log; cat $O/smoke.log | tail -1; cat $O/bench.json; cat $O/pmc.txt
+bash tools/timeline.sh > /dev/null 2>&1; cp gpurun_out/timeline.txt $O/timeline.txt 2>/dev/null
+tail -3 $O/pytest_gpu.log; cat $O/smoke.log | tail -1; cut -c1-600 $O/bench.json; cat $O/pmc.txt
