@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
                     } while (l_t >= ntiles);
                     sb.rsrc = ring_make_rsrc_n(Q16 + (int64_t)(qsub + l_q * qg) * kRBN * ldq_b, kRBN * ldq_b);
                 }
-                sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)((VAR & 64) ? (l_t & 31) : l_t) * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
+                sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)((VAR & 512) ? (l_t & 28) : (VAR & 64) ? (l_t & 31) : l_t) * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
             }
         }
     };
@@ -391,6 +391,7 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     if (variant == 128) rk = score_filter_r6_kernel<128>;
     if (variant == 144) rk = score_filter_r6_kernel<144>;
     if (variant == 256) rk = score_filter_r6_kernel<256>;
+    if (variant == 528) rk = score_filter_r6_kernel<528>;   // 16 + 512: the 4 row streams of an XCD share ONE tile (everything L2-resident)
 #endif
     LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<6>::kLds));
     const int qg = fused_query_group(nq_pad);
