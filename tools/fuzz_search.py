@@ -15,8 +15,8 @@ from util import assert_topk_matches
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed)
-N_CHOICES = [1, 5, 255, 256, 257, 1000, 4095, 4097, 12288, 32767, 32768, 33000, 50000, 98304, 110593, 200000]
-Q_CHOICES = [1, 2, 63, 64, 255, 256, 257, 511, 1024, 1500, 2049, 4096]
+N_CHOICES = [1, 5, 255, 256, 257, 1000, 4095, 4097, 12288, 16384, 20000, 32767, 32768, 33000, 50000, 98304, 110593, 200000]
+Q_CHOICES = [1, 2, 63, 64, 65, 255, 256, 257, 511, 1024, 1500, 2049, 4096, 16385, 20000]   # > 16384: the fused scan's query chunks
 D_CHOICES = [8, 32, 63, 64, 100, 128, 768, 1024]
 K_CHOICES = [1, 5, 10, 50, 100, 128, 500, 1000, 2048]
 fails = 0
