@@ -484,3 +484,55 @@ def test_last_stats_counts_filter_records(L):
     assert st['fused_pairs'] > 0 and st['overflowed_queries'] == 0
     # every query needs at least k' - (warm-up hits) records to fill its list; far fewer than one per scored pair
     assert 600 * 5 < st['fused_candidates'] < st['fused_pairs'] // 20, st
+
+
+def test_search_into_pinned_and_pageable_outputs_agree(L):
+    """Host outputs: pinned (device-mapped) buffers are written by the re-score kernel directly, pageable ones through a staging
+    buffer — same results; shape / dtype of the buffers is checked."""
+    import torch
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((40000, 128)).astype(np.float32)
+    q, g = planted_queries(x, 700)
+    ix = _index(x)
+    qd = torch.from_numpy(q).cuda()
+    ps = torch.empty((700, 20), dtype=torch.float32).pin_memory()
+    pl = torch.empty((700, 20), dtype=torch.int64).pin_memory()
+    ix.search_into(qd, 20, ps, pl)
+    ns, nl = np.empty((700, 20), np.float32), np.empty((700, 20), np.int64)
+    ix.search_into(qd, 20, ns, nl)
+    np.testing.assert_array_equal(ps.numpy(), ns)
+    np.testing.assert_array_equal(pl.numpy(), nl)
+    assert_topk_matches(q, x, ns, nl, 20)
+    with pytest.raises(ValueError):
+        ix.search_into(qd, 20, np.empty((700, 19), np.float32), nl)
+    with pytest.raises(ValueError):
+        ix.search_into(qd, 20, ns.astype(np.float64), nl)
+
+
+def test_error_paths_of_the_new_entry_points(L, tmp_path):
+    import ctypes
+    rng = np.random.default_rng(32)
+    x = rng.standard_normal((300, 32)).astype(np.float32)
+    ix = _index(x)
+    ix.search(x[:4], 5)
+    with pytest.raises(L.LdotError) as e:            # LDOT_OPT_VERIFY is off
+        ix.unproven(4)
+    assert e.value.code == -5
+    # a corrupt index file (header row count does not match the payload) is rejected, not allocated
+    from lightningdot_amd.indexer import FlatIPIndex
+    p = str(tmp_path / 'ix.bin')
+    ix.save(p)
+    raw = bytearray(open(p, 'rb').read())
+    raw[12:20] = (10 ** 12).to_bytes(8, 'little')    # n
+    open(p, 'wb').write(raw)
+    with pytest.raises(L.LdotError) as e:
+        FlatIPIndex.load(p)
+    assert e.value.code == -4
+    # search_finish without a pending search_begin
+    with pytest.raises(L.LdotError):
+        ix.search_finish()
+    # a tensor on the wrong device is refused before it reaches the library
+    import torch
+    if torch.cuda.device_count() > 1:
+        with pytest.raises(ValueError):
+            ix.search_tensors(torch.zeros(2, 32, device='cuda:1'), 3)
