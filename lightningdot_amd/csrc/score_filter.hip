@@ -191,8 +191,20 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     // the pieces of a slab ride between the MFMAs of two k-steps: pieces 0..2 after row blocks 1, 3, 5 of the k-step that follows
     // the barrier (the stage they overwrite was vacated there), pieces 3, 4 after row blocks 1, 3 of the next k-step (before the
     // next barrier's counted vmcnt, which therefore still sees whole slabs)
-    bool defer_burst = false;
+    bool defer_burst = false, defer_burst_b = false;
     auto hook_post = [&](int mr) {
+        if (VAR & 8192) return;   // ablation: the burst BEFORE the barrier (end of the k-step that precedes it), see hook_pre
+        if (VAR & 2048) {     // ablation: the burst at the START of the k-step that follows the barrier
+            if (mr == 0 && !defer_burst) issue();
+            return;
+        }
+        if (VAR & 4096) {     // ablation: row-panel pieces after this k-step, query-panel pieces after the next one
+            if (mr == MR - 1 && !defer_burst) {
+#pragma unroll
+                for (int j = 0; j < Geo::kALoads; ++j) piece(j);
+            }
+            return;
+        }
         if (!(VAR & 128)) {   // default: the whole slab as a burst after the k-step (VAR & 128: piece by piece, see below)
             if (mr == MR - 1 && !defer_burst) issue();
             return;
@@ -200,6 +212,18 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
         if (mr & 1) piece(mr >> 1);
     };
     auto hook_pre = [&](int mr) {
+        if (VAR & 8192) {
+            if (mr == MR - 1) issue();
+            return;
+        }
+        if (VAR & 4096) {
+            if (mr == MR - 1 && !defer_burst_b) {
+                piece(Geo::kALoads);
+                piece(Geo::kALoads + 1);
+                advance();
+            }
+            return;
+        }
         if (!(VAR & 128)) return;
         if (mr == 1) piece(3);
         if (mr == 3) {
@@ -250,6 +274,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
                 const char* a_w = st0 + c.wm * (32 * MR * 64) + (c.frag_off0 ^ 32);
                 const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (MODE == 2 && !(VAR & 1)) filter_hazard_cover();
+                if (MODE == 2) defer_burst_b = true;    // (VAR & 4096 only: the explicit issue() below carries the whole slab)
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr) {
                     if (MODE == 2 && !(VAR & 1)) {
@@ -263,7 +288,8 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
                     if (MODE == 2) hook_pre(mr);   // (MODE 1 = the very first slab: no slab is half issued yet)
                     if (MODE == 2 && !(VAR & 1)) __builtin_amdgcn_sched_barrier(0);
                 }
-                if (MODE == 2 && !(VAR & 256)) issue();   // the burst the previous (MODE 3) slab deferred
+                if (MODE == 2) defer_burst_b = false;
+                if (MODE == 2 && !(VAR & 256) && !(VAR & 8192)) issue();   // the burst the previous slab deferred
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -315,7 +341,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     for (int j = 0; j < ntile_total; ++j) {
 #pragma unroll 1
         for (int kk = 1; kk < nk; ++kk) {
-            defer_burst = !(VAR & 256) && kk == nk - 1 && j + 1 < ntile_total;   // (uniform) see MODE 2
+            defer_burst = !(VAR & 256) && !(VAR & 8192) && kk == nk - 1 && j + 1 < ntile_total;   // (uniform) see MODE 2
             slab(M0{});
         }
         defer_burst = false;
@@ -391,7 +417,13 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     if (variant == 128) rk = score_filter_r6_kernel<128>;
     if (variant == 144) rk = score_filter_r6_kernel<144>;
     if (variant == 256) rk = score_filter_r6_kernel<256>;
-    if (variant == 528) rk = score_filter_r6_kernel<528>;   // 16 + 512: the 4 row streams of an XCD share ONE tile (everything L2-resident)
+    if (variant == 528) rk = score_filter_r6_kernel<528>;
+    if (variant == 4096) rk = score_filter_r6_kernel<4096>;
+    if (variant == 4112) rk = score_filter_r6_kernel<4112>;
+    if (variant == 8192) rk = score_filter_r6_kernel<8192>;
+    if (variant == 8208) rk = score_filter_r6_kernel<8208>;
+    if (variant == 2048) rk = score_filter_r6_kernel<2048>;
+    if (variant == 2064) rk = score_filter_r6_kernel<2064>;   // 16 + 512: the 4 row streams of an XCD share ONE tile (everything L2-resident)
 #endif
     LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<6>::kLds));
     const int qg = fused_query_group(nq_pad);
