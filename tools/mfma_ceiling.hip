@@ -12,6 +12,9 @@
 //   feed      0  : register-resident fragments (MFMA only: the power ceiling of the pipe itself)
 //             1  : + ds_read_b128 fragment stream from an LDS ring image (no global loads)
 //             2  : + direct-to-LDS slab loads (buffer_load ... lds) through the 4-stage ring, counted vmcnt + one barrier per slab
+//             3/4: 2 without the loads / without the barrier;  5: the loads spread between the MFMAs;  6: the two waves of a SIMD
+//                  take turns issuing the pair's 10 pieces (measured: 78.6 % pipe issue vs 80.2 % for the plain burst — the idle
+//                  partner still meets the issuing one at the slab barrier)
 //   data      R  : N(0,1) random bf16 operands;  Z: all-zero operands (the DVFS give-back the guide describes)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -76,6 +79,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void ceiling_kernel(const char* __
         for (int j = 0; j < G::kLoads; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (rg_lptr_t)(st + (j * NW + c.wave) * 1024), 16, vo,
                                                      so + (j * NW + c.wave) * 1024, 0, 0);
+        ++issued;
+        so += kStage;
+        if (so >= so_end) so = 0;
+    };
+    // FEED 6: the two waves that share a SIMD (w and w ^ 4) take turns: on even slabs the waves 0..3 issue ALL 10 pieces of the pair, on
+    // odd slabs the waves 4..7 — one wave of every SIMD keeps the matrix pipe busy while its partner is in the VMEM issue
+    auto issue_alt = [&]() {
+        char* st = smem + (issued & 3) * kStage;
+        if ((c.wave >> 2) == (issued & 1)) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < G::kLoads; ++j) {
+                    const int wt = (c.wave & 3) + 4 * h;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (rg_lptr_t)(st + (j * NW + wt) * 1024), 16, vo, so + (j * NW + wt) * 1024, 0, 0);
+                }
+        }
         ++issued;
         so += kStage;
         if (so >= so_end) so = 0;
@@ -160,7 +180,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void ceiling_kernel(const char* __
         const char* st1 = smem + ((s + 1) & 3) * kStage;
         step(0, st0, c.frag_off0 ^ 32);
         __builtin_amdgcn_sched_barrier(0);
-        if (FEED == 2 || FEED == 3 || FEED == 5) {
+        if (FEED == 2 || FEED == 3 || FEED == 5 || FEED == 6) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (FEED != 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::kLoads) : "memory");
             __builtin_amdgcn_s_barrier();
@@ -168,6 +188,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void ceiling_kernel(const char* __
         step(1, st1, c.frag_off0);
         __builtin_amdgcn_sched_barrier(0);
         if (FEED == 2 || FEED == 4) issue();
+        if (FEED == 6) issue_alt();
     }
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
     const uint64_t t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
@@ -258,6 +279,8 @@ int main(int argc, char** argv) {
         run<4, 4>("W1 ds_read+dma, no barrier random", src, region, sink, ticks, target_ms);
         run<8, 5>("W2 full, dma interleaved   random", src, region, sink, ticks, target_ms);
         run<4, 5>("W1 full, dma interleaved   random", src, region, sink, ticks, target_ms);
+        run<8, 6>("W2 full, SIMD partners alternate random", src, region, sink, ticks, target_ms);
+        run<8, 6>("W2 full, SIMD partners alternate zeros", zsrc, region, sink, ticks, target_ms);
         run<8, 5>("W2 full, dma interleaved   zeros", zsrc, region, sink, ticks, target_ms);
         run<4, 5>("W1 full, dma interleaved   zeros", zsrc, region, sink, ticks, target_ms);
     }
