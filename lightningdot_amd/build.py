@@ -76,6 +76,22 @@ def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> 
     return LIB
 
 
+def build_tools(verbose: bool = True) -> str:
+    """measurement tools with device code (not part of the product library): tools/bin/mfma_ceiling"""
+    root = os.path.dirname(PKG)
+    src = os.path.join(root, 'tools', 'mfma_ceiling.hip')
+    out = os.path.join(root, 'tools', 'bin', 'mfma_ceiling')
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if _stale(out, [src, os.path.join(CSRC, 'gemm_ring.h')]):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I', CSRC, src, '-o', out]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == '__main__':
     build(force='--force' in sys.argv, ablation='--ablation' in sys.argv)
+    if '--tools' in sys.argv:
+        print(build_tools())
     print(LIB)
