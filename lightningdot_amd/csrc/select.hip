@@ -387,6 +387,143 @@ __global__ __launch_bounds__(64 * QPW) void select_dense_wave_kernel(const float
     sel.finish(ls, li, tau ? tau + q : nullptr);
 }
 
+// dense source, SHORT rows (ncols <= 64 * NV, k' <= 256): the whole row of scores sits in the wave's registers (NV per lane)
+// together with the running list (4 per lane) and the k'-th best key is found by a bitwise binary search whose counts are pure VALU work
+// (per-lane compare-and-count over the registers, one DPP wave reduction per bit) — no ballots, no LDS, no scalar-unit traffic.  Used for
+// rows of at most 1024 columns (see launch_select_dense for the measurements that set this limit).
+// Output list = a SET (valid entries first), tau = its k'-th best score.
+template <int NV, int QPW>
+__global__ __launch_bounds__(64 * QPW) void select_dense_regs_kernel(const float* __restrict__ S, int64_t lds_elems, int64_t nq,
+                                                                     int ncols, int64_t idx_base, float* __restrict__ list_s,
+                                                                     int32_t* __restrict__ list_i, int kp, float* __restrict__ tau) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * QPW + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    float* ls = list_s + q * kp;
+    int32_t* li = list_i + q * kp;
+    const float* row = S + q * lds_elems;
+    // chunk values: register r holds column (r / 4) * 256 + lane * 4 + r % 4 (coalesced float4 loads); invalid -> all-ones key
+    uint32_t hi[NV + 4];
+    uint32_t llo[4];   // rows of the running-list entries (chunk rows are implied by the column)
+#pragma unroll
+    for (int v = 0; v < NV / 4; ++v) {
+        const int c0 = v * 256 + lane * 4;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (c0 + 3 < ncols) {
+            x = *(const f32x4*)(row + c0);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c0 + e < ncols) x[e] = row[c0 + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hi[v * 4 + e] = (c0 + e < ncols) ? desc_key(x[e]) : 0xffffffffu;
+    }
+    int nvalid_l = 0;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) nvalid_l += hi[r] != 0xffffffffu;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int p = e * 64 + lane;
+        const int32_t r = p < kp ? li[p] : -1;
+        hi[NV + e] = r >= 0 ? desc_key(ls[p]) : 0xffffffffu;
+        llo[e] = (uint32_t)r;
+        nvalid_l += r >= 0;
+    }
+    // wave-wide integer sum in 7 DPP adds + one readlane (quad swaps, row mirrors, row broadcasts: the total lands in lane 63) —
+    // the bpermute-based __shfl_xor reduction costs ~600 cycles per call, and the search calls it once per bit
+    auto wave_sum = [&](int v) {
+        v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+        v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+        v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);   // row_half_mirror
+        v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);   // row_mirror  -> every lane: its row's sum
+        v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast15 into rows 1 and 3
+        v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast31 into rows 2 and 3
+        return __builtin_amdgcn_readlane(v, 63);
+    };
+    const int nvalid = wave_sum(nvalid_l);
+    uint32_t Th = 0xfffffffeu, Tl = 0xfffffffeu;   // "everything valid"
+    if (nvalid > kp) {
+        // Th = kp-th smallest score word (with multiplicity)
+        Th = 0;
+        for (int b = 31; b >= 0; --b) {
+            const uint32_t trial = Th | ((1u << b) - 1u);
+            int c = 0;
+#pragma unroll
+            for (int r = 0; r < NV + 4; ++r) c += hi[r] <= trial;
+            if (wave_sum(c) < kp) Th |= (1u << b);
+        }
+        int c_lt = 0, c_eq = 0;
+#pragma unroll
+        for (int r = 0; r < NV + 4; ++r) {
+            c_lt += hi[r] < Th;
+            c_eq += hi[r] == Th;
+        }
+        c_lt = wave_sum(c_lt);
+        c_eq = wave_sum(c_eq);
+        if (c_lt + c_eq > kp) {   // exact score ties straddle the cut: keep the kp - c_lt lowest rows among them
+            const int need = kp - c_lt;
+            Tl = 0;
+            for (int b = 31; b >= 0; --b) {
+                const uint32_t trial = Tl | ((1u << b) - 1u);
+                int c = 0;
+                uint32_t lo0 = (uint32_t)idx_base + (uint32_t)lane * 4u;
+                asm volatile("" : "+v"(lo0));   // (rare path: keep the NV row numbers out of registers — no hoisting out of the bit loop)
+#pragma unroll
+                for (int r = 0; r < NV; ++r)
+                    c += hi[r] == Th && lo0 + (uint32_t)((r / 4) * 256 + r % 4) <= trial;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c += hi[NV + e] == Th && llo[e] <= trial;
+                if (wave_sum(c) < need) Tl |= (1u << b);
+            }
+        }
+    }
+    // compaction: lane-exclusive prefix of the per-lane survivor counts, then every lane writes its survivors
+    int mine = 0;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+        const uint32_t lo = (uint32_t)(idx_base + (r / 4) * 256 + lane * 4 + r % 4);
+        mine += hi[r] != 0xffffffffu && (hi[r] < Th || (hi[r] == Th && lo <= Tl));
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mine += hi[NV + e] != 0xffffffffu && (hi[NV + e] < Th || (hi[NV + e] == Th && llo[e] <= Tl));
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    int pos = incl - mine;
+    const int total = __shfl(incl, 63);
+    // the list entries are read before anything is written (registers), so the in-place update is safe
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (hi[NV + e] != 0xffffffffu && (hi[NV + e] < Th || (hi[NV + e] == Th && llo[e] <= Tl))) {
+            if (pos < kp) {
+                ls[pos] = desc_key_to_float(hi[NV + e]);
+                li[pos] = (int32_t)llo[e];
+            }
+            ++pos;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+        const uint32_t lo = (uint32_t)(idx_base + (r / 4) * 256 + lane * 4 + r % 4);
+        if (hi[r] != 0xffffffffu && (hi[r] < Th || (hi[r] == Th && lo <= Tl))) {
+            if (pos < kp) {
+                ls[pos] = desc_key_to_float(hi[r]);
+                li[pos] = (int32_t)lo;
+            }
+            ++pos;
+        }
+    }
+    for (int e = total + lane; e < kp; e += 64) {
+        ls[e] = LDOT_PAD_SCORE;
+        li[e] = -1;
+    }
+    if (tau && lane == 0) tau[q] = (total >= kp) ? desc_key_to_float(Th) : -INFINITY;
+}
+
 // segmented dense source (few queries x many rows): blockIdx.y = segment of `seg_cols` columns; no running list, the
 // partial top-kp of the segment goes to part_[sl][seg][q][kp] with int64 labels (merged by select_lists_kernel)
 __global__ __launch_bounds__(kSelThreads) void select_dense_parts_kernel(const float* __restrict__ S, int64_t lds_elems,
@@ -797,6 +934,16 @@ int launch_init_lists(float* list_s, int32_t* list_i, int64_t n, float* tau, int
 int launch_select_dense(const float* S, int64_t lds_elems, int64_t nq, int64_t ncols, int64_t idx_base,
                         float* list_s, int32_t* list_i, int kp, float* tau, hipStream_t st) {
     if (nq <= 0) return LDOT_OK;
+    if (kp <= 256 && ncols <= 1024 && nq > 64) {   // very short rows (Flickr-1k sized index): the whole row in registers
+        // (measured: 53 -> 35 us at 5000 x 1000; with 64 / 128 values per lane — 4096 / 8192 columns — the VALU compare-and-count of
+        // the bit search and the register footprint (2 waves per SIMD) make it SLOWER than the streaming selector: 198 vs 170 us at
+        // 10240 x 4096, so longer rows keep the streaming path)
+        constexpr int QPW = 4;
+        hipLaunchKernelGGL((select_dense_regs_kernel<16, QPW>), dim3((unsigned)((nq + QPW - 1) / QPW)), dim3(64 * QPW), 0, st, S,
+                           lds_elems, nq, (int)ncols, idx_base, list_s, list_i, kp, tau);
+        LDOT_HIP_CHECK(hipGetLastError());
+        return LDOT_OK;
+    }
     if (kp + 256 <= WaveSelector::kRegKeys * 64 && nq > 64) {   // wave-per-query register selection (k' <= 512)
         constexpr int QPW = 4;
         const int wcap = WaveSelector::kRegKeys * 64;
