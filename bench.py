@@ -327,6 +327,7 @@ def main_s2(args, world, rank, dev, sharded):
     for _ in range(args.warmup):
         step()
     prof = dict(launches=0.0, kernel_ms=0.0, flops=0.0, bytes=0.0)
+    prof_dir = [dict(kernel_ms=0.0, flops=0.0), dict(kernel_ms=0.0, flops=0.0)]
     per_dir = [0.0, 0.0]
     barrier()
     t0 = time.perf_counter()
@@ -339,9 +340,11 @@ def main_s2(args, world, rank, dev, sharded):
         tc = time.perf_counter()
         per_dir[0] += tb - ta
         per_dir[1] += tc - tb
-        for pp in (p, flat_txt.last_profile()):
+        for d_, pp in enumerate((p, flat_txt.last_profile())):
             for k_ in prof:
                 prof[k_] += pp[k_]
+            for k_ in prof_dir[d_]:
+                prof_dir[d_][k_] += pp[k_]
     barrier()
     dt = time.perf_counter() - t0
     ranks_seen = 1
@@ -390,6 +393,8 @@ def main_s2(args, world, rank, dev, sharded):
                      'launches_per_step': prof['launches'] / max(args.steps, 1),
                      'kernel_ms_per_step': prof['kernel_ms'] / max(args.steps, 1),
                      'flops_per_step': flops_step,
+                     'achieved_text_to_image': prof_dir[0]['flops'] / max(prof_dir[0]['kernel_ms'], 1e-9) / 1e9,
+                     'achieved_image_to_text': prof_dir[1]['flops'] / max(prof_dir[1]['kernel_ms'], 1e-9) / 1e9,
                      'note': 'latency-class problem (a step is 0.05 - 1 TFLOP): the score kernels are a minority of the step, '
                              'the exact fp32 re-score gather (HBM/L2-bound) is the largest part'},
     }

@@ -595,6 +595,62 @@ constexpr int kPoolSelThreads = 64;
 // rows of the 8 scores of a record relative to its base row (accumulator registers 8h..8h+3 / 8h+4..8h+7 of a 32x32 MFMA tile)
 __device__ __forceinline__ int pool_rec_row(int j) { return j < 4 ? j : j + 4; }
 
+// Walk the records of 64 sub-pools (lane l holds the clamped count c of sub-pool sidx = s0 + l).  The counts are small and uneven
+// (1.5 on average, 6-10 at the fullest sub-pool), so walking LEVEL by level (entry e of every sub-pool per round) costs as many
+// dependent round trips as the fullest sub-pool has records while most lanes idle.  Instead the records are dealt densely: an
+// exclusive wave scan of the counts numbers them 0..T-1, every lane publishes its sub-pool id into slot[] for each of its records, and
+// round r lets lane l fetch record r*64 + l = (sub-pool slot[.], entry = number - that sub-pool's first number): ceil(T / 64) rounds
+// (~2 instead of ~8), every one with 64 useful records and 8 pushes.  slot[]: 256 bytes of LDS per wave (one window of 256 records).
+constexpr int kSlotWin = 256;
+__device__ __forceinline__ void walk_subpools(WaveSelector& sel, const uint4* __restrict__ base, int nsubs, int s0, int c,
+                                              int32_t row_end, unsigned char* slot) {
+    const int lane = threadIdx.x & 63;
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    const int excl = incl - c;
+    const int T = __shfl(incl, 63);
+    for (int w0 = 0; w0 < T; w0 += kSlotWin) {
+        WaveSelector::wave_sync();                       // the previous window's reads are done
+        for (int i = 0; i < c; ++i) {
+            const int j = excl + i - w0;
+            if (j >= 0 && j < kSlotWin) slot[j] = (unsigned char)lane;
+        }
+        WaveSelector::wave_sync();
+        const int wend = min(T, w0 + kSlotWin);
+        uint4 n0, n1;
+        int32_t nr;
+        auto fetch = [&](int r0) {
+            const int j = r0 + lane;
+            const bool have = j < wend;
+            const int sub = have ? (int)slot[j - w0] : 0;
+            const int e = j - __shfl(excl, sub);
+            const uint4* rec = base + (int64_t)e * kPoolPlanes * nsubs + s0 + sub;
+            n0 = have ? rec[0] : make_uint4(0u, 0u, 0u, 0u);
+            n1 = have ? rec[nsubs] : make_uint4(0u, 0u, 0u, 0u);
+            nr = have ? (int32_t)rec[2 * nsubs].x : row_end;
+        };
+        fetch(w0);
+        for (int r0 = w0; r0 < wend; r0 += 64) {
+            const uint4 p0 = n0, p1 = n1;
+            const int32_t r = nr;
+            if (r0 + 64 < wend) fetch(r0 + 64);
+            sel.reserve(8 * kPoolSelThreads);
+            sel.push(make_key(__uint_as_float(p0.x), (uint32_t)(r + 0)), r + 0 < row_end);
+            sel.push(make_key(__uint_as_float(p0.y), (uint32_t)(r + 1)), r + 1 < row_end);
+            sel.push(make_key(__uint_as_float(p0.z), (uint32_t)(r + 2)), r + 2 < row_end);
+            sel.push(make_key(__uint_as_float(p0.w), (uint32_t)(r + 3)), r + 3 < row_end);
+            sel.push(make_key(__uint_as_float(p1.x), (uint32_t)(r + 8)), r + 8 < row_end);
+            sel.push(make_key(__uint_as_float(p1.y), (uint32_t)(r + 9)), r + 9 < row_end);
+            sel.push(make_key(__uint_as_float(p1.z), (uint32_t)(r + 10)), r + 10 < row_end);
+            sel.push(make_key(__uint_as_float(p1.w), (uint32_t)(r + 11)), r + 11 < row_end);
+        }
+    }
+}
+
 template <int LV, int QPW>
 __global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(const uint4* __restrict__ pool,
                                                                        int32_t* __restrict__ pool_cnt, int nsubs, int64_t nq,
@@ -612,6 +668,7 @@ __global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(con
     if (q >= nq) return;
     WaveSelector sel;
     sel.init(keys + (size_t)wq * cap, kp, cap);
+    unsigned char* slot = (unsigned char*)(keys + (size_t)QPW * cap) + wq * kSlotWin;   // behind the QPW key buffers
     float* ls = list_s + q * kp;
     int32_t* li = list_i + q * kp;
     int32_t* cnt = pool_cnt + q * (int64_t)nsubs;
@@ -632,34 +689,7 @@ __global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(con
         nrec += c;
         if (sidx < nsubs) cnt[sidx] = 0;
         cn = sidx + kPoolSelThreads < nsubs ? cnt[sidx + kPoolSelThreads] : 0;   // next step's counters
-        int cm = c;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) cm = max(cm, __shfl_xor(cm, o));
-        if (dbg & 1) cm = 0;
-        uint4 n0, n1;
-        int32_t nr;
-        auto fetch = [&](int e) {
-            const uint4* rec = base + (int64_t)e * kPoolPlanes * nsubs + sidx;
-            const bool have = e < c;
-            n0 = have ? rec[0] : make_uint4(0u, 0u, 0u, 0u);
-            n1 = have ? rec[nsubs] : make_uint4(0u, 0u, 0u, 0u);
-            nr = have ? (int32_t)rec[2 * nsubs].x : row_end;
-        };
-        if (cm > 0) fetch(0);
-        for (int e = 0; e < cm; ++e) {
-            const uint4 p0 = n0, p1 = n1;
-            const int32_t r0 = nr;
-            if (e + 1 < cm) fetch(e + 1);
-            sel.reserve(8 * kPoolSelThreads);
-            sel.push(make_key(__uint_as_float(p0.x), (uint32_t)(r0 + 0)), r0 + 0 < row_end);
-            sel.push(make_key(__uint_as_float(p0.y), (uint32_t)(r0 + 1)), r0 + 1 < row_end);
-            sel.push(make_key(__uint_as_float(p0.z), (uint32_t)(r0 + 2)), r0 + 2 < row_end);
-            sel.push(make_key(__uint_as_float(p0.w), (uint32_t)(r0 + 3)), r0 + 3 < row_end);
-            sel.push(make_key(__uint_as_float(p1.x), (uint32_t)(r0 + 8)), r0 + 8 < row_end);
-            sel.push(make_key(__uint_as_float(p1.y), (uint32_t)(r0 + 9)), r0 + 9 < row_end);
-            sel.push(make_key(__uint_as_float(p1.z), (uint32_t)(r0 + 10)), r0 + 10 < row_end);
-            sel.push(make_key(__uint_as_float(p1.w), (uint32_t)(r0 + 11)), r0 + 11 < row_end);
-        }
+        walk_subpools(sel, base, nsubs, s0, (dbg & 1) ? 0 : c, row_end, slot);
     }
     const bool any_over = __any(over);
     if (dbg & 2) return;
@@ -691,6 +721,7 @@ __global__ __launch_bounds__(kPoolSelThreads) void select_pools_parts_kernel(con
     const int g = blockIdx.y;
     WaveSelector sel;
     sel.init(keys, kp, cap);
+    unsigned char* slot = (unsigned char*)(keys + cap);
     // nothing below the running list's threshold can enter it: start from that threshold (ties at the threshold score are kept,
     // the merge orders them by row)
     const float t0 = tau[q];
@@ -707,33 +738,7 @@ __global__ __launch_bounds__(kPoolSelThreads) void select_pools_parts_kernel(con
         over |= cn > kPoolCap;
         const int c = cn < kPoolCap ? cn : kPoolCap;
         nrec += c;
-        int cm = c;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) cm = max(cm, __shfl_xor(cm, o));
-        uint4 n0, n1;
-        int32_t nr;
-        auto fetch = [&](int e) {
-            const uint4* rec = base + (int64_t)e * kPoolPlanes * nsubs + sidx;
-            const bool have = e < c;
-            n0 = have ? rec[0] : make_uint4(0u, 0u, 0u, 0u);
-            n1 = have ? rec[nsubs] : make_uint4(0u, 0u, 0u, 0u);
-            nr = have ? (int32_t)rec[2 * nsubs].x : row_end;
-        };
-        if (cm > 0) fetch(0);
-        for (int e = 0; e < cm; ++e) {
-            const uint4 p0 = n0, p1 = n1;
-            const int32_t r0 = nr;
-            if (e + 1 < cm) fetch(e + 1);
-            sel.reserve(8 * kPoolSelThreads);
-            sel.push(make_key(__uint_as_float(p0.x), (uint32_t)(r0 + 0)), r0 + 0 < row_end);
-            sel.push(make_key(__uint_as_float(p0.y), (uint32_t)(r0 + 1)), r0 + 1 < row_end);
-            sel.push(make_key(__uint_as_float(p0.z), (uint32_t)(r0 + 2)), r0 + 2 < row_end);
-            sel.push(make_key(__uint_as_float(p0.w), (uint32_t)(r0 + 3)), r0 + 3 < row_end);
-            sel.push(make_key(__uint_as_float(p1.x), (uint32_t)(r0 + 8)), r0 + 8 < row_end);
-            sel.push(make_key(__uint_as_float(p1.y), (uint32_t)(r0 + 9)), r0 + 9 < row_end);
-            sel.push(make_key(__uint_as_float(p1.z), (uint32_t)(r0 + 10)), r0 + 10 < row_end);
-            sel.push(make_key(__uint_as_float(p1.w), (uint32_t)(r0 + 11)), r0 + 11 < row_end);
-        }
+        walk_subpools(sel, base, nsubs, s0, sidx < s_end ? c : 0, row_end, slot);
     }
     sel.compact();
     WaveSelector::wave_sync();
@@ -1012,10 +1017,10 @@ int launch_select_pools(const uint4* pool, const int32_t* pool_cnt, int nsubs, i
     if (cap <= WaveSelector::kRegKeys * 64) {   // register selection path: 4 independent query-waves per workgroup
         constexpr int QPW = 4;
         hipLaunchKernelGGL((select_pools_kernel<4, QPW>), dim3((unsigned)((nq + QPW - 1) / QPW)),
-                           dim3(kPoolSelThreads * QPW), (size_t)cap * 8 * QPW, st, pool, (int32_t*)pool_cnt, nsubs, nq,
+                           dim3(kPoolSelThreads * QPW), (size_t)cap * 8 * QPW + kSlotWin * QPW, st, pool, (int32_t*)pool_cnt, nsubs, nq,
                            row_end, list_s, list_i, kp, cap, tau, overflow_flags, over_sum, qcnt, dbg);
     } else {   // kp > 512: LDS sort path, one wave per workgroup
-        hipLaunchKernelGGL((select_pools_kernel<4, 1>), dim3((unsigned)nq), dim3(kPoolSelThreads), (size_t)cap * 8, st,
+        hipLaunchKernelGGL((select_pools_kernel<4, 1>), dim3((unsigned)nq), dim3(kPoolSelThreads), (size_t)cap * 8 + kSlotWin, st,
                            pool, (int32_t*)pool_cnt, nsubs, nq, row_end, list_s, list_i, kp, cap, tau, overflow_flags, over_sum, qcnt, dbg);
     }
     LDOT_HIP_CHECK(hipGetLastError());
@@ -1028,7 +1033,7 @@ int launch_select_pools_parts(const uint4* pool, const int32_t* pool_cnt, int ns
     if (nq <= 0) return LDOT_OK;
     const int cap = select_cap(kp, 1024, 8 * kPoolSelThreads);
     LDOT_REQUIRE(cap <= WaveSelector::kRegKeys * 64 && nsubs % G == 0, LDOT_EINVAL, "select_pools_parts: unsupported shape");
-    hipLaunchKernelGGL(select_pools_parts_kernel, dim3((unsigned)nq, (unsigned)G), dim3(kPoolSelThreads), (size_t)cap * 8, st, pool,
+    hipLaunchKernelGGL(select_pools_parts_kernel, dim3((unsigned)nq, (unsigned)G), dim3(kPoolSelThreads), (size_t)cap * 8 + kSlotWin, st, pool,
                        (int32_t*)pool_cnt, nsubs, nq, G, row_end, kp, cap, tau, part_s, part_l, overflow_flags, over_sum, qcnt);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
