@@ -528,7 +528,7 @@ static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_p
                                  (uint4*)ix->w_pool.p, (int32_t*)ix->w_pool_cnt.p, st);
         prof_end(ix, st);
         if (rc) return rc;
-        if (nq <= 64 && nsubs >= 512 && kp + 512 <= 1024) {
+        if (nq <= 64 && nsubs >= 512 && kp + 512 + 32 <= 1024) {
             // few queries: G waves per query fold the sub-pools into partial lists, one merge joins them with the running list
             const int G = 16;
             if ((rc = ix->w_part_s.ensure((size_t)G * nq * kp * 4))) return rc;

@@ -600,8 +600,11 @@ __device__ __forceinline__ int pool_rec_row(int j) { return j < 4 ? j : j + 4; }
 // dependent round trips as the fullest sub-pool has records while most lanes idle.  Instead the records are dealt densely: an
 // exclusive wave scan of the counts numbers them 0..T-1, every lane publishes its sub-pool id into slot[] for each of its records, and
 // round r lets lane l fetch record r*64 + l = (sub-pool slot[.], entry = number - that sub-pool's first number): ceil(T / 64) rounds
-// (~2 instead of ~8), every one with 64 useful records and 8 pushes.  slot[]: 256 bytes of LDS per wave (one window of 256 records).
+// (~2 instead of ~8), every one with 64 useful records and 8 pushes.  slot[] (one window of 256 records) occupies the LAST 256 bytes
+// of the wave's key buffer: the walk reserves 32 keys more than a round can push, so the keys never grow into it (an extra KiB of
+// LDS per workgroup would cost a workgroup per CU: 160 KiB / 33 KiB = 4 instead of 5).
 constexpr int kSlotWin = 256;
+constexpr int kSlotKeys = kSlotWin / 8;
 __device__ __forceinline__ void walk_subpools(WaveSelector& sel, const uint4* __restrict__ base, int nsubs, int s0, int c,
                                               int32_t row_end, unsigned char* slot) {
     const int lane = threadIdx.x & 63;
@@ -638,7 +641,7 @@ __device__ __forceinline__ void walk_subpools(WaveSelector& sel, const uint4* __
             const uint4 p0 = n0, p1 = n1;
             const int32_t r = nr;
             if (r0 + 64 < wend) fetch(r0 + 64);
-            sel.reserve(8 * kPoolSelThreads);
+            sel.reserve(8 * kPoolSelThreads + kSlotKeys);
             sel.push(make_key(__uint_as_float(p0.x), (uint32_t)(r + 0)), r + 0 < row_end);
             sel.push(make_key(__uint_as_float(p0.y), (uint32_t)(r + 1)), r + 1 < row_end);
             sel.push(make_key(__uint_as_float(p0.z), (uint32_t)(r + 2)), r + 2 < row_end);
@@ -668,7 +671,10 @@ __global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(con
     if (q >= nq) return;
     WaveSelector sel;
     sel.init(keys + (size_t)wq * cap, kp, cap);
-    unsigned char* slot = (unsigned char*)(keys + (size_t)QPW * cap) + wq * kSlotWin;   // behind the QPW key buffers
+    // the tail of this wave's key buffer — or, on the LDS-sort path (cap > 1024, one wave per workgroup, whose bitonic padding writes up
+    // to cap), a window of its own behind it
+    unsigned char* slot = cap > WaveSelector::kRegKeys * 64 ? (unsigned char*)(keys + (size_t)QPW * cap) + wq * kSlotWin
+                                                            : (unsigned char*)(keys + (size_t)(wq + 1) * cap) - kSlotWin;
     float* ls = list_s + q * kp;
     int32_t* li = list_i + q * kp;
     int32_t* cnt = pool_cnt + q * (int64_t)nsubs;
@@ -721,7 +727,7 @@ __global__ __launch_bounds__(kPoolSelThreads) void select_pools_parts_kernel(con
     const int g = blockIdx.y;
     WaveSelector sel;
     sel.init(keys, kp, cap);
-    unsigned char* slot = (unsigned char*)(keys + cap);
+    unsigned char* slot = (unsigned char*)(keys + cap) - kSlotWin;
     // nothing below the running list's threshold can enter it: start from that threshold (ties at the threshold score are kept,
     // the merge orders them by row)
     const float t0 = tau[q];
@@ -1004,7 +1010,7 @@ int launch_select_pools(const uint4* pool, const int32_t* pool_cnt, int nsubs, i
         LDOT_HIP_CHECK(hipGetLastError());
         return LDOT_OK;
     }
-    const int cap = select_cap(kp, 1024, 8 * kPoolSelThreads);   // a step appends up to 8 x 64 candidates on top of a full list
+    const int cap = select_cap(kp, 1024, 8 * kPoolSelThreads + kSlotKeys);   // a round appends up to 8 x 64 candidates on top of a full list (+ the slot window)
     int dbg = 0;
 #ifdef LDOT_ABLATION
     static int dbg_env = -1;   // LDOT_DEBUG_SEL: ablation bits (ablation builds only; results are then meaningless)
@@ -1017,7 +1023,7 @@ int launch_select_pools(const uint4* pool, const int32_t* pool_cnt, int nsubs, i
     if (cap <= WaveSelector::kRegKeys * 64) {   // register selection path: 4 independent query-waves per workgroup
         constexpr int QPW = 4;
         hipLaunchKernelGGL((select_pools_kernel<4, QPW>), dim3((unsigned)((nq + QPW - 1) / QPW)),
-                           dim3(kPoolSelThreads * QPW), (size_t)cap * 8 * QPW + kSlotWin * QPW, st, pool, (int32_t*)pool_cnt, nsubs, nq,
+                           dim3(kPoolSelThreads * QPW), (size_t)cap * 8 * QPW, st, pool, (int32_t*)pool_cnt, nsubs, nq,
                            row_end, list_s, list_i, kp, cap, tau, overflow_flags, over_sum, qcnt, dbg);
     } else {   // kp > 512: LDS sort path, one wave per workgroup
         hipLaunchKernelGGL((select_pools_kernel<4, 1>), dim3((unsigned)nq), dim3(kPoolSelThreads), (size_t)cap * 8 + kSlotWin, st,
@@ -1031,9 +1037,9 @@ int launch_select_pools_parts(const uint4* pool, const int32_t* pool_cnt, int ns
                               const float* tau, float* part_s, int64_t* part_l, int32_t* overflow_flags, int32_t* over_sum,
                               int32_t* qcnt, hipStream_t st) {
     if (nq <= 0) return LDOT_OK;
-    const int cap = select_cap(kp, 1024, 8 * kPoolSelThreads);
+    const int cap = select_cap(kp, 1024, 8 * kPoolSelThreads + kSlotKeys);
     LDOT_REQUIRE(cap <= WaveSelector::kRegKeys * 64 && nsubs % G == 0, LDOT_EINVAL, "select_pools_parts: unsupported shape");
-    hipLaunchKernelGGL(select_pools_parts_kernel, dim3((unsigned)nq, (unsigned)G), dim3(kPoolSelThreads), (size_t)cap * 8 + kSlotWin, st, pool,
+    hipLaunchKernelGGL(select_pools_parts_kernel, dim3((unsigned)nq, (unsigned)G), dim3(kPoolSelThreads), (size_t)cap * 8, st, pool,
                        (int32_t*)pool_cnt, nsubs, nq, G, row_end, kp, cap, tau, part_s, part_l, overflow_flags, over_sum, qcnt);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
