@@ -403,13 +403,17 @@ def main_s2(args, world, rank, dev, sharded):
         cores = os.cpu_count() or 1
         cpu = {}
         for name, qq, xx in (('t2i', txt, img), ('i2t', img_q, txt)):
-            dtc, cs, cl = OT.timed(qq.cpu(), xx.cpu(), K, cores, runs=3)
+            qc, xc = qq.cpu(), xx.cpu()
+            # (all hardware threads oversubscribe torch's intra-op pool on these boxes: take the better of all / half the threads)
+            trial = {t: OT.timed(qc, xc, K, t, runs=1)[0] for t in (cores, max(1, cores // 2))}
+            threads = min(trial, key=trial.get)
+            dtc, cs, cl = OT.timed(qc, xc, K, threads, runs=3)
             gl = (hl[0] if name == 't2i' else hl[1]).numpy()
-            cpu[name] = {'seconds': dtc, 'rank1_mismatches_vs_gpu': int((gl[:, 0] != cl.numpy()[:, 0]).sum())}
+            cpu[name] = {'seconds': dtc, 'threads': threads, 'rank1_mismatches_vs_gpu': int((gl[:, 0] != cl.numpy()[:, 0]).sum())}
         out['cpu_baseline'] = {'value': 2 * nq / (cpu['t2i']['seconds'] + cpu['i2t']['seconds']), 'unit': 'queries/s',
                                'cores': int(cores), 'kind': 'port',
                                'sample': 'the whole step (both searches), oracle_torch.search_blocked (torch.matmul + torch.topk, '
-                                         'fp32), median of 3 runs after warm-up', 'detail': cpu}
+                                         'fp32) at the better of all / half the hardware threads, median of 3 runs after warm-up', 'detail': cpu}
     print(json.dumps(out), flush=True)
     if sharded:
         dist.destroy_process_group()
@@ -417,35 +421,61 @@ def main_s2(args, world, rank, dev, sharded):
 
 def cpu_baseline(x_dev, q_dev, k, nsample, gpu_scores, gpu_labels):
     """The reference's CPU scorer is faiss IndexFlatIP (fp32 sgemm + per-query selection on the host cores).  faiss is used when it
-    is importable on the box; otherwise the stand-in SURVEY 8d prescribes (oracle.oracle_torch.search_blocked: torch.matmul over
-    4096-query x 131072-row tiles + torch.topk(sorted), torch.set_num_threads(all cores)).  Bounded sample: the first `nsample`
-    queries against the FULL index, median of 5 runs after a warm-up, all cores; plus a one-thread figure on 32 queries.  The same
-    sample is the parity check of the GPU results (rank-1 mismatches and max |delta score| against the fp32 CPU path)."""
-    from oracle import oracle_torch as OT      # checker / baseline only — never on the product path
+    is importable on the box.  Otherwise the baseline is the FASTEST of the restatements of that structure on this host, so that it
+    is not understated by one library's threading behaviour: (a) the stand-in SURVEY 8d prescribes, oracle_torch.search_blocked
+    (torch.matmul over 4096-query x 131072-row tiles + torch.topk(sorted)) at os.cpu_count() threads, (b) the same at half the
+    threads, (c) oracle_np.search_fast (numpy/BLAS sgemm blocks + argpartition).  Each candidate runs once after a warm-up, the
+    fastest runs four more times; `value` is the median of its five runs.  Bounded sample: the first `nsample` queries against the
+    FULL index; plus a one-thread figure on 32 queries.  The same sample is the parity check of the GPU results (rank-1 mismatches
+    and max |delta score| against the fp32 CPU path)."""
+    from oracle import oracle_np as O          # checker / baseline only — never on the product path
+    from oracle import oracle_torch as OT
     cores = os.cpu_count() or 1
     x = x_dev.cpu()
     q = q_dev[:nsample].cpu()
-    scorer = 'oracle_torch.search_blocked (torch.matmul 4096 x 131072 tiles + torch.topk, fp32)'
+    xn, qn = x.numpy(), q.numpy()
+
+    def torch_at(threads):
+        def run():
+            old = torch.get_num_threads()
+            torch.set_num_threads(threads)
+            try:
+                s_, l_ = OT.search_blocked(q, x, k)
+            finally:
+                torch.set_num_threads(old)
+            return s_.numpy(), l_.numpy()
+        return run
+
     if OT.have_faiss():
         import faiss
         faiss.omp_set_num_threads(cores)
-        xn, qn = x.numpy(), q.numpy()
-        OT.faiss_search(qn[:8], xn[:4096], k)
-        ts = []
-        for _ in range(5):
-            t0 = time.perf_counter()
-            cs, cl = OT.faiss_search(qn, xn, k)
-            ts.append(time.perf_counter() - t0)
-        dt, scorer = sorted(ts)[2], 'faiss.IndexFlatIP (the reference scorer)'
+        cands = {'faiss.IndexFlatIP (the reference scorer)': lambda: OT.faiss_search(qn, xn, k)}
     else:
-        dt, cs, cl = OT.timed(q, x, k, cores, runs=5)
-        cs, cl = cs.numpy(), cl.numpy()
+        cands = {f'oracle_torch.search_blocked (torch.matmul tiles + torch.topk), {cores} threads': torch_at(cores),
+                 f'oracle_torch.search_blocked, {max(1, cores // 2)} threads': torch_at(max(1, cores // 2)),
+                 'oracle_np.search_fast (numpy BLAS sgemm blocks + argpartition)': lambda: O.search_fast(qn, xn, k)}
+    OT.search_blocked(q[:8], x[:4096], k)
+    O.search_fast(qn[:8], xn[:4096], k)
+    first, res = {}, {}
+    for name, fn in cands.items():
+        t0 = time.perf_counter()
+        res[name] = fn()
+        first[name] = time.perf_counter() - t0
+    best = min(first, key=first.get)
+    ts = [first[best]]
+    for _ in range(4):
+        t0 = time.perf_counter()
+        cands[best]()
+        ts.append(time.perf_counter() - t0)
+    dt = sorted(ts)[2]
+    cs, cl = res[best]
     n1 = min(32, q.shape[0])
     dt1, _, _ = OT.timed(q[:n1], x, k, 1, runs=3)
     base = {'value': q.shape[0] / dt, 'unit': 'queries/s', 'cores': int(cores), 'kind': 'port',
-            'sample': f'first {q.shape[0]} queries x full {x.shape[0]} x {x.shape[1]} fp32 index, top-{k}, {scorer}, '
-                      f'{cores} threads, median of 5 runs after warm-up, {dt:.2f} s per run',
-            'value_1thread': n1 / dt1, 'sample_1thread': f'first {n1} queries, 1 thread, median of 3 runs, {dt1:.2f} s per run'}
+            'sample': f'first {q.shape[0]} queries x full {x.shape[0]} x {x.shape[1]} fp32 index, top-{k}; fastest of '
+                      f'{len(cands)} host scorers: {best}; median of 5 runs after warm-up, {dt:.2f} s per run',
+            'candidates_first_run_s': {n: round(t, 3) for n, t in first.items()},
+            'value_1thread': n1 / dt1, 'sample_1thread': f'first {n1} queries, torch scorer, 1 thread, median of 3 runs, {dt1:.2f} s per run'}
     gs, gl = gpu_scores[:q.shape[0]], gpu_labels[:q.shape[0]]
     scale = float(np.abs(cs).max()) or 1.0
     # positions where the label differs but the two fp32 scores agree to 1e-4 relative are summation-order ties
