@@ -115,6 +115,16 @@ int ldot_index_search_begin(ldot_index_t* ix, const void* queries, int64_t nq, i
                             float* tau_out, void* stream);
 int ldot_index_search_finish(ldot_index_t* ix, const float* floor, float* out_scores, int64_t* out_labels, int out_mem,
                              void* stream);
+/* Approximate search — stands where the reference selects faiss.IndexHNSWFlat (dvl/indexer/faiss_indexers.py:90-154, `--hnsw_index`).
+ * The index rows are stored sorted by inverted list (the caller clusters them and adds them in list order): list l = rows
+ * [list_offsets[l], list_offsets[l+1]).  Every query is scored EXACTLY (fp32) against the rows of its nprobe lists probes[q][0..nprobe)
+ * (-1 = skip) and the k best of those are returned in descending score order with their row labels (LDOT_PAD_LABEL / LDOT_PAD_SCORE
+ * when the lists hold fewer than k rows).  list_offsets [nlist+1] int64 and probes [nq*nprobe] int32 are DEVICE memory, the queries
+ * are DEVICE memory of `dtype`; max_list_len = the longest list.  (The coarse step — which lists to probe — is an ordinary
+ * ldot_index_search over the list centroids.) */
+int ldot_index_search_lists(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int normalize, const int64_t* list_offsets,
+                            int nlist, int64_t max_list_len, const int32_t* probes, int nprobe, int k, float* out_scores,
+                            int64_t* out_labels, int out_mem, void* stream);
 /* own on-disk format ("LDOTIDX1": header + fp32 rows); bf16 shadow is rebuilt on load */
 int ldot_index_save(ldot_index_t* ix, const char* path);
 int ldot_index_load(const char* path, ldot_index_t** out);

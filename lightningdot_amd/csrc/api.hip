@@ -749,6 +749,81 @@ int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dty
     return LDOT_OK;
 }
 
+// Approximate (inverted-file) search: see ldot.h.  Exact fp32 scores of every query against the rows of its nprobe lists, top-k of those.
+int ldot_index_search_lists(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int normalize, const int64_t* list_offsets,
+                            int nlist, int64_t max_list_len, const int32_t* probes, int nprobe, int k, float* out_scores,
+                            int64_t* out_labels, int out_mem, void* stream) {
+    LDOT_REQUIRE(ix != nullptr, LDOT_EINVAL, "index is NULL");
+    LDOT_REQUIRE(nq >= 0 && k >= 1 && k <= kMaxK, LDOT_EINVAL, "bad nq / k");
+    LDOT_REQUIRE(dtype >= 0 && dtype <= 2, LDOT_EINVAL, "bad dtype %d", dtype);
+    LDOT_REQUIRE(out_mem == LDOT_HOST || out_mem == LDOT_DEVICE, LDOT_EINVAL, "bad memory space");
+    LDOT_REQUIRE(nlist >= 1 && nprobe >= 1 && nprobe <= nlist && max_list_len >= 0, LDOT_EINVAL, "bad list geometry");
+    if (nq == 0) return LDOT_OK;
+    LDOT_REQUIRE(queries && list_offsets && probes && out_scores && out_labels, LDOT_EINVAL, "NULL buffer");
+    DeviceGuard guard(ix->device);
+    hipStream_t st = (hipStream_t)stream;
+    ix->pend_nq = 0;
+    ix->overflow_pending = false;
+    ix->qcnt_n = 0;
+    ix->unproven_n = 0;
+    for (int i = 0; i < 4; ++i) ix->stats[i] = 0;
+    const int kp = (int)round_up(k, 32);           // the candidates carry exact scores: no margin
+    const int lpad = (int)round_up(std::max<int64_t>(max_list_len, 1), 64);
+    const int64_t ncols = (int64_t)nprobe * lpad;
+    LDOT_REQUIRE(ncols < ((int64_t)1 << 31), LDOT_EINVAL, "nprobe * list length too large");
+    // queries are processed in chunks that bound the score workspace (<= 1 GiB)
+    const int64_t qchunk = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)1 << 28) / ncols));
+    int rc;
+    if ((rc = ix->w_q32.ensure((size_t)round_up(qchunk, kBM) * ix->dpad * 4))) return rc;
+    if ((rc = ix->w_S.ensure((size_t)qchunk * ncols * 4))) return rc;
+    if ((rc = ix->w_ls.ensure((size_t)qchunk * kp * 4))) return rc;
+    if ((rc = ix->w_li.ensure((size_t)qchunk * kp * 4))) return rc;
+    if ((rc = ix->w_tau.ensure((size_t)qchunk * 4))) return rc;
+    const int64_t seg_cols = std::max<int64_t>(1024, std::min<int64_t>(16384, round_up((ncols + 15) / 16, 256)));
+    const int64_t nseg = (ncols + seg_cols - 1) / seg_cols;
+    if ((rc = ix->w_part_s.ensure((size_t)nseg * qchunk * kp * 4))) return rc;
+    if ((rc = ix->w_part_l.ensure((size_t)nseg * qchunk * kp * 8))) return rc;
+    if (out_mem == LDOT_HOST) {
+        if ((rc = ix->w_outs.ensure((size_t)qchunk * k * 4))) return rc;
+        if ((rc = ix->w_outl.ensure((size_t)qchunk * k * 8))) return rc;
+    }
+    const size_t esz = dtype_size(dtype);
+    for (int64_t q0 = 0; q0 < nq; q0 += qchunk) {
+        const int64_t n = std::min(qchunk, nq - q0);
+        const char* src = (const char*)queries + (size_t)q0 * ix->d * esz;
+        if ((rc = launch_convert_rows(src, dtype, ix->d, n, n, ix->d, ix->dpad, normalize, (float*)ix->w_q32.p, nullptr, 0, nullptr, 0,
+                                      st)))
+            return rc;
+        if ((rc = launch_scan_lists((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, n, list_offsets,
+                                    probes + q0 * nprobe, nprobe, lpad, (float*)ix->w_S.p, ncols, st)))
+            return rc;
+        ix->stats[2] += n * ncols;
+        float* ls = (float*)ix->w_ls.p;
+        int32_t* li = (int32_t*)ix->w_li.p;
+        float* tau = (float*)ix->w_tau.p;
+        if ((rc = launch_init_lists(ls, li, n * kp, tau, n, n, st))) return rc;
+        if ((rc = launch_select_dense_parts((const float*)ix->w_S.p, ncols, n, ncols, seg_cols, 0, kp, (float*)ix->w_part_s.p,
+                                            (int64_t*)ix->w_part_l.p, st)))
+            return rc;
+        if ((rc = launch_merge_parts_into_lists((const float*)ix->w_part_s.p, (const int64_t*)ix->w_part_l.p, (int)nseg, n, kp, ls, li,
+                                                tau, st)))
+            return rc;
+        float* ds = out_mem == LDOT_DEVICE ? out_scores + q0 * k : (float*)ix->w_outs.p;
+        int64_t* dl = out_mem == LDOT_DEVICE ? out_labels + q0 * k : (int64_t*)ix->w_outl.p;
+        // final ordering (score desc, column asc) with the sort of the re-score kernel; no re-scoring: the scores are exact already
+        if ((rc = launch_rescore((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, n, ls, li, kp, k, 0, nullptr, ds, dl,
+                                 st)))
+            return rc;
+        if ((rc = launch_translate_cols(dl, n, k, list_offsets, probes + q0 * nprobe, nprobe, lpad, st))) return rc;
+        if (out_mem == LDOT_HOST) {
+            LDOT_HIP_CHECK(hipMemcpyAsync(out_scores + q0 * k, ds, (size_t)n * k * 4, hipMemcpyDeviceToHost, st));
+            LDOT_HIP_CHECK(hipMemcpyAsync(out_labels + q0 * k, dl, (size_t)n * k * 8, hipMemcpyDeviceToHost, st));
+            LDOT_HIP_CHECK(hipStreamSynchronize(st));
+        }
+    }
+    return LDOT_OK;
+}
+
 int ldot_index_last_profile(const ldot_index_t* ix, double out[4]) {
     LDOT_REQUIRE(ix != nullptr && out != nullptr, LDOT_EINVAL, "NULL argument");
     for (int i = 0; i < 4; ++i) out[i] = ix->prof[i];

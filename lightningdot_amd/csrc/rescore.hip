@@ -113,6 +113,98 @@ __global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __rest
     }
 }
 
+// ---- approximate (IVF) search: exact fp32 scores of a query against the rows of its probed lists ---------------------------------
+// The reference's approximate alternative is faiss.IndexHNSWFlat (dvl/indexer/faiss_indexers.py:90-154); a graph walk is a poor fit
+// for a wide machine, an inverted-file scan is not: the rows are stored sorted by list, a query reads nprobe contiguous row ranges of
+// the fp32 master copy (HBM-bound, ~3 KB per row) and scores them exactly.  Workgroup = 4 waves, 64 rows of one (query, probe) pair;
+// a wave scores 16 rows, four at a time (the arithmetic of one row is the re-score kernel's: 4 fmaf chains over the columns
+// lane*4 + 256*i, pairwise sum, xor-shuffle tree).  S[q][probe * lpad + offset] receives the score, rows past the list's end the
+// padding score (their columns are translated to label -1 afterwards).
+__global__ __launch_bounds__(256) void scan_lists_kernel(const float* __restrict__ q32, int64_t ldq, const float* __restrict__ x32,
+                                                         int64_t ldx, int dpad, const int64_t* __restrict__ list_offsets,
+                                                         const int32_t* __restrict__ probes, int nprobe, int lpad,
+                                                         float* __restrict__ S, int64_t lds_elems) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t q = blockIdx.y;
+    const int probe = blockIdx.x / (lpad / 64), blk = blockIdx.x % (lpad / 64);
+    const int32_t list = probes[q * nprobe + probe];
+    const int64_t r_beg = list >= 0 ? list_offsets[list] : 0, r_end = list >= 0 ? list_offsets[list + 1] : 0;
+    const int o0 = blk * 64 + wave * 16;
+    float* out = S + q * lds_elems + (int64_t)probe * lpad + o0;
+    const float* qrow = q32 + q * ldq;
+    constexpr int U = 4;
+    for (int u0 = 0; u0 < 16; u0 += U) {
+        float acc[U][4];
+        int64_t r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            r[u] = r_beg + o0 + u0 + u;
+            acc[u][0] = acc[u][1] = acc[u][2] = acc[u][3] = 0.f;
+        }
+        if (r[0] < r_end) {   // (wave-uniform)
+            for (int c = lane * 4; c < dpad; c += 256) {
+                const f32x4 qv = *(const f32x4*)(qrow + c);
+                f32x4 xv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    xv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (r[u] < r_end) xv[u] = *(const f32x4*)(x32 + r[u] * ldx + c);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    acc[u][0] = fmaf(xv[u][0], qv[0], acc[u][0]);
+                    acc[u][1] = fmaf(xv[u][1], qv[1], acc[u][1]);
+                    acc[u][2] = fmaf(xv[u][2], qv[2], acc[u][2]);
+                    acc[u][3] = fmaf(xv[u][3], qv[3], acc[u][3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float sc = (acc[u][0] + acc[u][1]) + (acc[u][2] + acc[u][3]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sc += __shfl_xor(sc, o);
+            if (lane == 0) out[u0 + u] = r[u] < r_end ? sc : LDOT_PAD_SCORE;
+        }
+    }
+}
+
+// labels of the list search are COLUMNS of S (probe * lpad + offset): -> index rows, or -1 past a list's end / for padding
+__global__ __launch_bounds__(256) void translate_cols_kernel(int64_t* __restrict__ labels, int64_t n, int k,
+                                                             const int64_t* __restrict__ list_offsets,
+                                                             const int32_t* __restrict__ probes, int nprobe, int lpad) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t col = labels[i];
+    int64_t row = -1;
+    if (col >= 0) {
+        const int probe = (int)(col / lpad), off = (int)(col % lpad);
+        const int32_t list = probes[(i / k) * nprobe + probe];
+        if (list >= 0 && list_offsets[list] + off < list_offsets[list + 1]) row = list_offsets[list] + off;
+    }
+    labels[i] = row;
+}
+
+int launch_scan_lists(const float* q32, int64_t ldq, const float* x32, int64_t ldx, int dpad, int64_t nq,
+                      const int64_t* list_offsets, const int32_t* probes, int nprobe, int lpad, float* S, int64_t lds_elems,
+                      hipStream_t st) {
+    if (nq <= 0 || nprobe <= 0) return LDOT_OK;
+    hipLaunchKernelGGL(scan_lists_kernel, dim3((unsigned)(nprobe * (lpad / 64)), (unsigned)nq), dim3(256), 0, st, q32, ldq, x32, ldx,
+                       dpad, list_offsets, probes, nprobe, lpad, S, lds_elems);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+int launch_translate_cols(int64_t* labels, int64_t nq, int k, const int64_t* list_offsets, const int32_t* probes, int nprobe,
+                          int lpad, hipStream_t st) {
+    const int64_t n = nq * k;
+    if (n <= 0) return LDOT_OK;
+    hipLaunchKernelGGL(translate_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, labels, n, k, list_offsets, probes,
+                       nprobe, lpad);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
 // LDOT_OPT_VERIFY: is the reported top-k PROVEN to be the exact fp32 top-k?  A row that is not among the k' candidates has a bf16
 // candidate score <= tau (the k'-th best candidate score), hence an exact score <= tau + E where E bounds the bf16 input-rounding
 // error of one score.  If the k-th reported exact score is >= tau + E no such row can displace it.  E is the statistical bound

@@ -340,16 +340,24 @@ class DenseHNSWFlatIndexer(DenseIndexer):
     with one extra dimension sqrt(phi - |x|^2) (phi = max |x|^2), queries augmented with 0, so that L2 order = inner
     product order; ``search_knn`` returns the SQUARED L2 distances of the augmented vectors, ascending.
 
-    Here the graph is not needed: the exact scan of a 1M x 768 index takes < 1 ms per query batch on an MI355X, so the
+    Default: the graph is not needed — the exact scan of a 1M x 768 index takes 0.5 ms per query on an MI355X — so the
     class keeps the reference's surface (constructor arguments, all-data-at-once rule, phi bookkeeping, score semantics,
     id mapping) on top of the exact flat index.  Neighbours are the exact ones (recall 1.0 instead of HNSW's ~0.99);
-    distances are |q|^2 + phi - 2 q.x from the exact fp32 inner products."""
+    distances are |q|^2 + phi - 2 q.x from the exact fp32 inner products.
+
+    ``approximate=True``: a real approximate index behind the same surface — the inverted-file index of ``ivf.py`` (the machine's
+    counterpart of the graph: ``ef_search // 4`` lists are probed per query); same phi augmentation, same distances, recall < 1."""
 
     def __init__(self, vector_sz: int, buffer_size: int = 50000, store_n: int = 512, ef_search: int = 128,
-                 ef_construction: int = 200):
+                 ef_construction: int = 200, approximate: bool = False):
         super(DenseHNSWFlatIndexer, self).__init__(buffer_size=buffer_size)
         self.index = FlatIPIndex(vector_sz)
-        self.store_n, self.ef_search, self.ef_construction = store_n, ef_search, ef_construction   # kept, unused
+        self.store_n, self.ef_search, self.ef_construction = store_n, ef_search, ef_construction   # store_n / ef_construction: unused
+        self._ivf = None
+        if approximate:
+            from .ivf import DenseIVFFlatIndexer
+            self._ivf = DenseIVFFlatIndexer(vector_sz, buffer_size, nprobe=max(1, ef_search // 4))
+            self.index = self._ivf.index
         self.phi = 0               # the reference's re-index guard (:106,112-113,154)
         self._phi_value = 0.0      # max squared row norm of the indexed data
 
@@ -368,6 +376,10 @@ class DenseHNSWFlatIndexer(DenseIndexer):
         logger.info('HNSWF DotProduct -> L2 space phi={}'.format(phi))
         self.phi = 0                                   # (:119: the reference resets its guard here)
         self._phi_value = max(float(phi), self._phi_value)
+        if self._ivf is not None:
+            self._ivf.index_data(data)
+            self.index_id_to_db_id = self._ivf.index_id_to_db_id
+            return
         for i in range(0, n, self.buffer_size):
             chunk = data[i:i + self.buffer_size]
             if chunk and _is_tensor(chunk[0][1]):
@@ -387,6 +399,10 @@ class DenseHNSWFlatIndexer(DenseIndexer):
             raise ValueError('ids / vectors length mismatch')
         if vectors.shape[0]:
             self._phi_value = max(self._phi_value, float((vectors.float() ** 2).sum(dim=1).max().item()))
+        if self._ivf is not None:
+            self._ivf.index_tensor(db_ids, vectors)
+            self.index_id_to_db_id = self._ivf.index_id_to_db_id
+            return
         self._update_id_mapping(list(db_ids))
         self.index.add(vectors)
 
@@ -395,7 +411,13 @@ class DenseHNSWFlatIndexer(DenseIndexer):
         return np.where(labels >= 0, dist, np.float32(3.4028234663852886e38)).astype(np.float32)   # faiss pads with FLT_MAX
 
     def search_knn(self, query_vectors: np.array, top_docs: int) -> List[Tuple[List[object], List[float]]]:
-        if _is_tensor(query_vectors):
+        if self._ivf is not None:
+            import torch
+            qt = query_vectors if _is_tensor(query_vectors) else torch.from_numpy(np.asarray(query_vectors, dtype=np.float32))
+            ip, indexes = self._ivf.search_knn_tensors(qt, top_docs)
+            qn = (qt.float() ** 2).sum(dim=1).cpu().numpy()
+            ip, indexes = ip.cpu().numpy(), indexes.cpu().numpy()
+        elif _is_tensor(query_vectors):
             ip, indexes = self.index.search_tensors(query_vectors, top_docs)
             qn = (query_vectors.float() ** 2).sum(dim=1).cpu().numpy()
             ip, indexes = ip.cpu().numpy(), indexes.cpu().numpy()

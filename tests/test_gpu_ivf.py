@@ -1,0 +1,118 @@
+"""GPU tests of the approximate (inverted-file) index behind the reference's --hnsw_index surface
+(dvl/indexer/faiss_indexers.py:90-154): exactness when every list is probed, recall on clustered data, L2-distance surface,
+persistence, the raw C entry point against a brute-force scan of the probed ranges."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _clustered(n, d, ncl, seed, spread=0.35):
+    rng = np.random.default_rng(seed)
+    cent = rng.standard_normal((ncl, d)).astype(np.float32)
+    x = (cent[rng.integers(0, ncl, n)] + spread * rng.standard_normal((n, d))).astype(np.float32)
+    return x, rng
+
+
+def test_probing_every_list_is_the_exact_search():
+    import torch
+    from lightningdot_amd.indexer import DenseFlatIndexer
+    from lightningdot_amd.ivf import DenseIVFFlatIndexer
+    x, rng = _clustered(20000, 96, 40, 1)
+    q = (x[rng.integers(0, 20000, 300)] + 0.3 * rng.standard_normal((300, 96))).astype(np.float32)
+    ids = [f'row{i}' for i in range(20000)]
+    ivf = DenseIVFFlatIndexer(96, nlist=50, nprobe=50)
+    ivf.index_tensor(ids, torch.from_numpy(x))
+    assert int(ivf.list_offsets[-1]) == 20000 and len(ivf.index_id_to_db_id) == 20000
+    flat = DenseFlatIndexer(96)
+    flat.index_tensor(ids, torch.from_numpy(x).cuda())
+    got, want = ivf.search_knn(q, 25), flat.search_knn(q, 25)
+    full = q.astype(np.float64) @ x.astype(np.float64).T
+    for (gi, gs), (wi, ws), frow in zip(got, want, full):
+        np.testing.assert_allclose(gs, ws, rtol=0, atol=2e-4)
+        assert gi[0] == wi[0]
+        # same id set except inside fp32 summation-order ties
+        if gi != wi:
+            sc = {i: frow[int(i[3:])] for i in set(gi) ^ set(wi)}
+            assert max(sc.values()) - min(sc.values()) < 1e-3
+    # fewer rows than k in the probed lists -> padded like faiss (-1 labels map to the LAST id, :85)
+    tiny = DenseIVFFlatIndexer(8, nlist=2, nprobe=1)
+    tiny.index_tensor(['a', 'b', 'c'], torch.eye(3, 8))
+    r = tiny.search_knn(np.eye(1, 8, dtype=np.float32), 5)
+    assert len(r[0][0]) == 5 and r[0][1][-1] == np.float32(-3.4028234663852886e38)
+
+
+def test_recall_on_clustered_data_and_hnsw_surface():
+    import torch
+    from lightningdot_amd.indexer import DenseFlatIndexer, DenseHNSWFlatIndexer
+    x, rng = _clustered(60000, 128, 300, 2)
+    q = (x[rng.integers(0, 60000, 500)] + 0.2 * rng.standard_normal((500, 128))).astype(np.float32)
+    ids = list(range(60000))
+    flat = DenseFlatIndexer(128)
+    flat.index_tensor(ids, torch.from_numpy(x).cuda())
+    want = flat.search_knn(q, 10)
+    approx = DenseHNSWFlatIndexer(128, ef_search=64, approximate=True)        # probes 16 of ~245 lists
+    approx.index_tensor(ids, torch.from_numpy(x))
+    got = approx.search_knn(q, 10)
+    recall = np.mean([len(set(g[0]) & set(w[0])) / 10.0 for g, w in zip(got, want)])
+    assert recall > 0.9, recall
+    assert np.mean([g[0][0] == w[0][0] for g, w in zip(got, want)]) > 0.95
+    # the surface's score semantics: squared L2 distances of the phi-augmented vectors, ascending (faiss_indexers.py:137-150)
+    phi = float((x.astype(np.float64) ** 2).sum(1).max())
+    for (gi, gd), qq in list(zip(got, q))[:50]:
+        assert (np.diff(gd) >= -1e-3).all()
+        ip = x[gi[0]].astype(np.float64) @ qq.astype(np.float64)
+        assert abs(gd[0] - ((qq.astype(np.float64) ** 2).sum() + phi - 2 * ip)) < 1e-2 * max(1.0, abs(gd[0]))
+    with pytest.raises(RuntimeError):
+        approx.index_tensor([1], torch.zeros(1, 128))                           # all data at once (:111-113)
+
+
+def test_ivf_persistence_roundtrip(tmp_path):
+    import torch
+    from lightningdot_amd.ivf import DenseIVFFlatIndexer
+    x, rng = _clustered(8000, 64, 30, 3)
+    q = x[:40] + 0.1
+    a = DenseIVFFlatIndexer(64, nlist=32, nprobe=6)
+    a.index_tensor([f'i{i}' for i in range(8000)], torch.from_numpy(x))
+    ra = a.search_knn(q, 10)
+    a.serialize(str(tmp_path / 'ix'))
+    b = DenseIVFFlatIndexer(64)
+    b.deserialize_from(str(tmp_path / 'ix'))
+    rb = b.search_knn(q, 10)
+    assert [r[0] for r in ra] == [r[0] for r in rb]
+    np.testing.assert_array_equal(np.stack([r[1] for r in ra]), np.stack([r[1] for r in rb]))
+
+
+def test_search_lists_entry_point_vs_brute_force():
+    """ldot_index_search_lists on hand-made lists (uneven, one empty, a -1 probe): equals a numpy scan of exactly those rows"""
+    import torch
+    from lightningdot_amd import _lib as L
+    from lightningdot_amd.indexer import FlatIPIndex
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((5000, 200)).astype(np.float32)
+    q = rng.standard_normal((33, 200)).astype(np.float32)
+    offs = np.array([0, 700, 700, 2100, 2164, 5000], dtype=np.int64)            # 5 lists: 700, 0, 1400, 64, 2836 rows
+    probes = np.stack([rng.permutation(5)[:3] for _ in range(33)]).astype(np.int32)
+    probes[5, 1] = -1
+    ix = FlatIPIndex(200)
+    ix.add(x)
+    k = 20
+    s = torch.empty((33, k), dtype=torch.float32, device='cuda')
+    l = torch.empty((33, k), dtype=torch.int64, device='cuda')
+    qd, od, pd = torch.from_numpy(q).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(probes).cuda()
+    L.check(ix._lib.ldot_index_search_lists(ix._h, ctypes.c_void_p(qd.data_ptr()), 33, L.F32, 0, ctypes.c_void_p(od.data_ptr()), 5,
+                                            2836, ctypes.c_void_p(pd.data_ptr()), 3, k, ctypes.c_void_p(s.data_ptr()),
+                                            ctypes.c_void_p(l.data_ptr()), L.DEVICE,
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    s, l = s.cpu().numpy(), l.cpu().numpy()
+    for i in range(33):
+        rows = np.concatenate([np.arange(offs[p], offs[p + 1]) for p in probes[i] if p >= 0]) if (probes[i] >= 0).any() else np.array([], int)
+        sc = x[rows].astype(np.float64) @ q[i].astype(np.float64)
+        order = np.lexsort((rows, -sc))[:k]
+        nv = len(order)
+        np.testing.assert_allclose(s[i, :nv], sc[order], rtol=0, atol=2e-4)
+        assert set(l[i, :nv]) == set(rows[order]) or np.abs(np.sort(sc[order]) - np.sort(s[i, :nv].astype(np.float64))).max() < 2e-4
+        assert l[i, 0] == rows[order[0]]
+        assert (l[i, nv:] == -1).all()
