@@ -795,7 +795,7 @@ int ldot_index_search_lists(ldot_index_t* ix, const void* queries, int64_t nq, i
                                       st)))
             return rc;
         if ((rc = launch_scan_lists((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, n, list_offsets,
-                                    probes + q0 * nprobe, nprobe, lpad, (float*)ix->w_S.p, ncols, st)))
+                                    probes + q0 * nprobe, nprobe, nlist, lpad, (float*)ix->w_S.p, ncols, st)))
             return rc;
         ix->stats[2] += n * ncols;
         float* ls = (float*)ix->w_ls.p;
@@ -814,7 +814,7 @@ int ldot_index_search_lists(ldot_index_t* ix, const void* queries, int64_t nq, i
         if ((rc = launch_rescore((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, n, ls, li, kp, k, 0, nullptr, ds, dl,
                                  st)))
             return rc;
-        if ((rc = launch_translate_cols(dl, n, k, list_offsets, probes + q0 * nprobe, nprobe, lpad, st))) return rc;
+        if ((rc = launch_translate_cols(dl, n, k, list_offsets, probes + q0 * nprobe, nprobe, nlist, lpad, st))) return rc;
         if (out_mem == LDOT_HOST) {
             LDOT_HIP_CHECK(hipMemcpyAsync(out_scores + q0 * k, ds, (size_t)n * k * 4, hipMemcpyDeviceToHost, st));
             LDOT_HIP_CHECK(hipMemcpyAsync(out_labels + q0 * k, dl, (size_t)n * k * 8, hipMemcpyDeviceToHost, st));

@@ -82,10 +82,10 @@ int launch_verify_exact(const float* q32, int64_t ldq, int d, int64_t nq, const 
 // IVF list search: S[q][probe * lpad + o] = exact fp32 score of query q against row list_offsets[probes[q][probe]] + o (padding score
 // past the list's end); lpad a multiple of 64.  translate: column labels of a selection over S -> index rows (-1 for padding)
 int launch_scan_lists(const float* q32, int64_t ldq, const float* x32, int64_t ldx, int dpad, int64_t nq,
-                      const int64_t* list_offsets, const int32_t* probes, int nprobe, int lpad, float* S, int64_t lds_elems,
-                      hipStream_t st);
+                      const int64_t* list_offsets, const int32_t* probes, int nprobe, int nlist, int lpad, float* S,
+                      int64_t lds_elems, hipStream_t st);
 int launch_translate_cols(int64_t* labels, int64_t nq, int k, const int64_t* list_offsets, const int32_t* probes, int nprobe,
-                          int lpad, hipStream_t st);
+                          int nlist, int lpad, hipStream_t st);
 
 int fused_tile_rows();
 int fused_query_group(int64_t nq_pad);   // 8 / 4 / 2 / 1 -> 1024 / qg sub-pools per query, 256 / qg row slices

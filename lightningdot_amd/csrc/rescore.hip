@@ -122,13 +122,14 @@ __global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __rest
 // padding score (their columns are translated to label -1 afterwards).
 __global__ __launch_bounds__(256) void scan_lists_kernel(const float* __restrict__ q32, int64_t ldq, const float* __restrict__ x32,
                                                          int64_t ldx, int dpad, const int64_t* __restrict__ list_offsets,
-                                                         const int32_t* __restrict__ probes, int nprobe, int lpad,
+                                                         const int32_t* __restrict__ probes, int nprobe, int nlist, int lpad,
                                                          float* __restrict__ S, int64_t lds_elems) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t q = blockIdx.y;
     const int probe = blockIdx.x / (lpad / 64), blk = blockIdx.x % (lpad / 64);
     const int32_t list = probes[q * nprobe + probe];
-    const int64_t r_beg = list >= 0 ? list_offsets[list] : 0, r_end = list >= 0 ? list_offsets[list + 1] : 0;
+    const bool ok = list >= 0 && list < nlist;      // (-1 = skip; an out-of-range list id is treated the same way)
+    const int64_t r_beg = ok ? list_offsets[list] : 0, r_end = ok ? list_offsets[list + 1] : 0;
     const int o0 = blk * 64 + wave * 16;
     float* out = S + q * lds_elems + (int64_t)probe * lpad + o0;
     const float* qrow = q32 + q * ldq;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void scan_lists_kernel(const float* __restrict
 // labels of the list search are COLUMNS of S (probe * lpad + offset): -> index rows, or -1 past a list's end / for padding
 __global__ __launch_bounds__(256) void translate_cols_kernel(int64_t* __restrict__ labels, int64_t n, int k,
                                                              const int64_t* __restrict__ list_offsets,
-                                                             const int32_t* __restrict__ probes, int nprobe, int lpad) {
+                                                             const int32_t* __restrict__ probes, int nprobe, int nlist, int lpad) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int64_t col = labels[i];
@@ -180,27 +181,27 @@ __global__ __launch_bounds__(256) void translate_cols_kernel(int64_t* __restrict
     if (col >= 0) {
         const int probe = (int)(col / lpad), off = (int)(col % lpad);
         const int32_t list = probes[(i / k) * nprobe + probe];
-        if (list >= 0 && list_offsets[list] + off < list_offsets[list + 1]) row = list_offsets[list] + off;
+        if (list >= 0 && list < nlist && list_offsets[list] + off < list_offsets[list + 1]) row = list_offsets[list] + off;
     }
     labels[i] = row;
 }
 
 int launch_scan_lists(const float* q32, int64_t ldq, const float* x32, int64_t ldx, int dpad, int64_t nq,
-                      const int64_t* list_offsets, const int32_t* probes, int nprobe, int lpad, float* S, int64_t lds_elems,
-                      hipStream_t st) {
+                      const int64_t* list_offsets, const int32_t* probes, int nprobe, int nlist, int lpad, float* S,
+                      int64_t lds_elems, hipStream_t st) {
     if (nq <= 0 || nprobe <= 0) return LDOT_OK;
     hipLaunchKernelGGL(scan_lists_kernel, dim3((unsigned)(nprobe * (lpad / 64)), (unsigned)nq), dim3(256), 0, st, q32, ldq, x32, ldx,
-                       dpad, list_offsets, probes, nprobe, lpad, S, lds_elems);
+                       dpad, list_offsets, probes, nprobe, nlist, lpad, S, lds_elems);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }
 
 int launch_translate_cols(int64_t* labels, int64_t nq, int k, const int64_t* list_offsets, const int32_t* probes, int nprobe,
-                          int lpad, hipStream_t st) {
+                          int nlist, int lpad, hipStream_t st) {
     const int64_t n = nq * k;
     if (n <= 0) return LDOT_OK;
     hipLaunchKernelGGL(translate_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, labels, n, k, list_offsets, probes,
-                       nprobe, lpad);
+                       nprobe, nlist, lpad);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }
