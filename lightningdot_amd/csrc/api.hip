@@ -102,6 +102,11 @@ struct ldot_index {
     DevBuf w_unproven;
     int64_t unproven_n = 0;
     DevBuf w_norm;                   // device scalar: largest L2 norm of an indexed row
+    // narrow search (<= 16 queries): run maxima, threshold keys, candidate keys + counters (zero between searches)
+    DevBuf w_nmax, w_ntau, w_ncand, w_ncnt;
+    bool narrow_clean = false;
+    int32_t *h_nover = nullptr, *d_nover = nullptr;   // per-query "candidate buffer full" flags (pinned, device-mapped)
+    int64_t overflow_narrow = 0;                      // > 0: the pending overflow summary is h_nover[0 .. overflow_narrow)
     // a search in two halves (ldot_index_search_begin / _finish): what _finish needs to know
     int64_t pend_nq = 0;
     int pend_k = 0, pend_kp = 0;
@@ -187,7 +192,12 @@ int ldot_index_destroy(ldot_index_t* ix) {
     ix->w_qcnt.release();
     ix->w_unproven.release();
     ix->w_norm.release();
+    ix->w_nmax.release();
+    ix->w_ntau.release();
+    ix->w_ncand.release();
+    ix->w_ncnt.release();
     if (ix->h_over_sum) (void)hipHostFree(ix->h_over_sum);
+    if (ix->h_nover) (void)hipHostFree(ix->h_nover);
     delete ix;
     return LDOT_OK;
 }
@@ -430,6 +440,10 @@ static int dense_scan(ldot_index* ix, int64_t q0, int64_t nqb, int64_t nqb_pad, 
     return LDOT_OK;
 }
 
+static bool narrow_ok(const ldot_index* ix, int64_t nq) {
+    return nq <= kNarrowMaxQueries && ix->ld16() / 32 <= kNarrowMaxSlabs;
+}
+
 // Few queries (one query tile) x many rows — the single-query serving shape (dvl/utils.py:204-211): one wide score
 // launch over up to 4M rows (only the valid query rows are stored), a segmented select with (query, segment)
 // parallelism and one merge.  HBM-bound: the index is streamed once.
@@ -448,8 +462,12 @@ static int dense_scan_wide(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, i
         if ((rc = ix->w_part_l.ensure((size_t)nseg * nq * kp * 8))) return rc;
         prof_begin(ix, st, 2.0 * nq * nrows * ix->d,
                    (double)nrows * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * nrows * 4);
-        rc = launch_score_dense(ix->w_q16b.p, ix->ld16(), kBM, ix->x16b, ix->ld16(), r, nrows_pad, (int)ix->ld16(),
-                                (float*)ix->w_S.p, nrows_pad, nq, st);
+        if (narrow_ok(ix, nq))   // <= 16 queries: HBM-speed wave-per-group scan, no query-tile padding
+            rc = launch_score_narrow(ix->w_q16b.p, ix->x16b, ix->ld16(), r, nrows, (float*)ix->w_S.p, nrows_pad, (int)nq, nullptr, 0,
+                                     0, st);
+        else
+            rc = launch_score_dense(ix->w_q16b.p, ix->ld16(), kBM, ix->x16b, ix->ld16(), r, nrows_pad, (int)ix->ld16(),
+                                    (float*)ix->w_S.p, nrows_pad, nq, st);
         prof_end(ix, st);
         if (rc) return rc;
         float* ps = (float*)ix->w_part_s.p;
@@ -460,6 +478,74 @@ static int dense_scan_wide(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, i
         if ((rc = launch_merge_parts_into_lists(ps, pl, (int)nseg, nq, kp, ls, li, tau, st))) return rc;
         ix->stats[2] += nrows * nq;
     }
+    return LDOT_OK;
+}
+
+// <= 16 queries against any number of rows (the serving shape): the index is streamed once at HBM speed (score_narrow.hip) and the
+// lists are selected from the run maxima the scan leaves behind (select_narrow.hip) — convert + 4 kernels + re-score, no threshold
+// to learn.  Speculative like the fused scan: a query whose candidate buffer filled up (rows stored in cluster order) is counted in
+// w_over_sum and the caller redoes the search with the streaming selector.
+// run size of a scan over nrows rows: <= 2048 run maxima per query (a coarser run lowers the threshold but adds hardly any candidates),
+// <= 16384 when k' is large
+static void narrow_plan(int64_t nrows, int kp, int* run_shift, int* nruns) {
+    const int64_t ngroups = (nrows + 15) / 16, max_runs = kp <= 512 ? 2048 : kNarrowMaxRuns;
+    int sh = 0;
+    while (((ngroups - 1) >> sh) + 1 > max_runs) ++sh;
+    *run_shift = sh;
+    *nruns = (int)(((ngroups - 1) >> sh) + 1);
+}
+
+static bool narrow_select_ok(const ldot_index* ix, int64_t nq, int kp) {
+    if (!narrow_ok(ix, nq) || kp > kNarrowCandCap / 4) return false;
+    if (ix->ntotal <= kNarrowCandCap) return true;   // every row fits the candidate buffer
+    // enough runs for a useful threshold: the k'-th largest of m run maxima admits ~ln(m / (m - k')) * m rows of an unordered index
+    int sh, nruns;
+    narrow_plan(std::min<int64_t>(ix->ntotal, (int64_t)1 << 22), kp, &sh, &nruns);
+    return nruns >= (kp <= 512 ? 2 : 4) * (int64_t)kp;
+}
+
+static int narrow_search(ldot_index* ix, int64_t nq, int kp, hipStream_t st) {
+    const int64_t wide = (int64_t)1 << 22;
+    const int cap = kNarrowCandCap;
+    int rc;
+    if (!ix->h_nover) {   // per-query "buffer full" flags: pinned host memory the final kernel writes directly
+        LDOT_HIP_CHECK(hipHostMalloc((void**)&ix->h_nover, kNarrowMaxQueries * 4));
+        LDOT_HIP_CHECK(hipHostGetDevicePointer((void**)&ix->d_nover, ix->h_nover, 0));
+    }
+    if (ix->w_ncnt.bytes == 0 || ix->w_nmax.bytes == 0) ix->narrow_clean = false;
+    if ((rc = ix->w_nmax.ensure((size_t)kNarrowMaxQueries * kNarrowMaxRuns * 4))) return rc;
+    if ((rc = ix->w_ntau.ensure((size_t)kNarrowMaxQueries * 4))) return rc;
+    if ((rc = ix->w_ncand.ensure((size_t)kNarrowMaxQueries * cap * 8))) return rc;
+    if ((rc = ix->w_ncnt.ensure((size_t)kNarrowMaxQueries * 4))) return rc;
+    if (!ix->narrow_clean) {   // (the kernels leave both all-zero; cleared only after an allocation or an aborted search)
+        LDOT_HIP_CHECK(hipMemsetAsync(ix->w_ncnt.p, 0, ix->w_ncnt.bytes, st));
+        LDOT_HIP_CHECK(hipMemsetAsync(ix->w_nmax.p, 0, ix->w_nmax.bytes, st));
+    }
+    ix->narrow_clean = false;
+    uint32_t* M = (uint32_t*)ix->w_nmax.p;
+    uint32_t* tk = (uint32_t*)ix->w_ntau.p;
+    for (int64_t r = 0; r < ix->ntotal; r += wide) {
+        const int64_t nrows = std::min(wide, ix->ntotal - r), nrows_pad = round_up(nrows, 16);
+        int sh, nruns;
+        narrow_plan(nrows, kp, &sh, &nruns);
+        if ((rc = ix->w_S.ensure((size_t)nq * nrows_pad * sizeof(float)))) return rc;
+        prof_begin(ix, st, 2.0 * nq * nrows * ix->d, (double)nrows * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * nrows * 4);
+        rc = launch_score_narrow(ix->w_q16b.p, ix->x16b, ix->ld16(), r, nrows, (float*)ix->w_S.p, nrows_pad, (int)nq, M,
+                                 kNarrowMaxRuns, sh, st);
+        prof_end(ix, st);
+        if (rc) return rc;
+        if ((rc = launch_narrow_tau(M, kNarrowMaxRuns, nruns, (int)nq, kp, tk, st))) return rc;
+        if ((rc = launch_narrow_collect((const float*)ix->w_S.p, nrows_pad, M, kNarrowMaxRuns, nruns, 16 << sh, nrows, r, (int)nq, tk,
+                                        (uint64_t*)ix->w_ncand.p, cap, (int32_t*)ix->w_ncnt.p, st)))
+            return rc;
+        ix->stats[2] += nrows * nq;
+    }
+    if ((rc = launch_narrow_final((const uint64_t*)ix->w_ncand.p, cap, (int32_t*)ix->w_ncnt.p, (int)nq, (float*)ix->w_ls.p,
+                                  (int32_t*)ix->w_li.p, kp, (float*)ix->w_tau.p, ix->d_nover, st)))
+        return rc;
+    ix->narrow_clean = true;
+    ix->overflow_pending = true;
+    ix->overflow_narrow = nq;
     return LDOT_OK;
 }
 
@@ -582,6 +668,13 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
 static bool fused_overflow_check(ldot_index* ix) {
     if (!ix->overflow_pending) return false;
     ix->overflow_pending = false;
+    if (ix->overflow_narrow > 0) {   // narrow search: flags written by its final kernel
+        int64_t n = 0;
+        for (int64_t q = 0; q < ix->overflow_narrow; ++q) n += ix->h_nover[q];
+        ix->overflow_narrow = 0;
+        ix->stats[1] = n;
+        return n > 0;
+    }
     const int64_t n_over = ix->h_over_sum[0];
     ix->stats[1] = n_over;
     ix->flags_clean = n_over == 0;
@@ -605,6 +698,7 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
     LDOT_REQUIRE(mem == LDOT_HOST || mem == LDOT_DEVICE, LDOT_EINVAL, "bad memory space");
     ix->pend_nq = 0;
     ix->overflow_pending = false;
+    ix->overflow_narrow = 0;
     ix->qcnt_n = 0;
     ix->unproven_n = 0;
     if (nq == 0) return LDOT_OK;
@@ -632,13 +726,24 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
                                   nullptr, ix->precision ? 2 : 0, (uint16_t*)ix->w_q16b.p, 0, st)))
         return rc;
     float* tau = (float*)ix->w_tau.p;
-    if ((rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, tau, nq, nq_pad, st))) return rc;
+    // (the narrow search writes complete lists and thresholds itself)
+    const bool narrow = ix->ntotal > 0 && ix->mode == LDOT_MODE_AUTO && narrow_select_ok(ix, nq, kp);
+    if (!narrow && (rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, tau, nq, nq_pad, st))) return rc;
 
-    if (ix->ntotal > 0) {
+    if (narrow) {
+        if ((rc = narrow_search(ix, nq, kp, st))) return rc;
+        if (!defer_check) {
+            LDOT_HIP_CHECK(hipStreamSynchronize(st));
+            if (fused_overflow_check(ix) && (rc = dense_redo(ix, nq, nq_pad, kp, st))) return rc;
+        }
+    } else if (ix->ntotal > 0) {
         // AUTO: the fused scan pays off from ~32k rows (tools/auto_threshold.py); very large batches (COCO-5k sized image->text
         // with the reference's un-deduplicated queries) already from 16k rows, where the dense score matrix is the cost
+        // <= 16 queries: one pass over the index at HBM speed (score_narrow.hip) + segmented select beats the fused scan's
+        // warm-up / filter / pool-select chain at every index size (tools/serving_latency.py)
         const bool fused = ix->mode == LDOT_MODE_FUSED ||
-                           (ix->mode == LDOT_MODE_AUTO && (ix->ntotal >= 32768 || (ix->ntotal >= 16384 && nq >= 16384)));
+                           (ix->mode == LDOT_MODE_AUTO && !narrow_ok(ix, nq) &&
+                            (ix->ntotal >= 32768 || (ix->ntotal >= 16384 && nq >= 16384)));
         if (fused) {
             if ((rc = fused_scan(ix, nq, nq_pad, kp, st))) return rc;
             if (!defer_check) {

@@ -37,6 +37,22 @@ int launch_score_dense(const void* q16, int64_t ldq_elems, int64_t nq_pad, const
                        int64_t xrow0, int64_t nrows_pad, int dpad, float* S, int64_t lds_elems, int64_t nq_valid,
                        hipStream_t st);
 
+// <= 16 queries (serving): wave-per-16-row-group scan straight from global memory (score_narrow.hip)
+constexpr int kNarrowMaxQueries = 16, kNarrowMaxSlabs = 64;
+constexpr int kNarrowMaxRuns = 16384;   // run maxima per query and launch (select_narrow.hip keeps them in one workgroup's registers)
+constexpr int kNarrowCandCap = 8192;    // candidate keys per query (64 KiB of LDS in the final sort)
+// M (optional, zero on entry) [nq][ldm]: ascending keys (~desc_key) of the per-run maxima over the valid rows, run = 16 << run_shift rows
+int launch_score_narrow(const void* q16b, const void* x16b, int64_t ld_elems, int64_t xrow0, int64_t nrows, float* S,
+                        int64_t lds_elems, int nq, uint32_t* M, int64_t ldm, int run_shift, hipStream_t st);
+// selection from the run maxima (select_narrow.hip): threshold key per query, candidate collection (leaves M zero again), final
+// sorted lists.  cnt [nq] must be zero before the first collect of a search (the final kernel leaves it zero); over[q] = 1 marks a
+// query whose candidate buffer was full (its list is unusable).
+int launch_narrow_tau(const uint32_t* M, int64_t ldm, int nruns, int nq, int kp, uint32_t* tau_key, hipStream_t st);
+int launch_narrow_collect(const float* S, int64_t lds_elems, uint32_t* M, int64_t ldm, int nruns, int run_rows, int64_t nrows,
+                          int64_t row0, int nq, const uint32_t* tau_key, uint64_t* cand, int cap, int32_t* cnt, hipStream_t st);
+int launch_narrow_final(const uint64_t* cand, int cap, int32_t* cnt, int nq, float* list_s, int32_t* list_i, int kp, float* tau,
+                        int32_t* over, hipStream_t st);
+
 // lists: [nq][kp] fp32 scores + int32 rows, kept sorted (score desc, row asc); empty slots have row -1.
 // also initialises the admission thresholds when tau != nullptr: -inf for queries < nq, +inf for the pad queries
 int launch_init_lists(float* list_s, int32_t* list_i, int64_t n, float* tau, int64_t nq, int64_t nq_pad, hipStream_t st);

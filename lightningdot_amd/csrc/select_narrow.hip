@@ -1,0 +1,164 @@
+// Top-k' of a few (<= 16) very long score rows — the selection behind the narrow scan (score_narrow.hip), replacing faiss' per-query
+// heap over the whole index (dvl/indexer/faiss_indexers.py:83 -> IndexFlatIP.search with nq = 1, the demo of dvl/utils.py:204-211).
+//
+// The streaming selector of select.hip needs ~70 us to learn its threshold on a fresh row however many workgroups share the row.
+// Here the threshold comes from the RUN MAXIMA the scan kernel leaves behind (one maximum per run of 16 << run_shift rows, <= 16384 per query):
+//
+//   tau = the k'-th largest run maximum.   Each run maximum IS the score of a row, so at least k' rows score >= tau, hence the k'-th
+//   best row scores >= tau and every row of the exact top-k' satisfies score >= tau — and lies in a run whose maximum is >= tau.
+//
+// 1. narrow_tau_kernel      one workgroup per query: exact k'-th largest of the run maxima (bit search on the order-preserving keys,
+//                           values in registers, one barrier per bit).  A COARSER run gives a lower threshold, yet hardly more
+//                           candidates (1M unordered rows, k' = 200: 205 candidates from 256-row runs, 218 from 1024-row runs), so
+//                           runs are sized for <= 2048 maxima per query (8 per thread of a 256-thread workgroup) unless k' is large
+// 2. narrow_collect_kernel  visits only the runs with maximum >= tau (~k' of them) and appends their rows with score >= tau to the
+//                           query's candidate buffer (for unordered rows ~1.01 k' candidates; rows stored in cluster order give more —
+//                           a full buffer is reported and the caller redoes the search with the streaming selector)
+// 3. narrow_final_kernel    sorts the candidates (score descending, row ascending) into the query's list, sets the list threshold.
+#include <math.h>
+
+#include "bitonic.h"
+#include "kernels.h"
+
+namespace ldot {
+
+// THREADS x NV >= nruns run maxima in registers
+template <int THREADS, int NV>
+__global__ __launch_bounds__(THREADS) void narrow_tau_kernel(const uint32_t* __restrict__ M, int64_t ldm, int nruns, int kp,
+                                                            uint32_t* __restrict__ tau_key) {
+    __shared__ int part[2][THREADS / 64];
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (nruns < kp) {   // fewer runs than list slots: every row is a candidate
+        if (tid == 0) tau_key[q] = 0xffffffffu;
+        return;
+    }
+    uint32_t key[NV];   // descending keys: smaller key = larger score
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int r = v * THREADS + tid;
+        key[v] = r < nruns ? ~M[(int64_t)q * ldm + r] : 0xffffffffu;
+    }
+    // smallest key value t with #(keys <= t) >= kp, most significant bit first
+    uint32_t res = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t test = res | ((1u << bit) - 1u);
+        // wave count through ballots: scalar popcounts, no cross-lane shuffles (a shuffle reduction is a chain of 6 LDS-pipe
+        // round trips per bit and was 3/4 of this kernel)
+        int cnt = 0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) cnt += __popcll(__ballot(key[v] <= test));
+        int* p = part[bit & 1];
+        if (lane == 0) p[wave] = cnt;
+        __syncthreads();
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < THREADS / 64; ++w) tot += p[w];
+        // (pad keys 0xffffffff only count when test is all ones, i.e. never before the real keys have been exhausted)
+        if (tot < kp) res |= 1u << bit;
+    }
+    if (tid == 0) tau_key[q] = res;
+}
+
+// grid (ceil(nruns / 4), nq): one WAVE per run — it looks at the run's maximum (and leaves it zero for the next scan) and, if that
+// qualifies, scans the run's rows, 4 loads in flight per lane
+__global__ __launch_bounds__(256) void narrow_collect_kernel(const float* __restrict__ S, int64_t lds_elems, uint32_t* __restrict__ M,
+                                                             int64_t ldm, int nruns, int run_rows, int64_t nrows, int64_t row0,
+                                                             const uint32_t* __restrict__ tau_key, uint64_t* __restrict__ cand,
+                                                             int cap, int32_t* __restrict__ cnt) {
+    const int q = blockIdx.y, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nruns) return;
+    const uint32_t tk = tau_key[q];
+    const uint32_t mk = M[(int64_t)q * ldm + r];
+    if (lane == 0) M[(int64_t)q * ldm + r] = 0;
+    if (~mk > tk) return;
+    const float* s_row = S + (int64_t)q * lds_elems;
+    uint64_t* c_row = cand + (int64_t)q * cap;
+    const int64_t c0 = (int64_t)r * run_rows;
+    const int64_t c1 = c0 + run_rows < nrows ? c0 + run_rows : nrows;
+    for (int64_t cb = c0; cb < c1; cb += 256) {   // (wave-uniform trip count: the ballots below are wave-wide)
+        float sv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t c = cb + u * 64 + lane;
+            sv[u] = c < c1 ? s_row[c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t c = cb + u * 64 + lane;
+            const bool hit = c < c1 && desc_key(sv[u]) <= tk;
+            const unsigned long long hm = __ballot(hit);
+            if (hm) {
+                const int leader = __ffsll((long long)hm) - 1;
+                int base = 0;
+                if (lane == leader) base = atomicAdd(cnt + q, __popcll(hm));
+                base = __shfl(base, leader);
+                const int pos = base + __popcll(hm & ((1ull << lane) - 1ull));
+                if (hit && pos < cap) c_row[pos] = ((uint64_t)desc_key(sv[u]) << 32) | (uint32_t)(row0 + c);
+            }
+        }
+    }
+}
+
+// one workgroup per query: candidates -> sorted list [kp] (score desc, row asc; empty slots: pad score, row -1), list threshold
+__global__ __launch_bounds__(256) void narrow_final_kernel(const uint64_t* __restrict__ cand, int cap, int32_t* __restrict__ cnt,
+                                                           float* __restrict__ list_s, int32_t* __restrict__ list_i, int kp,
+                                                           float* __restrict__ tau, int32_t* __restrict__ over) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
+    const int q = blockIdx.x;
+    int n = cnt[q];
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[q] = 0;   // ready for the next search
+    if (threadIdx.x == 0) over[q] = n > cap ? 1 : 0;   // (a full buffer makes the list unusable: the caller redoes the search)
+    if (n > cap) n = cap;
+    int P = 2;
+    while (P < n) P <<= 1;
+    for (int i = threadIdx.x; i < P; i += 256) keys[i] = i < n ? cand[(int64_t)q * cap + i] : ~0ull;
+    __syncthreads();
+    bitonic_sort_lds(keys, P);
+    for (int i = threadIdx.x; i < kp; i += 256) {
+        const bool have = i < n;
+        const uint64_t k = have ? keys[i] : 0;
+        list_s[(int64_t)q * kp + i] = have ? desc_key_to_float((uint32_t)(k >> 32)) : LDOT_PAD_SCORE;
+        list_i[(int64_t)q * kp + i] = have ? (int32_t)(uint32_t)k : -1;
+    }
+    if (threadIdx.x == 0) tau[q] = n >= kp ? desc_key_to_float((uint32_t)(keys[kp - 1] >> 32)) : -INFINITY;
+}
+
+int launch_narrow_tau(const uint32_t* M, int64_t ldm, int nruns, int nq, int kp, uint32_t* tau_key, hipStream_t st) {
+    LDOT_REQUIRE(nruns >= 1 && nruns <= kNarrowMaxRuns && nq >= 1, LDOT_EINVAL, "bad run count");
+    if (nruns <= 2048)
+        hipLaunchKernelGGL((narrow_tau_kernel<256, 8>), dim3(nq), dim3(256), 0, st, M, ldm, nruns, kp, tau_key);
+    else
+        hipLaunchKernelGGL((narrow_tau_kernel<1024, kNarrowMaxRuns / 1024>), dim3(nq), dim3(1024), 0, st, M, ldm, nruns, kp, tau_key);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+int launch_narrow_collect(const float* S, int64_t lds_elems, uint32_t* M, int64_t ldm, int nruns, int run_rows, int64_t nrows,
+                          int64_t row0, int nq, const uint32_t* tau_key, uint64_t* cand, int cap, int32_t* cnt, hipStream_t st) {
+    hipLaunchKernelGGL(narrow_collect_kernel, dim3((nruns + 3) / 4, nq), dim3(256), 0, st, S, lds_elems, M, ldm, nruns, run_rows,
+                       nrows, row0, tau_key, cand, cap, cnt);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+static bool g_final_attr[64];
+
+// over [nq]: 1 where the candidate buffer was full (may be device-mapped host memory)
+int launch_narrow_final(const uint64_t* cand, int cap, int32_t* cnt, int nq, float* list_s, int32_t* list_i, int kp, float* tau,
+                        int32_t* over, hipStream_t st) {
+    LDOT_REQUIRE(cap >= 2 && (cap & (cap - 1)) == 0 && cap <= kNarrowCandCap && kp <= cap, LDOT_EINVAL, "bad candidate capacity");
+    int dev = 0;
+    LDOT_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 64 || !g_final_attr[dev]) {
+        LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)narrow_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           kNarrowCandCap * 8));
+        if (dev < 64) g_final_attr[dev] = true;
+    }
+    hipLaunchKernelGGL(narrow_final_kernel, dim3(nq), dim3(256), (size_t)cap * 8, st, cand, cap, cnt, list_s, list_i, kp, tau, over);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+}  // namespace ldot

@@ -291,6 +291,67 @@ def test_few_queries_wide_path(L, nq, n, d, k):
     assert l2[0, 0] == n + 7
 
 
+@pytest.mark.parametrize('nq,n,d,k', [
+    (1, 123_287, 768, 100),    # the demo's image index size (dvl/utils.py:204-211), 24 slabs -> 8 blocks in flight
+    (16, 40_000, 768, 100),    # the widest narrow batch
+    (3, 2_500, 64, 10),        # 2 slabs, fewer groups than waves
+    (5, 33_333, 96, 100),      # d padded to 128: 4 slabs; ragged last 16-row group
+    (2, 20, 768, 100),         # k > ntotal, one partial group (below 2048 rows: the plain dense path)
+    (9, 4_200_000, 64, 50),    # more rows than one wide chunk (4M): partial lists of two chunks are merged
+])
+def test_narrow_scan_up_to_16_queries(L, nq, n, d, k):
+    """<= 16 queries take the HBM-speed narrow scan (score_narrow.hip) in AUTO mode at every index size; the forced fused scan
+    must return the same lists."""
+    rng = np.random.default_rng(n * 3 + nq)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    q, g = planted_queries(x, nq)
+    ix = _index(x)
+    s, l = ix.search(q, k)
+    if n > k:
+        assert (l[:, 0] == g).all()
+    assert_topk_matches(q, x, s, l, k)
+    st = ix.last_stats()
+    assert st['fused_pairs'] == 0 and st['dense_pairs'] == n * nq
+    if n >= 70_000:
+        ix.set_option(L.OPT_MODE, L.MODE_FUSED)
+        s2, l2 = ix.search(q, k)
+        np.testing.assert_array_equal(l, l2)
+        np.testing.assert_array_equal(s, s2)
+
+
+def test_narrow_search_full_candidate_buffer_falls_back(L):
+    """Rows stored as runs of 64 identical copies: a run maximum stands for 64 equal scores, the candidate buffer (8192 keys) of the
+    narrow search fills up, the overflow is reported (stats) and the search is redone with the streaming selector — exact."""
+    rng = np.random.default_rng(11)
+    base = rng.standard_normal((5_000, 64)).astype(np.float32)
+    x = np.repeat(base, 64, axis=0)                      # 320 000 rows -> runs of 32 rows, every run constant
+    q = (base[[7, 4_001]] + 0.3 * rng.standard_normal((2, 64))).astype(np.float32)
+    ix = _index(x)
+    s, l = ix.search(q, 200)
+    st = ix.last_stats()
+    assert st['overflowed_queries'] == 2
+    assert_topk_matches(q, x, s, l, 200)
+    assert (l[0, :64] == np.arange(7 * 64, 8 * 64)).all()          # ties: ascending row order
+    # an ordinary search afterwards is clean again (counters were left zero)
+    x2 = rng.standard_normal((50_000, 64)).astype(np.float32)
+    ix2 = _index(x2)
+    q2, g2 = planted_queries(x2, 3)
+    for _ in range(2):
+        s2, l2 = ix2.search(q2, 10)
+        assert (l2[:, 0] == g2).all() and ix2.last_stats()['overflowed_queries'] == 0
+
+
+def test_narrow_scan_falls_back_when_rows_are_too_long(L):
+    """split-bf16 rows of d = 768 are 72 slabs (> 64 KiB of query operand in LDS): the ring engine handles them"""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((9_000, 768)).astype(np.float32)
+    q, g = planted_queries(x, 4)
+    ix = _index(x, precision=1)
+    s, l = ix.search(q, 20)
+    assert (l[:, 0] == g).all()
+    assert_topk_matches(q, x, s, l, 20)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('n,mode', [(5000, 'dense'), (60000, 'fused')])
 def test_split_bf16_precision_on_crowded_scores(L, n, mode):

@@ -7,10 +7,13 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lightningdot_amd.indexer import FlatIPIndex
 
-def run(n, nq=1, d=768, k=100, reps=200):
+def run(n, nq=1, d=768, k=100, reps=200, mode=None):
     torch.manual_seed(0)
     x = torch.randn(n, d, device='cuda')
     ix = FlatIPIndex(d); ix.add(x)
+    if mode is not None:
+        from lightningdot_amd import _lib as L
+        ix.set_option(L.OPT_MODE, mode)
     q = x[:nq] + 0.5 * torch.randn(nq, d, device='cuda')
     hs = torch.empty((nq, k), dtype=torch.float32).pin_memory(); hl = torch.empty((nq, k), dtype=torch.int64).pin_memory()
     for _ in range(10): ix.search_into(q, k, hs, hl)
@@ -20,7 +23,7 @@ def run(n, nq=1, d=768, k=100, reps=200):
     ts.sort()
     ok = bool((hl[:, 0] == torch.arange(nq)).all())
     med = ts[len(ts) // 2]
-    return dict(rows=n, queries=nq, ms_median=med * 1e3, ms_p10=ts[len(ts) // 10] * 1e3, ms_p90=ts[9 * len(ts) // 10] * 1e3,
+    return dict(rows=n, queries=nq, mode={None: 'auto', 2: 'fused'}[mode], ms_median=med * 1e3, ms_p10=ts[len(ts) // 10] * 1e3, ms_p90=ts[9 * len(ts) // 10] * 1e3,
                 hbm_frac_of_8TBps=n * d * 2 / med / 8e12, rank1_ok=ok)
 
 if __name__ == '__main__':
@@ -28,3 +31,5 @@ if __name__ == '__main__':
     for n in ([only] if only else [1_000_000, 123_287]):
         for nq in (1, 16):
             print(json.dumps(run(n, nq)), flush=True)
+            if os.environ.get('LDOT_COMPARE_FUSED'):
+                print(json.dumps(run(n, nq, mode=2)), flush=True)
