@@ -516,7 +516,7 @@ static int narrow_search(ldot_index* ix, int64_t nq, int kp, hipStream_t st) {
     if ((rc = ix->w_nmax.ensure((size_t)kNarrowMaxQueries * kNarrowMaxRuns * 4))) return rc;
     if ((rc = ix->w_ntau.ensure((size_t)kNarrowMaxQueries * 4))) return rc;
     if ((rc = ix->w_ncand.ensure((size_t)kNarrowMaxQueries * cap * 8))) return rc;
-    if ((rc = ix->w_ncnt.ensure((size_t)kNarrowMaxQueries * 4))) return rc;
+    if ((rc = ix->w_ncnt.ensure((size_t)kNarrowMaxQueries * kNarrowCntStride * 4))) return rc;
     if (!ix->narrow_clean) {   // (the kernels leave both all-zero; cleared only after an allocation or an aborted search)
         LDOT_HIP_CHECK(hipMemsetAsync(ix->w_ncnt.p, 0, ix->w_ncnt.bytes, st));
         LDOT_HIP_CHECK(hipMemsetAsync(ix->w_nmax.p, 0, ix->w_nmax.bytes, st));

@@ -41,11 +41,12 @@ int launch_score_dense(const void* q16, int64_t ldq_elems, int64_t nq_pad, const
 constexpr int kNarrowMaxQueries = 16, kNarrowMaxSlabs = 64;
 constexpr int kNarrowMaxRuns = 16384;   // run maxima per query and launch (select_narrow.hip keeps them in one workgroup's registers)
 constexpr int kNarrowCandCap = 8192;    // candidate keys per query (64 KiB of LDS in the final sort)
+constexpr int kNarrowCntStride = 64;    // ints between the candidate counters of two queries (atomics on one cache line serialise)
 // M (optional, zero on entry) [nq][ldm]: ascending keys (~desc_key) of the per-run maxima over the valid rows, run = 16 << run_shift rows
 int launch_score_narrow(const void* q16b, const void* x16b, int64_t ld_elems, int64_t xrow0, int64_t nrows, float* S,
                         int64_t lds_elems, int nq, uint32_t* M, int64_t ldm, int run_shift, hipStream_t st);
 // selection from the run maxima (select_narrow.hip): threshold key per query, candidate collection (leaves M zero again), final
-// sorted lists.  cnt [nq] must be zero before the first collect of a search (the final kernel leaves it zero); over[q] = 1 marks a
+// sorted lists.  cnt [nq * kNarrowCntStride] must be zero before the first collect of a search (the final kernel leaves it zero); over[q] = 1 marks a
 // query whose candidate buffer was full (its list is unusable).
 int launch_narrow_tau(const uint32_t* M, int64_t ldm, int nruns, int nq, int kp, uint32_t* tau_key, hipStream_t st);
 int launch_narrow_collect(const float* S, int64_t lds_elems, uint32_t* M, int64_t ldm, int nruns, int run_rows, int64_t nrows,

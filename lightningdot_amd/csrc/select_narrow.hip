@@ -38,9 +38,12 @@ __global__ __launch_bounds__(THREADS) void narrow_tau_kernel(const uint32_t* __r
         const int r = v * THREADS + tid;
         key[v] = r < nruns ? ~M[(int64_t)q * ldm + r] : 0xffffffffu;
     }
-    // smallest key value t with #(keys <= t) >= kp, most significant bit first
-    uint32_t res = 0;
-    for (int bit = 31; bit >= 0; --bit) {
+    // smallest key value t with #(keys <= t) >= kp, most significant bit first.  The search stops after kTauBits bits and leaves
+    // the remaining low bits set: a slightly larger key = a slightly lower threshold (2^-9 relative), still a lower bound of the
+    // k'-th best score — a few more candidates for 12 fewer barrier rounds
+    constexpr int kTauBits = 20;
+    uint32_t res = (1u << (32 - kTauBits)) - 1u;
+    for (int bit = 31; bit >= 32 - kTauBits; --bit) {
         const uint32_t test = res | ((1u << bit) - 1u);
         // wave count through ballots: scalar popcounts, no cross-lane shuffles (a shuffle reduction is a chain of 6 LDS-pipe
         // round trips per bit and was 3/4 of this kernel)
@@ -59,42 +62,42 @@ __global__ __launch_bounds__(THREADS) void narrow_tau_kernel(const uint32_t* __r
     if (tid == 0) tau_key[q] = res;
 }
 
-// grid (ceil(nruns / 4), nq): one WAVE per run — it looks at the run's maximum (and leaves it zero for the next scan) and, if that
-// qualifies, scans the run's rows, 4 loads in flight per lane
+// grid (<= ceil(nruns / 4), nq), waves stride over the runs: one WAVE per run — it looks at the run's maximum (and leaves it zero for
+// the next scan) and, if that qualifies, scans the run's rows, 4 loads in flight per lane
 __global__ __launch_bounds__(256) void narrow_collect_kernel(const float* __restrict__ S, int64_t lds_elems, uint32_t* __restrict__ M,
                                                              int64_t ldm, int nruns, int run_rows, int64_t nrows, int64_t row0,
                                                              const uint32_t* __restrict__ tau_key, uint64_t* __restrict__ cand,
                                                              int cap, int32_t* __restrict__ cnt) {
     const int q = blockIdx.y, lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= nruns) return;
     const uint32_t tk = tau_key[q];
-    const uint32_t mk = M[(int64_t)q * ldm + r];
-    if (lane == 0) M[(int64_t)q * ldm + r] = 0;
-    if (~mk > tk) return;
     const float* s_row = S + (int64_t)q * lds_elems;
     uint64_t* c_row = cand + (int64_t)q * cap;
-    const int64_t c0 = (int64_t)r * run_rows;
-    const int64_t c1 = c0 + run_rows < nrows ? c0 + run_rows : nrows;
-    for (int64_t cb = c0; cb < c1; cb += 256) {   // (wave-uniform trip count: the ballots below are wave-wide)
-        float sv[4];
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < nruns; r += gridDim.x * 4) {
+        const uint32_t mk = M[(int64_t)q * ldm + r];
+        if (lane == 0) M[(int64_t)q * ldm + r] = 0;
+        if (~mk > tk) continue;
+        const int64_t c0 = (int64_t)r * run_rows;
+        const int64_t c1 = c0 + run_rows < nrows ? c0 + run_rows : nrows;
+        for (int64_t cb = c0; cb < c1; cb += 256) {   // (wave-uniform trip count: the ballots below are wave-wide)
+            float sv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t c = cb + u * 64 + lane;
-            sv[u] = c < c1 ? s_row[c] : 0.f;
-        }
+            for (int u = 0; u < 4; ++u) {
+                const int64_t c = cb + u * 64 + lane;
+                sv[u] = c < c1 ? s_row[c] : 0.f;
+            }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t c = cb + u * 64 + lane;
-            const bool hit = c < c1 && desc_key(sv[u]) <= tk;
-            const unsigned long long hm = __ballot(hit);
-            if (hm) {
-                const int leader = __ffsll((long long)hm) - 1;
-                int base = 0;
-                if (lane == leader) base = atomicAdd(cnt + q, __popcll(hm));
-                base = __shfl(base, leader);
-                const int pos = base + __popcll(hm & ((1ull << lane) - 1ull));
-                if (hit && pos < cap) c_row[pos] = ((uint64_t)desc_key(sv[u]) << 32) | (uint32_t)(row0 + c);
+            for (int u = 0; u < 4; ++u) {
+                const int64_t c = cb + u * 64 + lane;
+                const bool hit = c < c1 && desc_key(sv[u]) <= tk;
+                const unsigned long long hm = __ballot(hit);
+                if (hm) {
+                    const int leader = __ffsll((long long)hm) - 1;
+                    int base = 0;
+                    if (lane == leader) base = atomicAdd(cnt + q * kNarrowCntStride, __popcll(hm));
+                    base = __shfl(base, leader);
+                    const int pos = base + __popcll(hm & ((1ull << lane) - 1ull));
+                    if (hit && pos < cap) c_row[pos] = ((uint64_t)desc_key(sv[u]) << 32) | (uint32_t)(row0 + c);
+                }
             }
         }
     }
@@ -106,9 +109,9 @@ __global__ __launch_bounds__(256) void narrow_final_kernel(const uint64_t* __res
                                                            float* __restrict__ tau, int32_t* __restrict__ over) {
     extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
     const int q = blockIdx.x;
-    int n = cnt[q];
+    int n = cnt[q * kNarrowCntStride];
     __syncthreads();
-    if (threadIdx.x == 0) cnt[q] = 0;   // ready for the next search
+    if (threadIdx.x == 0) cnt[q * kNarrowCntStride] = 0;   // ready for the next search
     if (threadIdx.x == 0) over[q] = n > cap ? 1 : 0;   // (a full buffer makes the list unusable: the caller redoes the search)
     if (n > cap) n = cap;
     int P = 2;
@@ -137,7 +140,9 @@ int launch_narrow_tau(const uint32_t* M, int64_t ldm, int nruns, int nq, int kp,
 
 int launch_narrow_collect(const float* S, int64_t lds_elems, uint32_t* M, int64_t ldm, int nruns, int run_rows, int64_t nrows,
                           int64_t row0, int nq, const uint32_t* tau_key, uint64_t* cand, int cap, int32_t* cnt, hipStream_t st) {
-    hipLaunchKernelGGL(narrow_collect_kernel, dim3((nruns + 3) / 4, nq), dim3(256), 0, st, S, lds_elems, M, ldm, nruns, run_rows,
+    // (thousands of workgroups that exit at once cost more in dispatch than they do in work: 16 queries x 489 took 27 us)
+    const int want = (nruns + 3) / 4, lim = 1024 / nq > 16 ? 1024 / nq : 16;
+    hipLaunchKernelGGL(narrow_collect_kernel, dim3(want < lim ? want : lim, nq), dim3(256), 0, st, S, lds_elems, M, ldm, nruns, run_rows,
                        nrows, row0, tau_key, cand, cap, cnt);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
