@@ -125,6 +125,14 @@ int ldot_index_search_finish(ldot_index_t* ix, const float* floor, float* out_sc
 int ldot_index_search_lists(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int normalize, const int64_t* list_offsets,
                             int nlist, int64_t max_list_len, const int32_t* probes, int nprobe, int k, float* out_scores,
                             int64_t* out_labels, int out_mem, void* stream);
+/* The whole approximate query in one call: coarse search (which lists to probe) + list scan.  `coarse` is an ordinary index over the
+ * nlist = ntotal(coarse) list centroids in the augmented space of the reference's HNSW indexer (faiss_indexers.py:114-131) plus one
+ * coordinate: row l = [c_l, sqrt(phi - |c_l|^2), -|c~_l|^2 / 2] (dimension d + 2), so that its inner product with [q, 0, 1] ranks the
+ * lists by L2 distance to the query.  Queries are DEVICE memory of `dtype`, list_offsets [nlist+1] int64 DEVICE memory; the result is
+ * that of ldot_index_search_lists with probes = the nprobe nearest lists. */
+int ldot_ivf_search(ldot_index_t* ix, ldot_index_t* coarse, const void* queries, int64_t nq, int dtype, int normalize,
+                    const int64_t* list_offsets, int64_t max_list_len, int nprobe, int k, float* out_scores, int64_t* out_labels,
+                    int out_mem, void* stream);
 /* own on-disk format ("LDOTIDX1": header + fp32 rows); bf16 shadow is rebuilt on load */
 int ldot_index_save(ldot_index_t* ix, const char* path);
 int ldot_index_load(const char* path, ldot_index_t** out);

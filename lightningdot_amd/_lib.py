@@ -39,6 +39,7 @@ SYMBOLS = {
     'ldot_index_search_begin': (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     'ldot_index_search_finish': (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     'ldot_index_search_lists': (_i, [_vp, _vp, _i64, _i, _i, _vp, _i, _i64, _vp, _i, _i, _vp, _vp, _i, _vp]),
+    'ldot_ivf_search': (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i64, _i, _i, _vp, _vp, _i, _vp]),
     'ldot_index_save': (_i, [_vp, _c.c_char_p]),
     'ldot_index_load': (_i, [_c.c_char_p, _c.POINTER(_vp)]),
     'ldot_index_get_rows': (_i, [_vp, _i64, _i64, _vp, _i, _vp]),

@@ -104,6 +104,7 @@ struct ldot_index {
     DevBuf w_norm;                   // device scalar: largest L2 norm of an indexed row
     // narrow search (<= 16 queries): run maxima, threshold keys, candidate keys + counters (zero between searches)
     DevBuf w_nmax, w_ntau, w_ncand, w_ncnt;
+    DevBuf w_lplist, w_lrowbase, w_lcstart, w_laug, w_lprobe_s, w_lprobe_l;   // list search: validated probes, prefix sums, coarse query / result
     bool narrow_clean = false;
     int32_t *h_nover = nullptr, *d_nover = nullptr;   // per-query "candidate buffer full" flags (pinned, device-mapped)
     int64_t overflow_narrow = 0;                      // > 0: the pending overflow summary is h_nover[0 .. overflow_narrow)
@@ -196,6 +197,12 @@ int ldot_index_destroy(ldot_index_t* ix) {
     ix->w_ntau.release();
     ix->w_ncand.release();
     ix->w_ncnt.release();
+    ix->w_lplist.release();
+    ix->w_lcstart.release();
+    ix->w_lrowbase.release();
+    ix->w_laug.release();
+    ix->w_lprobe_s.release();
+    ix->w_lprobe_l.release();
     if (ix->h_over_sum) (void)hipHostFree(ix->h_over_sum);
     if (ix->h_nover) (void)hipHostFree(ix->h_nover);
     delete ix;
@@ -485,6 +492,30 @@ static int dense_scan_wide(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, i
 // lists are selected from the run maxima the scan leaves behind (select_narrow.hip) — convert + 4 kernels + re-score, no threshold
 // to learn.  Speculative like the fused scan: a query whose candidate buffer filled up (rows stored in cluster order) is counted in
 // w_over_sum and the caller redoes the search with the streaming selector.
+constexpr int64_t kListsQueryChunk = 256;   // queries per pass of the run-maxima selection (bounds its buffers and flag array)
+
+// buffers of the run-maxima selection (select_narrow.hip) for up to nq queries x ldm runs; M and the counters are kept all-zero
+// between searches by the kernels themselves and cleared here only after a (re)allocation or an aborted search
+static int narrow_buffers(ldot_index* ix, int64_t nq, int64_t ldm, hipStream_t st) {
+    int rc;
+    if (!ix->h_nover) {   // per-query "buffer full" flags: pinned host memory the final kernel writes directly
+        LDOT_HIP_CHECK(hipHostMalloc((void**)&ix->h_nover, kListsQueryChunk * 4));
+        LDOT_HIP_CHECK(hipHostGetDevicePointer((void**)&ix->d_nover, ix->h_nover, 0));
+    }
+    const size_t b_max = ix->w_nmax.bytes, b_cnt = ix->w_ncnt.bytes;
+    if ((rc = ix->w_nmax.ensure((size_t)nq * ldm * 4))) return rc;
+    if ((rc = ix->w_ntau.ensure((size_t)nq * 4))) return rc;
+    if ((rc = ix->w_ncand.ensure((size_t)nq * kNarrowCandCap * 8))) return rc;
+    if ((rc = ix->w_ncnt.ensure((size_t)nq * kNarrowCntStride * 4))) return rc;
+    if (ix->w_nmax.bytes != b_max || ix->w_ncnt.bytes != b_cnt) ix->narrow_clean = false;
+    if (!ix->narrow_clean) {
+        LDOT_HIP_CHECK(hipMemsetAsync(ix->w_ncnt.p, 0, ix->w_ncnt.bytes, st));
+        LDOT_HIP_CHECK(hipMemsetAsync(ix->w_nmax.p, 0, ix->w_nmax.bytes, st));
+    }
+    ix->narrow_clean = false;   // until the final kernel of this search has run
+    return LDOT_OK;
+}
+
 // run size of a scan over nrows rows: <= 2048 run maxima per query (a coarser run lowers the threshold but adds hardly any candidates),
 // <= 16384 when k' is large
 static void narrow_plan(int64_t nrows, int kp, int* run_shift, int* nruns) {
@@ -508,20 +539,7 @@ static int narrow_search(ldot_index* ix, int64_t nq, int kp, hipStream_t st) {
     const int64_t wide = (int64_t)1 << 22;
     const int cap = kNarrowCandCap;
     int rc;
-    if (!ix->h_nover) {   // per-query "buffer full" flags: pinned host memory the final kernel writes directly
-        LDOT_HIP_CHECK(hipHostMalloc((void**)&ix->h_nover, kNarrowMaxQueries * 4));
-        LDOT_HIP_CHECK(hipHostGetDevicePointer((void**)&ix->d_nover, ix->h_nover, 0));
-    }
-    if (ix->w_ncnt.bytes == 0 || ix->w_nmax.bytes == 0) ix->narrow_clean = false;
-    if ((rc = ix->w_nmax.ensure((size_t)kNarrowMaxQueries * kNarrowMaxRuns * 4))) return rc;
-    if ((rc = ix->w_ntau.ensure((size_t)kNarrowMaxQueries * 4))) return rc;
-    if ((rc = ix->w_ncand.ensure((size_t)kNarrowMaxQueries * cap * 8))) return rc;
-    if ((rc = ix->w_ncnt.ensure((size_t)kNarrowMaxQueries * kNarrowCntStride * 4))) return rc;
-    if (!ix->narrow_clean) {   // (the kernels leave both all-zero; cleared only after an allocation or an aborted search)
-        LDOT_HIP_CHECK(hipMemsetAsync(ix->w_ncnt.p, 0, ix->w_ncnt.bytes, st));
-        LDOT_HIP_CHECK(hipMemsetAsync(ix->w_nmax.p, 0, ix->w_nmax.bytes, st));
-    }
-    ix->narrow_clean = false;
+    if ((rc = narrow_buffers(ix, kNarrowMaxQueries, kNarrowMaxRuns, st))) return rc;
     uint32_t* M = (uint32_t*)ix->w_nmax.p;
     uint32_t* tk = (uint32_t*)ix->w_ntau.p;
     for (int64_t r = 0; r < ix->ntotal; r += wide) {
@@ -536,7 +554,7 @@ static int narrow_search(ldot_index* ix, int64_t nq, int kp, hipStream_t st) {
         if (rc) return rc;
         if ((rc = launch_narrow_tau(M, kNarrowMaxRuns, nruns, (int)nq, kp, tk, st))) return rc;
         if ((rc = launch_narrow_collect((const float*)ix->w_S.p, nrows_pad, M, kNarrowMaxRuns, nruns, 16 << sh, nrows, r, (int)nq, tk,
-                                        (uint64_t*)ix->w_ncand.p, cap, (int32_t*)ix->w_ncnt.p, st)))
+                                        (uint64_t*)ix->w_ncand.p, cap, (int32_t*)ix->w_ncnt.p, nullptr, 0, st)))
             return rc;
         ix->stats[2] += nrows * nq;
     }
@@ -544,8 +562,10 @@ static int narrow_search(ldot_index* ix, int64_t nq, int kp, hipStream_t st) {
                                   (int32_t*)ix->w_li.p, kp, (float*)ix->w_tau.p, ix->d_nover, st)))
         return rc;
     ix->narrow_clean = true;
-    ix->overflow_pending = true;
-    ix->overflow_narrow = nq;
+    if (ix->ntotal > cap) {   // (an index that fits the candidate buffer cannot fill it)
+        ix->overflow_pending = true;
+        ix->overflow_narrow = nq;
+    }
     return LDOT_OK;
 }
 
@@ -854,7 +874,128 @@ int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dty
     return LDOT_OK;
 }
 
-// Approximate (inverted-file) search: see ldot.h.  Exact fp32 scores of every query against the rows of its nprobe lists, top-k of those.
+// ---- approximate (inverted-file) search: see ldot.h -------------------------------------------------------------------------------
+// first version of the list scan, kept as the always-correct path (large k, or a query whose candidate buffer filled up): every probed
+// list padded to the longest one, streaming segmented select.  probes: int32 [n][nprobe] (device)
+static int lists_chunk_padded(ldot_index* ix, int64_t n, const int64_t* list_offsets, int nlist, int lpad, const int32_t* probes,
+                              int nprobe, int k, int kp, float* ds, int64_t* dl, hipStream_t st) {
+    const int64_t ncols = (int64_t)nprobe * lpad;
+    int rc;
+    if ((rc = ix->w_S.ensure((size_t)n * ncols * 4))) return rc;
+    if ((rc = ix->w_ls.ensure((size_t)n * kp * 4))) return rc;
+    if ((rc = ix->w_li.ensure((size_t)n * kp * 4))) return rc;
+    if ((rc = ix->w_tau.ensure((size_t)n * 4))) return rc;
+    const int64_t seg_cols = std::max<int64_t>(1024, std::min<int64_t>(16384, round_up((ncols + 15) / 16, 256)));
+    const int64_t nseg = (ncols + seg_cols - 1) / seg_cols;
+    if ((rc = ix->w_part_s.ensure((size_t)nseg * n * kp * 4))) return rc;
+    if ((rc = ix->w_part_l.ensure((size_t)nseg * n * kp * 8))) return rc;
+    if ((rc = launch_scan_lists((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, n, list_offsets, probes, nprobe, nlist,
+                                lpad, (float*)ix->w_S.p, ncols, st)))
+        return rc;
+    float* ls = (float*)ix->w_ls.p;
+    int32_t* li = (int32_t*)ix->w_li.p;
+    float* tau = (float*)ix->w_tau.p;
+    if ((rc = launch_init_lists(ls, li, n * kp, tau, n, n, st))) return rc;
+    if ((rc = launch_select_dense_parts((const float*)ix->w_S.p, ncols, n, ncols, seg_cols, 0, kp, (float*)ix->w_part_s.p,
+                                        (int64_t*)ix->w_part_l.p, st)))
+        return rc;
+    if ((rc = launch_merge_parts_into_lists((const float*)ix->w_part_s.p, (const int64_t*)ix->w_part_l.p, (int)nseg, n, kp, ls, li, tau,
+                                            st)))
+        return rc;
+    // final ordering (score desc, column asc) with the sort of the re-score kernel; no re-scoring: the scores are exact already
+    if ((rc = launch_rescore((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, n, ls, li, kp, k, 0, nullptr, ds, dl, st)))
+        return rc;
+    return launch_translate_cols(dl, n, k, list_offsets, probes, nprobe, nlist, lpad, st);
+}
+
+// queries: device memory of `dtype`; probes: device [nq][nprobe], int32 or int64 (the labels of a coarse search)
+static int lists_search_impl(ldot_index* ix, const void* queries, int64_t nq, int dtype, int normalize, const int64_t* list_offsets,
+                             int nlist, int64_t max_list_len, const void* probes, bool probes_int64, int nprobe, int k, float* out_scores,
+                             int64_t* out_labels, int out_mem, hipStream_t st) {
+    ix->pend_nq = 0;
+    ix->overflow_pending = false;
+    ix->overflow_narrow = 0;
+    ix->qcnt_n = 0;
+    ix->unproven_n = 0;
+    for (int i = 0; i < 4; ++i) ix->stats[i] = 0;
+    const int kp = (int)round_up(k, 32);           // the candidates carry exact scores: no margin
+    const int lpad = (int)round_up(std::max<int64_t>(max_list_len, 1), 64);
+    const int64_t max_cols = (int64_t)nprobe * lpad;   // upper bound of a query's column count
+    LDOT_REQUIRE(max_cols < ((int64_t)1 << 31), LDOT_EINVAL, "nprobe * list length too large");
+    // run-maxima selection: runs of 16 << run_shift columns, as long as it takes for <= 2048 runs per query (a coarser run hardly adds
+    // candidates and makes the threshold search a 256-thread job) — but a query with fewer than k' runs makes every row a candidate,
+    // which must fit the candidate buffer: run * k' <= capacity
+    int run_shift = 0;
+    while ((max_cols + (16 << run_shift) - 1) / (16 << run_shift) > 2048 && (int64_t)(32 << run_shift) * kp <= kNarrowCandCap) ++run_shift;
+    const int run = 16 << run_shift;
+    const int64_t nruns = (max_cols + run - 1) / run;
+    const bool compact = nruns <= kNarrowMaxRuns && (int64_t)run * kp <= kNarrowCandCap && (size_t)(nprobe + 1) * 12 <= 64 * 1024;
+    // queries are processed in chunks that bound the score workspace (<= 1 GiB)
+    int64_t qchunk = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)1 << 28) / max_cols));
+    if (compact) qchunk = std::min(qchunk, kListsQueryChunk);
+    int rc;
+    if ((rc = ix->w_q32.ensure((size_t)round_up(qchunk, kBM) * ix->dpad * 4))) return rc;
+    if ((rc = ix->w_S.ensure((size_t)qchunk * max_cols * 4))) return rc;
+    if ((rc = ix->w_lplist.ensure((size_t)qchunk * nprobe * 4))) return rc;
+    if ((rc = ix->w_lcstart.ensure((size_t)qchunk * (nprobe + 1) * 4))) return rc;
+    if ((rc = ix->w_lrowbase.ensure((size_t)qchunk * nprobe * 8))) return rc;
+    if (out_mem == LDOT_HOST) {
+        if ((rc = ix->w_outs.ensure((size_t)qchunk * k * 4))) return rc;
+        if ((rc = ix->w_outl.ensure((size_t)qchunk * k * 8))) return rc;
+    }
+    const size_t esz = dtype_size(dtype), psz = probes_int64 ? 8 : 4;
+    int32_t* plist = (int32_t*)ix->w_lplist.p;
+    int32_t* cstart = (int32_t*)ix->w_lcstart.p;
+    int64_t* rowbase = (int64_t*)ix->w_lrowbase.p;
+    for (int64_t q0 = 0; q0 < nq; q0 += qchunk) {
+        const int64_t n = std::min(qchunk, nq - q0);
+        const char* src = (const char*)queries + (size_t)q0 * ix->d * esz;
+        const char* pr = (const char*)probes + (size_t)q0 * nprobe * psz;
+        float* ds = out_mem == LDOT_DEVICE ? out_scores + q0 * k : (float*)ix->w_outs.p;
+        int64_t* dl = out_mem == LDOT_DEVICE ? out_labels + q0 * k : (int64_t*)ix->w_outl.p;
+        if ((rc = launch_convert_rows(src, dtype, ix->d, n, n, ix->d, ix->dpad, normalize, (float*)ix->w_q32.p, nullptr, 0, nullptr, 0,
+                                      st)))
+            return rc;
+        // validated list ids (int32) + the per-query prefix sums of the list lengths
+        if ((rc = launch_ivf_prefix(pr, probes_int64 ? 1 : 0, n, nprobe, nlist, list_offsets, plist, rowbase, cstart, st)))
+            return rc;
+        bool redo = !compact;
+        if (compact) {
+            if ((rc = narrow_buffers(ix, n, nruns, st))) return rc;
+            uint32_t* M = (uint32_t*)ix->w_nmax.p;
+            uint32_t* tk = (uint32_t*)ix->w_ntau.p;
+            if ((rc = launch_ivf_scan((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, n, rowbase, cstart, nprobe,
+                                      max_cols, run_shift, (float*)ix->w_S.p, max_cols, M, nruns, st)))
+                return rc;
+            if ((rc = launch_narrow_tau(M, nruns, (int)nruns, (int)n, kp, tk, st))) return rc;
+            if ((rc = launch_narrow_collect((const float*)ix->w_S.p, max_cols, M, nruns, (int)nruns, run, max_cols, 0, (int)n, tk,
+                                            (uint64_t*)ix->w_ncand.p, kNarrowCandCap, (int32_t*)ix->w_ncnt.p, cstart + nprobe, nprobe + 1,
+                                            st)))
+                return rc;
+            if ((rc = launch_ivf_final((const uint64_t*)ix->w_ncand.p, kNarrowCandCap, (int32_t*)ix->w_ncnt.p, n, rowbase, cstart, nprobe, k,
+                                       ds, dl, ix->d_nover, st)))
+                return rc;
+            ix->narrow_clean = true;
+            // a full candidate buffer (thousands of equal scores) is rare but must not go unnoticed: one synchronisation per chunk
+            LDOT_HIP_CHECK(hipStreamSynchronize(st));
+            for (int64_t q = 0; q < n; ++q) {
+                if (ix->h_nover[q]) {
+                    redo = true;
+                    ix->stats[1] += 1;
+                }
+            }
+        }
+        if (redo && (rc = lists_chunk_padded(ix, n, list_offsets, nlist, lpad, plist, nprobe, k, kp, ds, dl, st))) return rc;
+        ix->stats[2] += n * max_cols;
+        if (out_mem == LDOT_HOST) {
+            LDOT_HIP_CHECK(hipMemcpyAsync(out_scores + q0 * k, ds, (size_t)n * k * 4, hipMemcpyDeviceToHost, st));
+            LDOT_HIP_CHECK(hipMemcpyAsync(out_labels + q0 * k, dl, (size_t)n * k * 8, hipMemcpyDeviceToHost, st));
+            LDOT_HIP_CHECK(hipStreamSynchronize(st));
+        }
+    }
+    return LDOT_OK;
+}
+
 int ldot_index_search_lists(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int normalize, const int64_t* list_offsets,
                             int nlist, int64_t max_list_len, const int32_t* probes, int nprobe, int k, float* out_scores,
                             int64_t* out_labels, int out_mem, void* stream) {
@@ -866,67 +1007,41 @@ int ldot_index_search_lists(ldot_index_t* ix, const void* queries, int64_t nq, i
     if (nq == 0) return LDOT_OK;
     LDOT_REQUIRE(queries && list_offsets && probes && out_scores && out_labels, LDOT_EINVAL, "NULL buffer");
     DeviceGuard guard(ix->device);
+    return lists_search_impl(ix, queries, nq, dtype, normalize, list_offsets, nlist, max_list_len, probes, false, nprobe, k, out_scores,
+                             out_labels, out_mem, (hipStream_t)stream);
+}
+
+// The whole approximate query in one call: coarse search over the list centroids + list scan.  `coarse` indexes the nlist centroids
+// in the augmented space of the reference's HNSW indexer (faiss_indexers.py:114-131) with one more coordinate:
+// row l = [c~_l (d + 1), -|c~_l|^2 / 2], so that the inner product with [q, 0, 1] orders the lists by L2 distance to [q, 0].
+int ldot_ivf_search(ldot_index_t* ix, ldot_index_t* coarse, const void* queries, int64_t nq, int dtype, int normalize,
+                    const int64_t* list_offsets, int64_t max_list_len, int nprobe, int k, float* out_scores, int64_t* out_labels,
+                    int out_mem, void* stream) {
+    LDOT_REQUIRE(ix != nullptr && coarse != nullptr, LDOT_EINVAL, "index is NULL");
+    LDOT_REQUIRE(nq >= 0 && k >= 1 && k <= kMaxK, LDOT_EINVAL, "bad nq / k");
+    LDOT_REQUIRE(dtype >= 0 && dtype <= 2, LDOT_EINVAL, "bad dtype %d", dtype);
+    LDOT_REQUIRE(out_mem == LDOT_HOST || out_mem == LDOT_DEVICE, LDOT_EINVAL, "bad memory space");
+    LDOT_REQUIRE(coarse->d == ix->d + 2 && coarse->device == ix->device, LDOT_EINVAL,
+                 "the coarse index must hold (d + 2)-dimensional augmented centroids on the same device");
+    const int64_t nlist = coarse->ntotal;
+    LDOT_REQUIRE(nlist >= 1 && nlist < ((int64_t)1 << 31) && nprobe >= 1 && nprobe <= nlist && nprobe <= kMaxK && max_list_len >= 0,
+                 LDOT_EINVAL, "bad list geometry");
+    if (nq == 0) return LDOT_OK;
+    LDOT_REQUIRE(queries && list_offsets && out_scores && out_labels, LDOT_EINVAL, "NULL buffer");
+    DeviceGuard guard(ix->device);
     hipStream_t st = (hipStream_t)stream;
-    ix->pend_nq = 0;
-    ix->overflow_pending = false;
-    ix->qcnt_n = 0;
-    ix->unproven_n = 0;
-    for (int i = 0; i < 4; ++i) ix->stats[i] = 0;
-    const int kp = (int)round_up(k, 32);           // the candidates carry exact scores: no margin
-    const int lpad = (int)round_up(std::max<int64_t>(max_list_len, 1), 64);
-    const int64_t ncols = (int64_t)nprobe * lpad;
-    LDOT_REQUIRE(ncols < ((int64_t)1 << 31), LDOT_EINVAL, "nprobe * list length too large");
-    // queries are processed in chunks that bound the score workspace (<= 1 GiB)
-    const int64_t qchunk = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)1 << 28) / ncols));
     int rc;
-    if ((rc = ix->w_q32.ensure((size_t)round_up(qchunk, kBM) * ix->dpad * 4))) return rc;
-    if ((rc = ix->w_S.ensure((size_t)qchunk * ncols * 4))) return rc;
-    if ((rc = ix->w_ls.ensure((size_t)qchunk * kp * 4))) return rc;
-    if ((rc = ix->w_li.ensure((size_t)qchunk * kp * 4))) return rc;
-    if ((rc = ix->w_tau.ensure((size_t)qchunk * 4))) return rc;
-    const int64_t seg_cols = std::max<int64_t>(1024, std::min<int64_t>(16384, round_up((ncols + 15) / 16, 256)));
-    const int64_t nseg = (ncols + seg_cols - 1) / seg_cols;
-    if ((rc = ix->w_part_s.ensure((size_t)nseg * qchunk * kp * 4))) return rc;
-    if ((rc = ix->w_part_l.ensure((size_t)nseg * qchunk * kp * 8))) return rc;
-    if (out_mem == LDOT_HOST) {
-        if ((rc = ix->w_outs.ensure((size_t)qchunk * k * 4))) return rc;
-        if ((rc = ix->w_outl.ensure((size_t)qchunk * k * 8))) return rc;
-    }
-    const size_t esz = dtype_size(dtype);
-    for (int64_t q0 = 0; q0 < nq; q0 += qchunk) {
-        const int64_t n = std::min(qchunk, nq - q0);
-        const char* src = (const char*)queries + (size_t)q0 * ix->d * esz;
-        if ((rc = launch_convert_rows(src, dtype, ix->d, n, n, ix->d, ix->dpad, normalize, (float*)ix->w_q32.p, nullptr, 0, nullptr, 0,
-                                      st)))
-            return rc;
-        if ((rc = launch_scan_lists((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, n, list_offsets,
-                                    probes + q0 * nprobe, nprobe, nlist, lpad, (float*)ix->w_S.p, ncols, st)))
-            return rc;
-        ix->stats[2] += n * ncols;
-        float* ls = (float*)ix->w_ls.p;
-        int32_t* li = (int32_t*)ix->w_li.p;
-        float* tau = (float*)ix->w_tau.p;
-        if ((rc = launch_init_lists(ls, li, n * kp, tau, n, n, st))) return rc;
-        if ((rc = launch_select_dense_parts((const float*)ix->w_S.p, ncols, n, ncols, seg_cols, 0, kp, (float*)ix->w_part_s.p,
-                                            (int64_t*)ix->w_part_l.p, st)))
-            return rc;
-        if ((rc = launch_merge_parts_into_lists((const float*)ix->w_part_s.p, (const int64_t*)ix->w_part_l.p, (int)nseg, n, kp, ls, li,
-                                                tau, st)))
-            return rc;
-        float* ds = out_mem == LDOT_DEVICE ? out_scores + q0 * k : (float*)ix->w_outs.p;
-        int64_t* dl = out_mem == LDOT_DEVICE ? out_labels + q0 * k : (int64_t*)ix->w_outl.p;
-        // final ordering (score desc, column asc) with the sort of the re-score kernel; no re-scoring: the scores are exact already
-        if ((rc = launch_rescore((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, n, ls, li, kp, k, 0, nullptr, ds, dl,
-                                 st)))
-            return rc;
-        if ((rc = launch_translate_cols(dl, n, k, list_offsets, probes + q0 * nprobe, nprobe, nlist, lpad, st))) return rc;
-        if (out_mem == LDOT_HOST) {
-            LDOT_HIP_CHECK(hipMemcpyAsync(out_scores + q0 * k, ds, (size_t)n * k * 4, hipMemcpyDeviceToHost, st));
-            LDOT_HIP_CHECK(hipMemcpyAsync(out_labels + q0 * k, dl, (size_t)n * k * 8, hipMemcpyDeviceToHost, st));
-            LDOT_HIP_CHECK(hipStreamSynchronize(st));
-        }
-    }
-    return LDOT_OK;
+    // augmented queries [q, 0, 1] (fp32) and the coarse result (probe labels) live in workspaces of the ROW index
+    const int da = ix->d + 2;
+    if ((rc = ix->w_laug.ensure((size_t)nq * da * 4))) return rc;
+    if ((rc = ix->w_lprobe_s.ensure((size_t)nq * nprobe * 4))) return rc;
+    if ((rc = ix->w_lprobe_l.ensure((size_t)nq * nprobe * 8))) return rc;
+    if ((rc = launch_augment_queries(queries, dtype, ix->d, nq, normalize, (float*)ix->w_laug.p, st))) return rc;
+    if ((rc = ldot_index_search(coarse, ix->w_laug.p, nq, LDOT_F32, LDOT_DEVICE, 0, nprobe, (float*)ix->w_lprobe_s.p,
+                                (int64_t*)ix->w_lprobe_l.p, LDOT_DEVICE, stream)))
+        return rc;
+    return lists_search_impl(ix, queries, nq, dtype, normalize, list_offsets, (int)nlist, max_list_len, ix->w_lprobe_l.p, true, nprobe, k,
+                             out_scores, out_labels, out_mem, st);
 }
 
 int ldot_index_last_profile(const ldot_index_t* ix, double out[4]) {

@@ -105,6 +105,59 @@ int launch_row_norm_max(const float* x32, int64_t ld, int64_t n, int d, float* o
     return LDOT_OK;
 }
 
+// coarse query of the inverted-file search: [q (optionally L2-normalised like the row search does), 0, 1] in fp32 — the inner product
+// with a centroid row [c~, -|c~|^2 / 2] (c~ = [c, sqrt(phi - |c|^2)], dvl/indexer/faiss_indexers.py:123-131) orders the lists by L2
+// distance in the augmented space.  One wave per query.
+template <int DT>
+__global__ __launch_bounds__(256) void augment_queries_kernel(const void* __restrict__ src, int d, int64_t n, int normalize,
+                                                              float* __restrict__ dst) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float scale = 1.f;
+    if (normalize) {
+        double ss = 0.0;
+        for (int c = lane; c < d; c += 64) {
+            const double v = (double)load_elem<DT>(src, row * d + c);
+            ss += v * v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        const double nrm = sqrt(ss);
+        scale = (float)(1.0 / (nrm > 1e-12 ? nrm : 1e-12));
+    }
+    float* out = dst + row * (d + 2);
+    for (int c = lane; c < d; c += 64) {
+        const float v = load_elem<DT>(src, row * d + c);
+        out[c] = normalize ? v * scale : v;
+    }
+    if (lane == 0) {
+        out[d] = 0.f;
+        out[d + 1] = 1.f;
+    }
+}
+
+int launch_augment_queries(const void* src, int dtype, int d, int64_t n, int normalize, float* dst, hipStream_t st) {
+    if (n <= 0) return LDOT_OK;
+    const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+    switch (dtype) {
+        case LDOT_F32:
+            hipLaunchKernelGGL(augment_queries_kernel<LDOT_F32>, grid, block, 0, st, src, d, n, normalize, dst);
+            break;
+        case LDOT_BF16:
+            hipLaunchKernelGGL(augment_queries_kernel<LDOT_BF16>, grid, block, 0, st, src, d, n, normalize, dst);
+            break;
+        case LDOT_F16:
+            hipLaunchKernelGGL(augment_queries_kernel<LDOT_F16>, grid, block, 0, st, src, d, n, normalize, dst);
+            break;
+        default:
+            set_error("unsupported dtype %d", dtype);
+            return LDOT_EINVAL;
+    }
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
 int launch_convert_rows(const void* src, int dtype, int64_t ld_src, int64_t n, int64_t n_pad, int d, int dpad,
                         int normalize, float* dst32, uint16_t* dst16, int split, uint16_t* dst16b, int64_t row0b,
                         hipStream_t st) {

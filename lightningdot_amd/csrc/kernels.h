@@ -49,10 +49,26 @@ int launch_score_narrow(const void* q16b, const void* x16b, int64_t ld_elems, in
 // sorted lists.  cnt [nq * kNarrowCntStride] must be zero before the first collect of a search (the final kernel leaves it zero); over[q] = 1 marks a
 // query whose candidate buffer was full (its list is unusable).
 int launch_narrow_tau(const uint32_t* M, int64_t ldm, int nruns, int nq, int kp, uint32_t* tau_key, hipStream_t st);
+// nrows_q (optional): per-query row counts nrows_q[q * nrows_q_stride] instead of nrows
 int launch_narrow_collect(const float* S, int64_t lds_elems, uint32_t* M, int64_t ldm, int nruns, int run_rows, int64_t nrows,
-                          int64_t row0, int nq, const uint32_t* tau_key, uint64_t* cand, int cap, int32_t* cnt, hipStream_t st);
+                          int64_t row0, int nq, const uint32_t* tau_key, uint64_t* cand, int cap, int32_t* cnt, const int32_t* nrows_q,
+                          int64_t nrows_q_stride, hipStream_t st);
 int launch_narrow_final(const uint64_t* cand, int cap, int32_t* cnt, int nq, float* list_s, int32_t* list_i, int kp, float* tau,
                         int32_t* over, hipStream_t st);
+
+// dst [n][d + 2] fp32 = [q (L2-normalised if asked), 0, 1]: the coarse query of the inverted-file search (convert.hip)
+int launch_augment_queries(const void* src, int dtype, int d, int64_t n, int normalize, float* dst, hipStream_t st);
+// inverted-file scan (ivf.hip): per-query compact column space over the probed lists
+// plist [nq][nprobe] validated list ids, rowbase [nq][nprobe] first row of each list, cstart [nq][nprobe + 1] exclusive prefix sums of
+// the list lengths (last = column count)
+int launch_ivf_prefix(const void* probes, int probes_are_int64, int64_t nq, int nprobe, int nlist, const int64_t* list_offsets,
+                      int32_t* plist, int64_t* rowbase, int32_t* cstart, hipStream_t st);
+// S[q][col] exact fp32 scores, M[q][col / (16 << run_shift)] run maxima (ascending keys, atomicMax into zeros)
+int launch_ivf_scan(const float* q32, int64_t ldq, const float* x32, int64_t ldx, int dpad, int64_t nq, const int64_t* rowbase,
+                    const int32_t* cstart, int nprobe, int64_t max_cols, int run_shift, float* S, int64_t lds_elems, uint32_t* M,
+                    int64_t ldm, hipStream_t st);
+int launch_ivf_final(const uint64_t* cand, int cap, int32_t* cnt, int64_t nq, const int64_t* rowbase, const int32_t* cstart,
+                     int nprobe, int k, float* out_s, int64_t* out_l, int32_t* over, hipStream_t st);
 
 // lists: [nq][kp] fp32 scores + int32 rows, kept sorted (score desc, row asc); empty slots have row -1.
 // also initialises the admission thresholds when tau != nullptr: -inf for queries < nq, +inf for the pad queries

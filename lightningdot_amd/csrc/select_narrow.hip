@@ -67,9 +67,11 @@ __global__ __launch_bounds__(THREADS) void narrow_tau_kernel(const uint32_t* __r
 __global__ __launch_bounds__(256) void narrow_collect_kernel(const float* __restrict__ S, int64_t lds_elems, uint32_t* __restrict__ M,
                                                              int64_t ldm, int nruns, int run_rows, int64_t nrows, int64_t row0,
                                                              const uint32_t* __restrict__ tau_key, uint64_t* __restrict__ cand,
-                                                             int cap, int32_t* __restrict__ cnt) {
+                                                             int cap, int32_t* __restrict__ cnt,
+                                                             const int32_t* __restrict__ nrows_q, int64_t nrows_q_stride) {
     const int q = blockIdx.y, lane = threadIdx.x & 63;
     const uint32_t tk = tau_key[q];
+    if (nrows_q) nrows = nrows_q[q * nrows_q_stride];   // (per-query column counts: the inverted-file scan)
     const float* s_row = S + (int64_t)q * lds_elems;
     uint64_t* c_row = cand + (int64_t)q * cap;
     for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < nruns; r += gridDim.x * 4) {
@@ -132,6 +134,8 @@ int launch_narrow_tau(const uint32_t* M, int64_t ldm, int nruns, int nq, int kp,
     LDOT_REQUIRE(nruns >= 1 && nruns <= kNarrowMaxRuns && nq >= 1, LDOT_EINVAL, "bad run count");
     if (nruns <= 2048)
         hipLaunchKernelGGL((narrow_tau_kernel<256, 8>), dim3(nq), dim3(256), 0, st, M, ldm, nruns, kp, tau_key);
+    else if (nruns <= 4096)
+        hipLaunchKernelGGL((narrow_tau_kernel<512, 8>), dim3(nq), dim3(512), 0, st, M, ldm, nruns, kp, tau_key);
     else
         hipLaunchKernelGGL((narrow_tau_kernel<1024, kNarrowMaxRuns / 1024>), dim3(nq), dim3(1024), 0, st, M, ldm, nruns, kp, tau_key);
     LDOT_HIP_CHECK(hipGetLastError());
@@ -139,11 +143,12 @@ int launch_narrow_tau(const uint32_t* M, int64_t ldm, int nruns, int nq, int kp,
 }
 
 int launch_narrow_collect(const float* S, int64_t lds_elems, uint32_t* M, int64_t ldm, int nruns, int run_rows, int64_t nrows,
-                          int64_t row0, int nq, const uint32_t* tau_key, uint64_t* cand, int cap, int32_t* cnt, hipStream_t st) {
+                          int64_t row0, int nq, const uint32_t* tau_key, uint64_t* cand, int cap, int32_t* cnt, const int32_t* nrows_q,
+                          int64_t nrows_q_stride, hipStream_t st) {
     // (thousands of workgroups that exit at once cost more in dispatch than they do in work: 16 queries x 489 took 27 us)
     const int want = (nruns + 3) / 4, lim = 1024 / nq > 16 ? 1024 / nq : 16;
     hipLaunchKernelGGL(narrow_collect_kernel, dim3(want < lim ? want : lim, nq), dim3(256), 0, st, S, lds_elems, M, ldm, nruns, run_rows,
-                       nrows, row0, tau_key, cand, cap, cnt);
+                       nrows, row0, tau_key, cand, cap, cnt, nrows_q, nrows_q_stride);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

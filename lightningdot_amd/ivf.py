@@ -126,9 +126,22 @@ class DenseIVFFlatIndexer(DenseIndexer):
             q = q[None]
         nq = q.shape[0]
         nprobe = min(int(nprobe or self.nprobe), self.nlist)
-        qa = torch.cat([q, torch.zeros(nq, 1, device=q.device), torch.ones(nq, 1, device=q.device)], 1)   # [q, 0 | 1]
-        _, probes = self.coarse.search_tensors(qa, nprobe)
-        probes = probes.to(torch.int32).contiguous()
+        scores = torch.empty((nq, top_docs), dtype=torch.float32, device=q.device)
+        labels = torch.empty((nq, top_docs), dtype=torch.int64, device=q.device)
+        ix = self.index
+        # one library call: coarse query [q, 0 | 1] -> nprobe nearest lists -> exact scan of their rows -> top-k
+        L.check(ix._lib.ldot_ivf_search(ix._h, self.coarse._h, ctypes.c_void_p(q.data_ptr()), nq, L.F32, 0,
+                                        ctypes.c_void_p(self.list_offsets.data_ptr()), int(self.max_list_len), nprobe, int(top_docs),
+                                        ctypes.c_void_p(scores.data_ptr()), ctypes.c_void_p(labels.data_ptr()), L.DEVICE,
+                                        _stream_ptr(ix.device)))
+        return scores, labels
+
+    def search_lists_tensors(self, query_vectors, probes, top_docs: int):
+        """the scan step alone: probes [nq, nprobe] int32 list ids chosen by the caller (-1 = skip)"""
+        import torch
+        q = query_vectors.detach().float().cuda().contiguous()
+        probes = probes.to(device=q.device, dtype=torch.int32).contiguous()
+        nq, nprobe = probes.shape
         scores = torch.empty((nq, top_docs), dtype=torch.float32, device=q.device)
         labels = torch.empty((nq, top_docs), dtype=torch.int64, device=q.device)
         ix = self.index

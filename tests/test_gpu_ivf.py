@@ -116,3 +116,79 @@ def test_search_lists_entry_point_vs_brute_force():
         assert set(l[i, :nv]) == set(rows[order]) or np.abs(np.sort(sc[order]) - np.sort(s[i, :nv].astype(np.float64))).max() < 2e-4
         assert l[i, 0] == rows[order[0]]
         assert (l[i, nv:] == -1).all()
+
+
+def test_one_call_ivf_search_equals_coarse_search_plus_list_scan():
+    """ldot_ivf_search = ordinary search over the augmented centroids ([q, 0, 1]) + ldot_index_search_lists with those probes"""
+    import torch
+    from lightningdot_amd.ivf import DenseIVFFlatIndexer
+    x, rng = _clustered(30000, 64, 120, 7)
+    ivf = DenseIVFFlatIndexer(64, nlist=150, nprobe=9)
+    ivf.index_tensor(list(range(30000)), torch.from_numpy(x))
+    for nq in (1, 16, 300):                                   # narrow coarse search, its widest batch, more than one 256-query chunk
+        q = torch.from_numpy((x[rng.integers(0, 30000, nq)] + 0.2 * rng.standard_normal((nq, 64))).astype(np.float32)).cuda()
+        s1, l1 = ivf.search_knn_tensors(q, 20)
+        qa = torch.cat([q, torch.zeros(nq, 1, device='cuda'), torch.ones(nq, 1, device='cuda')], 1)
+        _, probes = ivf.coarse.search_tensors(qa, 9)
+        s2, l2 = ivf.search_lists_tensors(q, probes, 20)
+        assert torch.equal(l1, l2) and torch.equal(s1, s2)
+        # against a brute-force scan of the probed rows
+        offs = ivf.list_offsets.cpu().numpy()
+        xs = ivf.index.get_rows(0, 30000) if hasattr(ivf.index, 'get_rows') else None
+        if xs is not None:
+            xs = np.asarray(xs)
+            for i in range(min(nq, 5)):
+                rows = np.concatenate([np.arange(offs[p], offs[p + 1]) for p in probes[i].cpu().numpy()])
+                sc = xs[rows].astype(np.float64) @ q[i].cpu().numpy().astype(np.float64)
+                order = np.lexsort((rows, -sc))[:20]
+                np.testing.assert_allclose(s1[i].cpu().numpy(), sc[order], rtol=0, atol=2e-4)
+                assert int(l1[i, 0]) == rows[order[0]]
+
+
+def test_list_scan_large_k_and_full_candidate_buffer_take_the_padded_path():
+    """k' * run > candidate capacity (k = 600) never enters the run-maxima selection; 9000 identical rows in the probed lists fill the
+    candidate buffer, which is noticed (stats) and redone — both against numpy"""
+    import torch
+    from lightningdot_amd import _lib as L
+    from lightningdot_amd.indexer import FlatIPIndex
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((12000, 32)).astype(np.float32)
+    x[1000:10000] = x[1000]                                   # 9000 equal rows inside list 1
+    offs = np.array([0, 500, 10500, 12000], dtype=np.int64)
+    q = np.stack([x[1000] * 2.0, rng.standard_normal(32).astype(np.float32)])
+    probes = np.array([[1, 0], [2, 1]], dtype=np.int32)
+    ix = FlatIPIndex(32)
+    ix.add(x)
+    qd, od, pd = torch.from_numpy(q).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(probes).cuda()
+    for k, expect_over in ((50, 1), (600, 0)):
+        s = torch.empty((2, k), dtype=torch.float32, device='cuda')
+        l = torch.empty((2, k), dtype=torch.int64, device='cuda')
+        L.check(ix._lib.ldot_index_search_lists(ix._h, ctypes.c_void_p(qd.data_ptr()), 2, L.F32, 0, ctypes.c_void_p(od.data_ptr()), 3,
+                                                10000, ctypes.c_void_p(pd.data_ptr()), 2, k, ctypes.c_void_p(s.data_ptr()),
+                                                ctypes.c_void_p(l.data_ptr()), L.DEVICE,
+                                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        assert ix.last_stats()['overflowed_queries'] == expect_over
+        s, l = s.cpu().numpy(), l.cpu().numpy()
+        for i in range(2):
+            rows = np.concatenate([np.arange(offs[p], offs[p + 1]) for p in probes[i]])
+            sc = x[rows].astype(np.float64) @ q[i].astype(np.float64)
+            best = np.sort(sc)[::-1][:k]
+            np.testing.assert_allclose(s[i], best, rtol=0, atol=2e-4)
+            np.testing.assert_allclose(x[l[i]].astype(np.float64) @ q[i].astype(np.float64), s[i], rtol=0, atol=2e-4)
+            assert len(set(l[i].tolist())) == k and set(l[i].tolist()) <= set(rows.tolist())
+
+
+def test_ivf_search_rejects_a_mismatched_coarse_index():
+    import torch
+    from lightningdot_amd import _lib as L
+    from lightningdot_amd.indexer import FlatIPIndex
+    ix, bad = FlatIPIndex(16), FlatIPIndex(16)
+    ix.add(np.eye(16, dtype=np.float32))
+    bad.add(np.eye(16, dtype=np.float32))
+    q = torch.zeros(1, 16, device='cuda')
+    offs = torch.tensor([0, 16], dtype=torch.int64, device='cuda')
+    s = torch.empty((1, 4), dtype=torch.float32, device='cuda')
+    l = torch.empty((1, 4), dtype=torch.int64, device='cuda')
+    rc = ix._lib.ldot_ivf_search(ix._h, bad._h, ctypes.c_void_p(q.data_ptr()), 1, L.F32, 0, ctypes.c_void_p(offs.data_ptr()), 16, 1, 4,
+                                 ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(l.data_ptr()), L.DEVICE, None)
+    assert rc != 0 and b'coarse' in ix._lib.ldot_last_error()
