@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round evidence in ONE gpurun call: GPU tests, smoke, headline bench (+ CPU baselines), S2-shape benches, serving latency, MFMA ceiling
 # microbenchmark, rocprofv3 kernel stats of the bench command, PMC passes (separate --pmc runs, --kernel-trace only), per-pass timeline,
-# 2-rank dry run on one GPU, vendor GEMM reference.
+# 2-rank dry run on one GPU, vendor GEMM reference, single-query kernel timelines (exact and inverted-file search).
 # usage (GPU box): tools/evidence.sh <tag>   -> gpurun_out/ev_<tag>/
 T=${1:-ev}; O=$GRAFT_REPO_ROOT/gpurun_out/ev_$T; mkdir -p $O
 cd $GRAFT_REPO_ROOT
@@ -24,4 +24,8 @@ for g in "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIV
   bash tools/pmc2.sh "$g" >> $O/pmc.txt 2>&1
 done
 bash tools/timeline.sh > /dev/null 2>&1; cp gpurun_out/timeline.txt $O/timeline.txt 2>/dev/null
+bash tools/serving_timeline.sh 1000000 > $O/serving_timeline_1m.txt 2>&1
+bash tools/serving_timeline.sh 123287 > $O/serving_timeline_123287.txt 2>&1
+timeout 600 python tools/ivf_bench.py > $O/ivf_bench.jsonl 2>> $O/bench.err
+bash tools/timeline_tail.sh 8 python tools/ivf_one.py > $O/ivf_timeline.txt 2>&1
 tail -3 $O/pytest_gpu.log; cat $O/smoke.log | tail -1; cut -c1-600 $O/bench.json; cat $O/pmc.txt
