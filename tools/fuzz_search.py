@@ -15,8 +15,9 @@ from util import assert_topk_matches
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed)
-N_CHOICES = [1, 5, 255, 256, 257, 1000, 4095, 4097, 12288, 16384, 20000, 32767, 32768, 33000, 50000, 98304, 110593, 200000]
-Q_CHOICES = [1, 2, 63, 64, 65, 255, 256, 257, 511, 1024, 1500, 2049, 4096, 16385, 20000]   # > 16384: the fused scan's query chunks
+N_CHOICES = [1, 5, 255, 256, 257, 1000, 4095, 4097, 8192, 8193, 12288, 16384, 20000, 32767, 32768, 33000, 50000, 98304, 110593, 200000,
+             300000, 1100000]   # 8192 / 8193: the narrow search's candidate-buffer size; > 262144 rows: coarser run maxima
+Q_CHOICES = [1, 1, 2, 3, 16, 17, 63, 64, 65, 255, 256, 257, 511, 1024, 1500, 2049, 4096, 16385, 20000]   # > 16384: the fused scan's query chunks
 D_CHOICES = [8, 32, 63, 64, 100, 128, 768, 1024]
 K_CHOICES = [1, 5, 10, 50, 100, 128, 500, 1000, 2048]
 fails = 0
@@ -26,6 +27,7 @@ for it in range(cases):
     if n * nq * d > 3e11 or nq * n > 4e8:   # keep the fp64 reference affordable
         nq = max(1, int(4e8 // n)) if nq * n > 4e8 else nq
         if n * nq * d > 3e11: d = 64
+    if n * d > 2e8: d = 64 if n > 500000 else 128            # host memory / generation time
     mode = int(rng.choice([L.MODE_AUTO, L.MODE_AUTO, L.MODE_FUSED, L.MODE_DENSE]))
     normalize = bool(rng.integers(0, 4) == 0)
     clustered = bool(rng.integers(0, 3) == 0)
@@ -33,6 +35,8 @@ for it in range(cases):
     if clustered:   # rows around few centres: many close scores
         c = rng.standard_normal((max(1, n // 50), d)).astype(np.float32)
         x = (c[rng.integers(0, c.shape[0], n)] + 0.3 * x).astype(np.float32)
+        if rng.integers(0, 2) == 0:   # ... stored in cluster order (run-correlated scores: the narrow search's hard case)
+            x = x[np.argsort(x @ c[0], kind='stable')]
     q = (x[rng.integers(0, n, nq)] + 0.5 * rng.standard_normal((nq, d))).astype(np.float32)
     desc = f'n={n} nq={nq} d={d} k={k} mode={mode} norm={normalize} clustered={clustered}'
     try:
