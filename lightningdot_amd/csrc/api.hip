@@ -108,6 +108,9 @@ struct ldot_index {
     bool narrow_clean = false;
     int32_t *h_nover = nullptr, *d_nover = nullptr;   // per-query "candidate buffer full" flags (pinned, device-mapped)
     int64_t overflow_narrow = 0;                      // > 0: the pending overflow summary is h_nover[0 .. overflow_narrow)
+    // rows stored in cluster order can fill the candidate buffer on EVERY search of an index: after an overflow the narrow search is
+    // skipped for `narrow_backoff` searches, twice as many after every further overflow (reset by a search that fits)
+    int narrow_backoff = 0, narrow_penalty = 16;
     // a search in two halves (ldot_index_search_begin / _finish): what _finish needs to know
     int64_t pend_nq = 0;
     int pend_k = 0, pend_kp = 0;
@@ -693,6 +696,12 @@ static bool fused_overflow_check(ldot_index* ix) {
         for (int64_t q = 0; q < ix->overflow_narrow; ++q) n += ix->h_nover[q];
         ix->overflow_narrow = 0;
         ix->stats[1] = n;
+        if (n > 0) {
+            ix->narrow_backoff = ix->narrow_penalty;
+            ix->narrow_penalty = std::min(2 * ix->narrow_penalty, 1024);
+        } else {
+            ix->narrow_penalty = 16;
+        }
         return n > 0;
     }
     const int64_t n_over = ix->h_over_sum[0];
@@ -747,7 +756,11 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
         return rc;
     float* tau = (float*)ix->w_tau.p;
     // (the narrow search writes complete lists and thresholds itself)
-    const bool narrow = ix->ntotal > 0 && ix->mode == LDOT_MODE_AUTO && narrow_select_ok(ix, nq, kp);
+    bool narrow = ix->ntotal > 0 && ix->mode == LDOT_MODE_AUTO && narrow_select_ok(ix, nq, kp);
+    if (narrow && ix->narrow_backoff > 0) {   // (this index recently filled the candidate buffer: streaming selector for a while)
+        --ix->narrow_backoff;
+        narrow = false;
+    }
     if (!narrow && (rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, tau, nq, nq_pad, st))) return rc;
 
     if (narrow) {

@@ -40,7 +40,7 @@ int launch_score_dense(const void* q16, int64_t ldq_elems, int64_t nq_pad, const
 // <= 16 queries (serving): wave-per-16-row-group scan straight from global memory (score_narrow.hip)
 constexpr int kNarrowMaxQueries = 16, kNarrowMaxSlabs = 64;
 constexpr int kNarrowMaxRuns = 16384;   // run maxima per query and launch (select_narrow.hip keeps them in one workgroup's registers)
-constexpr int kNarrowCandCap = 8192;    // candidate keys per query (64 KiB of LDS in the final sort)
+constexpr int kNarrowCandCap = 16384;   // candidate keys per query (128 KiB of LDS in the final sort, sized by the actual count)
 constexpr int kNarrowCntStride = 64;    // ints between the candidate counters of two queries (atomics on one cache line serialise)
 // M (optional, zero on entry) [nq][ldm]: ascending keys (~desc_key) of the per-run maxima over the valid rows, run = 16 << run_shift rows
 int launch_score_narrow(const void* q16b, const void* x16b, int64_t ld_elems, int64_t xrow0, int64_t nrows, float* S,

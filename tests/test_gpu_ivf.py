@@ -146,25 +146,25 @@ def test_one_call_ivf_search_equals_coarse_search_plus_list_scan():
 
 
 def test_list_scan_large_k_and_full_candidate_buffer_take_the_padded_path():
-    """k' * run > candidate capacity (k = 600) never enters the run-maxima selection; 9000 identical rows in the probed lists fill the
+    """k' * run > candidate capacity (k = 1200) never enters the run-maxima selection; 20000 identical rows in the probed lists fill the
     candidate buffer, which is noticed (stats) and redone — both against numpy"""
     import torch
     from lightningdot_amd import _lib as L
     from lightningdot_amd.indexer import FlatIPIndex
     rng = np.random.default_rng(9)
-    x = rng.standard_normal((12000, 32)).astype(np.float32)
-    x[1000:10000] = x[1000]                                   # 9000 equal rows inside list 1
-    offs = np.array([0, 500, 10500, 12000], dtype=np.int64)
+    x = rng.standard_normal((24000, 32)).astype(np.float32)
+    x[1000:21000] = x[1000]                                   # 20000 equal rows inside list 1
+    offs = np.array([0, 500, 22500, 24000], dtype=np.int64)
     q = np.stack([x[1000] * 2.0, rng.standard_normal(32).astype(np.float32)])
     probes = np.array([[1, 0], [2, 1]], dtype=np.int32)
     ix = FlatIPIndex(32)
     ix.add(x)
     qd, od, pd = torch.from_numpy(q).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(probes).cuda()
-    for k, expect_over in ((50, 1), (600, 0)):
+    for k, expect_over in ((50, 1), (1200, 0)):
         s = torch.empty((2, k), dtype=torch.float32, device='cuda')
         l = torch.empty((2, k), dtype=torch.int64, device='cuda')
         L.check(ix._lib.ldot_index_search_lists(ix._h, ctypes.c_void_p(qd.data_ptr()), 2, L.F32, 0, ctypes.c_void_p(od.data_ptr()), 3,
-                                                10000, ctypes.c_void_p(pd.data_ptr()), 2, k, ctypes.c_void_p(s.data_ptr()),
+                                                22000, ctypes.c_void_p(pd.data_ptr()), 2, k, ctypes.c_void_p(s.data_ptr()),
                                                 ctypes.c_void_p(l.data_ptr()), L.DEVICE,
                                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
         assert ix.last_stats()['overflowed_queries'] == expect_over

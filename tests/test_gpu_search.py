@@ -320,7 +320,7 @@ def test_narrow_scan_up_to_16_queries(L, nq, n, d, k):
 
 
 def test_narrow_search_full_candidate_buffer_falls_back(L):
-    """Rows stored as runs of 64 identical copies: a run maximum stands for 64 equal scores, the candidate buffer (8192 keys) of the
+    """Rows stored as runs of 64 identical copies: a run maximum stands for 64 equal scores, the candidate buffer (16384 keys) of the
     narrow search fills up, the overflow is reported (stats) and the search is redone with the streaming selector — exact."""
     rng = np.random.default_rng(11)
     base = rng.standard_normal((5_000, 64)).astype(np.float32)
@@ -332,6 +332,11 @@ def test_narrow_search_full_candidate_buffer_falls_back(L):
     assert st['overflowed_queries'] == 2
     assert_topk_matches(q, x, s, l, 200)
     assert (l[0, :64] == np.arange(7 * 64, 8 * 64)).all()          # ties: ascending row order
+    # the index backs off from the narrow search for a while (streaming selector: no overflow to report), results unchanged
+    s1, l1 = ix.search(q, 200)
+    assert ix.last_stats()['overflowed_queries'] == 0
+    np.testing.assert_array_equal(l, l1)
+    np.testing.assert_array_equal(s, s1)
     # an ordinary search afterwards is clean again (counters were left zero)
     x2 = rng.standard_normal((50_000, 64)).astype(np.float32)
     ix2 = _index(x2)
