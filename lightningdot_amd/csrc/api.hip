@@ -102,7 +102,7 @@ struct ldot_index {
     DevBuf w_unproven;
     int64_t unproven_n = 0;
     DevBuf w_norm;                   // device scalar: largest L2 norm of an indexed row
-    // narrow search (<= 16 queries): run maxima, threshold keys, candidate keys + counters (zero between searches)
+    // narrow search (<= 64 queries): run maxima, threshold keys, candidate keys + counters (zero between searches)
     DevBuf w_nmax, w_ntau, w_ncand, w_ncnt;
     DevBuf w_lplist, w_lrowbase, w_lcstart, w_laug, w_lprobe_s, w_lprobe_l;   // list search: validated probes, prefix sums, coarse query / result
     bool narrow_clean = false;
@@ -451,7 +451,8 @@ static int dense_scan(ldot_index* ix, int64_t q0, int64_t nqb, int64_t nqb_pad, 
 }
 
 static bool narrow_ok(const ldot_index* ix, int64_t nq) {
-    return nq <= kNarrowMaxQueries && ix->ld16() / 32 <= kNarrowMaxSlabs;
+    const int64_t qg = nq <= 16 ? 1 : nq <= 32 ? 2 : 4;   // groups of 16 queries whose operand blocks sit in LDS
+    return nq <= kNarrowMaxQueries && ix->ld16() / 32 * qg <= kNarrowMaxLdsKiB;
 }
 
 // Few queries (one query tile) x many rows — the single-query serving shape (dvl/utils.py:204-211): one wide score
@@ -472,7 +473,7 @@ static int dense_scan_wide(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, i
         if ((rc = ix->w_part_l.ensure((size_t)nseg * nq * kp * 8))) return rc;
         prof_begin(ix, st, 2.0 * nq * nrows * ix->d,
                    (double)nrows * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * nrows * 4);
-        if (narrow_ok(ix, nq))   // <= 16 queries: HBM-speed wave-per-group scan, no query-tile padding
+        if (narrow_ok(ix, nq))   // <= 64 queries: HBM-speed wave-per-group scan, no query-tile padding
             rc = launch_score_narrow(ix->w_q16b.p, ix->x16b, ix->ld16(), r, nrows, (float*)ix->w_S.p, nrows_pad, (int)nq, nullptr, 0,
                                      0, st);
         else
@@ -491,7 +492,7 @@ static int dense_scan_wide(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, i
     return LDOT_OK;
 }
 
-// <= 16 queries against any number of rows (the serving shape): the index is streamed once at HBM speed (score_narrow.hip) and the
+// <= 64 queries against any number of rows (the serving shape): the index is streamed once at HBM speed (score_narrow.hip) and the
 // lists are selected from the run maxima the scan leaves behind (select_narrow.hip) — convert + 4 kernels + re-score, no threshold
 // to learn.  Speculative like the fused scan: a query whose candidate buffer filled up (rows stored in cluster order) is counted in
 // w_over_sum and the caller redoes the search with the streaming selector.
@@ -772,10 +773,11 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
     } else if (ix->ntotal > 0) {
         // AUTO: the fused scan pays off from ~32k rows (tools/auto_threshold.py); very large batches (COCO-5k sized image->text
         // with the reference's un-deduplicated queries) already from 16k rows, where the dense score matrix is the cost
-        // <= 16 queries: one pass over the index at HBM speed (score_narrow.hip) + segmented select beats the fused scan's
-        // warm-up / filter / pool-select chain at every index size (tools/serving_latency.py)
+        // <= 16 queries whose narrow search is not available (large k', or the index recently filled its candidate buffer): one pass
+        // over the index at HBM speed (score_narrow.hip) + segmented streaming select still beats the fused scan's warm-up / filter /
+        // pool-select chain at every index size (tools/serving_latency.py)
         const bool fused = ix->mode == LDOT_MODE_FUSED ||
-                           (ix->mode == LDOT_MODE_AUTO && !narrow_ok(ix, nq) &&
+                           (ix->mode == LDOT_MODE_AUTO && !(nq <= 16 && narrow_ok(ix, nq)) &&
                             (ix->ntotal >= 32768 || (ix->ntotal >= 16384 && nq >= 16384)));
         if (fused) {
             if ((rc = fused_scan(ix, nq, nq_pad, kp, st))) return rc;

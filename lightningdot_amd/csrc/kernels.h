@@ -37,8 +37,9 @@ int launch_score_dense(const void* q16, int64_t ldq_elems, int64_t nq_pad, const
                        int64_t xrow0, int64_t nrows_pad, int dpad, float* S, int64_t lds_elems, int64_t nq_valid,
                        hipStream_t st);
 
-// <= 16 queries (serving): wave-per-16-row-group scan straight from global memory (score_narrow.hip)
-constexpr int kNarrowMaxQueries = 16, kNarrowMaxSlabs = 64;
+// <= 64 queries (serving): wave-per-16-row-group scan straight from global memory (score_narrow.hip)
+constexpr int kNarrowMaxQueries = 64;    // 1, 2 or 4 groups of 16 queries per scan
+constexpr int kNarrowMaxLdsKiB = 128;    // query operand in LDS: slabs x query groups KiB
 constexpr int kNarrowMaxRuns = 16384;   // run maxima per query and launch (select_narrow.hip keeps them in one workgroup's registers)
 constexpr int kNarrowCandCap = 16384;   // candidate keys per query (128 KiB of LDS in the final sort, sized by the actual count)
 constexpr int kNarrowCntStride = 64;    // ints between the candidate counters of two queries (atomics on one cache line serialise)

@@ -1,8 +1,8 @@
-// Narrow score scan:  S[q][n] = Q16[q,:] . X16[row0 + n,:]  for at most 16 queries — the single-query serving shape
+// Narrow score scan:  S[q][n] = Q16[q,:] . X16[row0 + n,:]  for at most 64 queries — the single-query serving shape
 // (dvl/utils.py:204-211 retrieve_query: one text query against the whole image index; faiss IndexFlatIP.search with nq = 1,
 // dvl/indexer/faiss_indexers.py:83).
 //
-// With <= 16 queries the search is one pass over the index at HBM speed: 2 flop per byte streamed, the matrix pipe is ~5 % busy.
+// With a handful of queries the search is one pass over the index at HBM speed: 2 flop per byte streamed, the matrix pipe is ~5 % busy.
 // The ring engine of score_dense / score_filter (384 x 256 tiles through LDS) is the wrong tool — a 256-query tile is 94 % padding
 // and its workgroup count is bounded by the row tiles.  Here every WAVE owns 16-row groups of the blocked bf16 shadow: a group's
 // nslab 1-KiB blocks are CONTIGUOUS in memory, a block is exactly one MFMA 16x16x32 A operand in register order (lane l: row l & 15,
@@ -21,25 +21,28 @@
 
 namespace ldot {
 
-template <int UNR>
-__global__ __launch_bounds__(256) void score_narrow_kernel(const char* __restrict__ Q16b, const char* __restrict__ X16b,
-                                                           int nslab, int64_t g0, int64_t ngroups, int per, int64_t nrows,
-                                                           float* __restrict__ S, int64_t lds_elems, int nq,
-                                                           uint32_t* __restrict__ M, int64_t ldm, int run_shift) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // nslab KiB: query block 0 of the blocked query shadow
+// UNR blocks in flight per wave, QG groups of 16 queries (1, 2 or 4), THREADS per workgroup
+template <int UNR, int QG, int THREADS>
+__global__ __launch_bounds__(THREADS) void score_narrow_kernel(const char* __restrict__ Q16b, const char* __restrict__ X16b,
+                                                               int nslab, int64_t g0, int64_t ngroups, int per, int64_t nrows,
+                                                               float* __restrict__ S, int64_t lds_elems, int nq,
+                                                               uint32_t* __restrict__ M, int64_t ldm, int run_shift) {
+    // QG * nslab KiB: query blocks 0 .. QG-1 of the blocked query shadow (block (g, s) at (g * nslab + s) KiB, like the source)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
-    for (int i = tid; i < nslab * 64; i += 256) ((uint4*)smem)[i] = ((const uint4*)Q16b)[i];
+    for (int i = tid; i < QG * nslab * 64; i += THREADS) ((uint4*)smem)[i] = ((const uint4*)Q16b)[i];
     __syncthreads();
     const int lane = tid & 63;
     // a wave owns `per` CONSECUTIVE groups: one contiguous stream of per * nslab KiB, and a run maximum is raised once per run the
     // stream crosses instead of once per group
-    const int64_t gbeg = ((int64_t)blockIdx.x * 4 + (tid >> 6)) * per;
+    const int64_t gbeg = ((int64_t)blockIdx.x * (THREADS / 64) + (tid >> 6)) * per;
     const int64_t gend = gbeg + per < ngroups ? gbeg + per : ngroups;
     if (gbeg >= gend) return;
     const int lo = (lane & 15) * 64 + (lane >> 4) * 16;
     const int nc = nslab / UNR;                               // chunks of UNR blocks per group
     const char* xp = X16b + (g0 + gbeg) * (int64_t)nslab * 1024 + lo;   // current chunk
     const char* qb = smem + lo;
+    const int qstride = nslab * 1024;                         // LDS bytes between two query groups
     int64_t left = (gend - gbeg) * nc;                        // chunks left, the current one included
 
     bf16x8_t a[2][UNR];
@@ -50,8 +53,13 @@ __global__ __launch_bounds__(256) void score_narrow_kernel(const char* __restric
     load(a[0], xp);
     int64_t g = gbeg;
     int c = 0;
-    float m = -INFINITY;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float m[QG];
+    f32x4 acc[QG][2];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        m[qg] = -INFINITY;
+        acc[qg][0] = acc[qg][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     for (;;) {
         // (two chunks per trip so that the register double buffer is indexed statically)
 #pragma unroll
@@ -62,26 +70,34 @@ __global__ __launch_bounds__(256) void score_narrow_kernel(const char* __restric
             load(a[half ^ 1], xn);
             const char* qc = qb + c * UNR * 1024;
 #pragma unroll
-            for (int u = 0; u < UNR; u += 2) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[half][u], *(const bf16x8_t*)(qc + u * 1024), acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[half][u + 1], *(const bf16x8_t*)(qc + (u + 1) * 1024), acc1, 0, 0, 0);
+            for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+                for (int qg = 0; qg < QG; ++qg)
+                    acc[qg][u & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        a[half][u], *(const bf16x8_t*)(qc + qg * qstride + u * 1024), acc[qg][u & 1], 0, 0, 0);
             }
             if (++c == nc) {   // the group is complete
                 c = 0;
-                const f32x4 v = acc0 + acc1;
                 const int64_t col = g * 16 + (lane >> 4) * 4;
-                if ((lane & 15) < nq) *(f32x4*)(S + (int64_t)(lane & 15) * lds_elems + col) = v;
-                acc0 = acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (M != nullptr) {
-                    // (the zero rows that pad the last group are not index rows: they must not raise a run maximum)
-                    const int64_t valid = nrows - col;
-                    m = fmaxf(m, fmaxf(fmaxf(valid > 0 ? v[0] : -INFINITY, valid > 1 ? v[1] : -INFINITY),
-                                       fmaxf(valid > 2 ? v[2] : -INFINITY, valid > 3 ? v[3] : -INFINITY)));
-                    if (((g + 1) >> run_shift) != (g >> run_shift) || g + 1 == gend) {   // last group of a run, or of the stream
-                        m = fmaxf(m, __shfl_xor(m, 16));
-                        m = fmaxf(m, __shfl_xor(m, 32));
-                        if (lane < nq) atomicMax(M + (int64_t)lane * ldm + (g >> run_shift), ~desc_key(m));
-                        m = -INFINITY;
+                // (the zero rows that pad the last group are not index rows: they must not raise a run maximum)
+                const int64_t valid = nrows - col;
+                const bool flush = ((g + 1) >> run_shift) != (g >> run_shift) || g + 1 == gend;   // last group of a run / the stream
+#pragma unroll
+                for (int qg = 0; qg < QG; ++qg) {
+                    const f32x4 v = acc[qg][0] + acc[qg][1];
+                    acc[qg][0] = acc[qg][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const int q = qg * 16 + (lane & 15);
+                    if (q < nq) *(f32x4*)(S + (int64_t)q * lds_elems + col) = v;
+                    if (M != nullptr) {
+                        m[qg] = fmaxf(m[qg], fmaxf(fmaxf(valid > 0 ? v[0] : -INFINITY, valid > 1 ? v[1] : -INFINITY),
+                                                   fmaxf(valid > 2 ? v[2] : -INFINITY, valid > 3 ? v[3] : -INFINITY)));
+                        if (flush) {
+                            float t = fmaxf(m[qg], __shfl_xor(m[qg], 16));
+                            t = fmaxf(t, __shfl_xor(t, 32));
+                            if (lane < 16 && qg * 16 + lane < nq)
+                                atomicMax(M + (int64_t)(qg * 16 + lane) * ldm + (g >> run_shift), ~desc_key(t));
+                            m[qg] = -INFINITY;
+                        }
                     }
                 }
                 ++g;
@@ -92,47 +108,61 @@ __global__ __launch_bounds__(256) void score_narrow_kernel(const char* __restric
     }
 }
 
-static bool g_narrow_attr[3][64];   // hipFuncSetAttribute once per kernel variant and device (it costs microseconds per call)
+static bool g_narrow_attr[9][64];   // hipFuncSetAttribute once per kernel variant and device (it costs microseconds per call)
 
 // q16b / x16b: the BLOCKED shadows; xrow0 a multiple of 16; scores of rows [xrow0, xrow0 + 16 * ceil(nrows / 16)) are written to
-// S[q][row - xrow0] for q < nq <= 16 (the caller's row stride lds_elems covers the rounded-up count).
+// S[q][row - xrow0] for q < nq <= 64 (the caller's row stride lds_elems covers the rounded-up count).
 // M (optional, all zero on entry): M[q][r] = ascending key (~desc_key) of the max score of query q over the VALID rows of
 // run r = rows [r * (16 << run_shift), (r + 1) * (16 << run_shift)) of the launch.
 int launch_score_narrow(const void* q16b, const void* x16b, int64_t ld_elems, int64_t xrow0, int64_t nrows, float* S,
                         int64_t lds_elems, int nq, uint32_t* M, int64_t ldm, int run_shift, hipStream_t st) {
     if (nrows <= 0 || nq <= 0) return LDOT_OK;
     const int nslab = (int)(ld_elems / 32);
-    LDOT_REQUIRE(nq <= kNarrowMaxQueries && xrow0 % 16 == 0 && ld_elems % 64 == 0 && nslab <= kNarrowMaxSlabs && run_shift >= 0,
+    const int qg = nq <= 16 ? 1 : nq <= 32 ? 2 : 4;
+    LDOT_REQUIRE(nq <= kNarrowMaxQueries && xrow0 % 16 == 0 && ld_elems % 64 == 0 && nslab * qg <= kNarrowMaxLdsKiB && run_shift >= 0,
                  LDOT_EINVAL, "bad narrow scan shape");
     const int64_t ngroups = (nrows + 15) / 16;
     LDOT_REQUIRE(lds_elems >= ngroups * 16 && (M == nullptr || ldm > ((ngroups - 1) >> run_shift)), LDOT_EINVAL,
                  "score row stride too short");
-    // at most 5 workgroups (20 waves) per CU, every wave the same number of consecutive groups (the last one possibly fewer): with a
-    // fixed 5120 waves a 7706-group index would leave half of them a second group to do while the others idle
-    const int64_t max_waves = 256 * 5 * 4, per = (ngroups + max_waves - 1) / max_waves, waves = (ngroups + per - 1) / per;
-    const int grid = (int)((waves + 3) / 4);
+    // waves per CU by the query operand's LDS footprint: 20 (5 workgroups of 4 waves) for one query group, 12 for two, 8 (one
+    // 512-thread workgroup) for four; every wave the same number of consecutive groups (the last one possibly fewer): with a fixed wave
+    // count a 7706-group index would leave half of them a second group to do while the others idle
+    const int wg_waves = qg == 4 ? 8 : 4;
+    const int64_t max_waves = 256 * (qg == 1 ? 20 : qg == 2 ? 12 : 8);
+    const int64_t per = (ngroups + max_waves - 1) / max_waves, waves = (ngroups + per - 1) / per;
+    const int grid = (int)((waves + wg_waves - 1) / wg_waves);
     LDOT_REQUIRE(per < ((int64_t)1 << 30), LDOT_EINVAL, "too many rows for one narrow scan");
-    const size_t lds = (size_t)nslab * 1024;
+    const size_t lds = (size_t)nslab * qg * 1024;
     const char* q = (const char*)q16b;
     const char* x = (const char*)x16b;
     int dev = 0;
     LDOT_HIP_CHECK(hipGetDevice(&dev));
-#define LDOT_NARROW(U, SLOT)                                                                                               \
-    do {                                                                                                                   \
-        if (dev >= 64 || !g_narrow_attr[SLOT][dev]) {                                                                      \
-            LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)score_narrow_kernel<U>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                               kNarrowMaxSlabs * 1024));                                                   \
-            if (dev < 64) g_narrow_attr[SLOT][dev] = true;                                                                 \
-        }                                                                                                                  \
-        hipLaunchKernelGGL(score_narrow_kernel<U>, dim3(grid), dim3(256), lds, st, q, x, nslab, xrow0 / 16, ngroups, (int)per, nrows, \
-                           S, lds_elems, nq, M, ldm, run_shift);                                                           \
+#define LDOT_NARROW(U, QG, T, SLOT)                                                                                            \
+    do {                                                                                                                       \
+        if (dev >= 64 || !g_narrow_attr[SLOT][dev]) {                                                                          \
+            LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)score_narrow_kernel<U, QG, T>,                                     \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, kNarrowMaxLdsKiB * 1024));          \
+            if (dev < 64) g_narrow_attr[SLOT][dev] = true;                                                                     \
+        }                                                                                                                      \
+        hipLaunchKernelGGL((score_narrow_kernel<U, QG, T>), dim3(grid), dim3(T), lds, st, q, x, nslab, xrow0 / 16, ngroups,    \
+                           (int)per, nrows, S, lds_elems, nq, M, ldm, run_shift);                                              \
+    } while (0)
+#define LDOT_NARROW_U(U, SLOT)               \
+    do {                                     \
+        if (qg == 1)                         \
+            LDOT_NARROW(U, 1, 256, SLOT);    \
+        else if (qg == 2)                    \
+            LDOT_NARROW(U, 2, 256, SLOT + 1); \
+        else                                 \
+            LDOT_NARROW(U, 4, 512, SLOT + 2); \
     } while (0)
     if (nslab % 8 == 0)
-        LDOT_NARROW(8, 0);
+        LDOT_NARROW_U(8, 0);
     else if (nslab % 4 == 0)
-        LDOT_NARROW(4, 1);
+        LDOT_NARROW_U(4, 3);
     else
-        LDOT_NARROW(2, 2);
+        LDOT_NARROW_U(2, 6);
+#undef LDOT_NARROW_U
 #undef LDOT_NARROW
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;

@@ -62,8 +62,9 @@ __global__ __launch_bounds__(THREADS) void narrow_tau_kernel(const uint32_t* __r
     if (tid == 0) tau_key[q] = res;
 }
 
-// grid (<= ceil(nruns / 4), nq), waves stride over the runs: one WAVE per run — it looks at the run's maximum (and leaves it zero for
-// the next scan) and, if that qualifies, scans the run's rows, 4 loads in flight per lane
+// grid (ceil(nruns / 64), nq): a WAVE takes 16 consecutive runs — one load fetches their maxima (and leaves them zero for the next
+// scan), then it scans the qualifying ones (about one in ten), 4 loads in flight per lane.  (One run per wave left every wave a
+// dependent maximum-then-rows chain and thousands of workgroups to dispatch: 28 us for 64 queries.)
 __global__ __launch_bounds__(256) void narrow_collect_kernel(const float* __restrict__ S, int64_t lds_elems, uint32_t* __restrict__ M,
                                                              int64_t ldm, int nruns, int run_rows, int64_t nrows, int64_t row0,
                                                              const uint32_t* __restrict__ tau_key, uint64_t* __restrict__ cand,
@@ -74,10 +75,16 @@ __global__ __launch_bounds__(256) void narrow_collect_kernel(const float* __rest
     if (nrows_q) nrows = nrows_q[q * nrows_q_stride];   // (per-query column counts: the inverted-file scan)
     const float* s_row = S + (int64_t)q * lds_elems;
     uint64_t* c_row = cand + (int64_t)q * cap;
-    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < nruns; r += gridDim.x * 4) {
-        const uint32_t mk = M[(int64_t)q * ldm + r];
-        if (lane == 0) M[(int64_t)q * ldm + r] = 0;
-        if (~mk > tk) continue;
+    const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    bool pass = false;
+    if (lane < 16 && r0 + lane < nruns) {
+        pass = ~M[(int64_t)q * ldm + r0 + lane] <= tk;
+        M[(int64_t)q * ldm + r0 + lane] = 0;
+    }
+    unsigned long long runs = __ballot(pass);
+    while (runs) {
+        const int r = r0 + __ffsll((long long)runs) - 1;
+        runs &= runs - 1;
         const int64_t c0 = (int64_t)r * run_rows;
         const int64_t c1 = c0 + run_rows < nrows ? c0 + run_rows : nrows;
         for (int64_t cb = c0; cb < c1; cb += 256) {   // (wave-uniform trip count: the ballots below are wave-wide)
@@ -145,9 +152,7 @@ int launch_narrow_tau(const uint32_t* M, int64_t ldm, int nruns, int nq, int kp,
 int launch_narrow_collect(const float* S, int64_t lds_elems, uint32_t* M, int64_t ldm, int nruns, int run_rows, int64_t nrows,
                           int64_t row0, int nq, const uint32_t* tau_key, uint64_t* cand, int cap, int32_t* cnt, const int32_t* nrows_q,
                           int64_t nrows_q_stride, hipStream_t st) {
-    // (thousands of workgroups that exit at once cost more in dispatch than they do in work: 16 queries x 489 took 27 us)
-    const int want = (nruns + 3) / 4, lim = 1024 / nq > 16 ? 1024 / nq : 16;
-    hipLaunchKernelGGL(narrow_collect_kernel, dim3(want < lim ? want : lim, nq), dim3(256), 0, st, S, lds_elems, M, ldm, nruns, run_rows,
+    hipLaunchKernelGGL(narrow_collect_kernel, dim3((nruns + 63) / 64, nq), dim3(256), 0, st, S, lds_elems, M, ldm, nruns, run_rows,
                        nrows, row0, tau_key, cand, cap, cnt, nrows_q, nrows_q_stride);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;

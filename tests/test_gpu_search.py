@@ -298,9 +298,12 @@ def test_few_queries_wide_path(L, nq, n, d, k):
     (5, 33_333, 96, 100),      # d padded to 128: 4 slabs; ragged last 16-row group
     (2, 20, 768, 100),         # k > ntotal, one partial group (below 2048 rows: the plain dense path)
     (9, 4_200_000, 64, 50),    # more rows than one wide chunk (4M): partial lists of two chunks are merged
+    (17, 50_000, 128, 100),    # two groups of 16 queries per scan
+    (40, 123_287, 768, 50),    # four groups (512-thread workgroups, 96 KiB of query operand in LDS)
+    (64, 300_000, 96, 10),     # the widest narrow batch; runs of 32 rows
 ])
-def test_narrow_scan_up_to_16_queries(L, nq, n, d, k):
-    """<= 16 queries take the HBM-speed narrow scan (score_narrow.hip) in AUTO mode at every index size; the forced fused scan
+def test_narrow_scan_up_to_64_queries(L, nq, n, d, k):
+    """<= 64 queries take the HBM-speed narrow scan (score_narrow.hip) in AUTO mode at every index size; the forced fused scan
     must return the same lists."""
     rng = np.random.default_rng(n * 3 + nq)
     x = rng.standard_normal((n, d)).astype(np.float32)

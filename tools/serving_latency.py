@@ -29,7 +29,7 @@ def run(n, nq=1, d=768, k=100, reps=200, mode=None):
 if __name__ == '__main__':
     only = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     for n in ([only] if only else [1_000_000, 123_287]):
-        for nq in (1, 16):
+        for nq in (1, 16, 64):
             print(json.dumps(run(n, nq)), flush=True)
             if os.environ.get('LDOT_COMPARE_FUSED'):
                 print(json.dumps(run(n, nq, mode=2)), flush=True)
