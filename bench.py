@@ -64,7 +64,7 @@ def main():
                                                       'bookkeeping on a one-GPU box together with --all-on-device0)')
     ap.add_argument('--all-on-device0', action='store_true', help='debug: every rank uses cuda:0')
     ap.add_argument('--cpu-sample-queries', type=int, default=512)
-    ap.add_argument('--workload', default='synthetic1m', choices=['synthetic1m', 'flickr', 'coco'],
+    ap.add_argument('--workload', default='synthetic1m', choices=['synthetic1m', 'flickr', 'coco', 'serving'],
                     help='synthetic1m: BASELINE.json configs[3] (the headline); flickr / coco: the retrieval evaluation of configs[1] / '
                          'configs[2] at the SURVEY 8d S2 stand-in shapes (1 000 / 5 000 images x 5 captions, both directions)')
     ap.add_argument('--normalised', action='store_true',
@@ -102,6 +102,8 @@ def main():
     from lightningdot_amd import _lib as L
     from lightningdot_amd.indexer import DenseFlatIndexer
     L.require_gpu()
+    if args.workload == 'serving':
+        return main_serving(args, world, rank, dev, sharded)
     if args.workload != 'synthetic1m':
         return main_s2(args, world, rank, dev, sharded)
 
@@ -265,6 +267,78 @@ def main():
     print(json.dumps(out), flush=True)
     if sharded:
         dist.destroy_process_group()
+
+
+PEAK_HBM_GBPS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured with a float4 copy)
+
+
+def main_serving(args, world, rank, dev, sharded):
+    """The demo's query path (dvl/utils.py:204-211 retrieve_query): a handful of queries (default 1, --queries) against an
+    HBM-resident index of --rows x --dim, top-k, query on the device -> results in pinned host memory.  A step = one search; the
+    dominant kernel is the index stream of the narrow search (score_narrow_kernel), HBM-bound: roofline in GB/s."""
+    assert not sharded, 'the serving workload is a single-GPU latency measurement'
+    from lightningdot_amd import _lib as L
+    from lightningdot_amd.indexer import FlatIPIndex
+    N, D, K = args.rows, args.dim, args.k
+    Q = args.queries if args.queries != 10_000 else 1
+    x = gen_rows(0, N, D, dev)
+    ix = FlatIPIndex(D)
+    ix.add(x)
+    g = torch.Generator(device='cpu').manual_seed(4321)
+    gt = (torch.arange(Q, dtype=torch.int64) * 9973) % N
+    q = x[gt.to(dev)] + 0.5 * torch.randn(Q, D, generator=g).to(dev)
+    hs = torch.empty((Q, K), dtype=torch.float32).pin_memory()
+    hl = torch.empty((Q, K), dtype=torch.int64).pin_memory()
+    ix.set_option(L.OPT_PROFILE, 1)
+    for _ in range(max(args.warmup, 3)):
+        ix.search_into(q, K, hs, hl)
+    prof = dict(launches=0.0, kernel_ms=0.0, flops=0.0, bytes=0.0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ix.search_into(q, K, hs, hl)
+        pp = ix.last_profile()
+        for k_ in prof:
+            prof[k_] += pp[k_]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stream_bytes = float(N) * D * 2                 # algorithmic bytes of one launch: the bf16 index rows, read once
+    kms = prof['kernel_ms'] / max(prof['launches'], 1.0)
+    ach = stream_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    traffic, tsrc = None, None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'traffic.json')) as f:
+            tj = json.load(f)
+        if N == 1_000_000 and D == 768 and Q == 1 and 'serving_hbm_bytes_per_launch' in tj:
+            traffic, tsrc = tj['serving_hbm_bytes_per_launch'], tj.get('serving_note')
+    except OSError:
+        pass
+    out = {
+        'metric': 'queries/sec', 'value': Q * args.steps / dt, 'unit': 'queries/s', 'n_gpus': 1, 'ranks_seen': 1, 'steps': args.steps,
+        'warmup': max(args.warmup, 3), 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': f'serving latency (dvl/utils.py:204-211 retrieve_query shape): {Q} query x {N} rows x {D}-d, top-{K}, '
+                               f'exact fp32 re-score, results in pinned host memory', 'rows': N, 'queries': Q, 'dim': D, 'k': K,
+                   'parallelism': 'single GPU'},
+        'rank1_ok': bool((hl[:, 0] == gt).all()),
+        'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBPS,
+                     'traffic': traffic, 'traffic_source': tsrc, 'kernel': 'score_narrow_kernel (the index stream)',
+                     'launches_per_step': prof['launches'] / max(args.steps, 1), 'kernel_ms_per_launch': kms,
+                     'algorithmic_bytes_per_launch': stream_bytes,
+                     'whole_search_frac_of_peak': stream_bytes / (dt / args.steps) / 1e9 / PEAK_HBM_GBPS},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import oracle_torch as OT
+        cores = os.cpu_count() or 1
+        qc, xc = q.cpu(), x.cpu()
+        trial = {t: OT.timed(qc, xc, K, t, runs=1)[0] for t in (cores, max(1, cores // 2))}
+        threads = min(trial, key=trial.get)
+        dtc, _, cl = OT.timed(qc, xc, K, threads, runs=5)
+        out['cpu_baseline'] = {'value': Q / dtc, 'unit': 'queries/s', 'cores': int(threads), 'kind': 'port',
+                               'sample': f'the same {Q}-query search, oracle_torch.search_blocked (torch.matmul + torch.topk, fp32) at '
+                                         f'{threads} threads (better of all / half), median of 5 runs after warm-up',
+                               'rank1_mismatches_vs_gpu': int((hl.numpy()[:, 0] != cl.numpy()[:, 0]).sum())}
+    print(json.dumps(out), flush=True)
 
 
 def main_s2(args, world, rank, dev, sharded):

@@ -13,6 +13,8 @@ timeout 600 python bench.py --workload flickr --steps 50 --warmup 5 > $O/bench_f
 timeout 600 python bench.py --workload coco --steps 20 --warmup 3 > $O/bench_coco.json 2>> $O/bench.err
 timeout 600 python bench.py --gpus 2 --all-on-device0 --backend gloo --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_2ranks_gloo_one_gpu.json 2>> $O/bench.err
 timeout 300 python tools/serving_latency.py > $O/serving_latency.jsonl 2>> $O/bench.err
+timeout 600 python bench.py --workload serving --steps 50 --warmup 5 > $O/bench_serving.json 2>> $O/bench.err
+timeout 600 python bench.py --workload serving --rows 123287 --steps 50 --warmup 5 > $O/bench_serving_123287.json 2>> $O/bench.err
 [ -x tools/bin/mfma_ceiling ] && timeout 300 tools/bin/mfma_ceiling 12 > $O/mfma_ceiling.txt 2>&1
 timeout 300 python tools/gemm_ref.py > $O/vendor_gemm.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
@@ -24,6 +26,7 @@ for g in "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIV
   bash tools/pmc2.sh "$g" >> $O/pmc.txt 2>&1
 done
 bash tools/timeline.sh > /dev/null 2>&1; cp gpurun_out/timeline.txt $O/timeline.txt 2>/dev/null
+bash tools/pmc_serving.sh > $O/pmc_serving.txt 2>&1
 bash tools/serving_timeline.sh 1000000 > $O/serving_timeline_1m.txt 2>&1
 bash tools/serving_timeline.sh 123287 > $O/serving_timeline_123287.txt 2>&1
 timeout 600 python tools/ivf_bench.py > $O/ivf_bench.jsonl 2>> $O/bench.err
