@@ -66,6 +66,8 @@ class DenseIVFFlatIndexer(DenseIndexer):
         self.list_offsets = None                          # int64 [nlist + 1], device
         self.max_list_len = 0
         self.phi = 0.0
+        self.biased_list_len = 0.0                        # sum(len^2) / sum(len): expected length of a probed list
+        self.last_route = None                            # 'lists' or 'exact': what the last search did
 
     # ---- build (all data at once, like the reference's HNSW indexer :111-113) --------------------------------------------------
     def index_data(self, data: List[Tuple[object, np.array]]):
@@ -101,6 +103,7 @@ class DenseIVFFlatIndexer(DenseIndexer):
         counts = torch.bincount(assign, minlength=nlist)
         self.list_offsets = torch.cat([torch.zeros(1, dtype=torch.int64, device=x.device), counts.cumsum(0)]).contiguous()
         self.max_list_len = int(counts.max().item()) if n else 0
+        self.biased_list_len = float((counts.double() ** 2).sum().item() / max(n, 1))
         order_h = order.cpu().tolist()
         self._update_id_mapping([db_ids[i] for i in order_h])                    # label (sorted row) -> external id
         self.index.add(x[order])
@@ -115,8 +118,25 @@ class DenseIVFFlatIndexer(DenseIndexer):
         self.coarse.add(torch.cat([cent, -0.5 * (cent * cent).sum(1, keepdim=True)], 1))
 
     # ---- search ------------------------------------------------------------------------------------------------------------------
-    def search_knn_tensors(self, query_vectors, top_docs: int, nprobe: Optional[int] = None):
-        """(scores [nq, k] fp32 descending, row labels [nq, k] int64; -1 padding) as device tensors"""
+    def _exact_is_cheaper(self, nq: int, nprobe: int) -> bool:
+        """Cost model from the measured rates on MI355X (profiles/r02_ivf_bench.jsonl, r02_serving_latency.jsonl): the list scan gathers
+        fp32 rows at ~3.5 TB/s per query; the exact search streams the bf16 index once at ~6.3 TB/s for <= 64 queries (+17 % per 16
+        queries of score traffic) and runs at ~1.2 PFLOP/s plus ~0.6 ms of fixed cost for larger batches."""
+        n, d = self.index.ntotal, self.d
+        # probed rows per query: a query lands in (and next to) a list with probability proportional to its size, so the expected
+        # length of a probed list is the size-biased mean sum(len^2) / sum(len), not n / nlist — and its neighbours are long lists too
+        # (measured on clustered data: twice the size-biased mean again)
+        rows = min(n, 2.0 * nprobe * self.biased_list_len)
+        t_lists = 0.10e-3 + nq * rows * d * 4 / 3.5e12
+        if nq <= 64:
+            t_exact = 0.06e-3 + n * d * 2 / 6.3e12 * (1 + 0.17 * ((nq - 1) // 16))
+        else:
+            t_exact = 0.6e-3 + 2.0 * nq * n * d / 1.2e15
+        return t_exact < t_lists
+
+    def search_knn_tensors(self, query_vectors, top_docs: int, nprobe: Optional[int] = None, exact_when_cheaper: bool = True):
+        """(scores [nq, k] fp32 descending, row labels [nq, k] int64; -1 padding) as device tensors.  ``exact_when_cheaper``: answer
+        with the exact search when the cost model says it is faster than scanning the probed lists (large batches)."""
         import torch
         if self.coarse is None:
             raise RuntimeError('the IVF index is empty')
@@ -126,6 +146,12 @@ class DenseIVFFlatIndexer(DenseIndexer):
             q = q[None]
         nq = q.shape[0]
         nprobe = min(int(nprobe or self.nprobe), self.nlist)
+        if exact_when_cheaper and self._exact_is_cheaper(nq, nprobe):
+            # a batch re-reads its probed fp32 rows once per query, the exact search reuses every bf16 index tile across the whole batch:
+            # from a handful of queries on, the exact answer (recall 1.0, same row labels) is also the faster one
+            self.last_route = 'exact'
+            return self.index.search_tensors(q, top_docs)
+        self.last_route = 'lists'
         scores = torch.empty((nq, top_docs), dtype=torch.float32, device=q.device)
         labels = torch.empty((nq, top_docs), dtype=torch.int64, device=q.device)
         ix = self.index
@@ -174,6 +200,8 @@ class DenseIVFFlatIndexer(DenseIndexer):
         assert len(self.index_id_to_db_id) == self.index.ntotal, 'Deserialized index_id_to_db_id should match faiss index size'
         self.list_offsets = torch.from_numpy(m['list_offsets']).cuda()
         self.max_list_len = int(np.diff(m['list_offsets']).max()) if len(m['list_offsets']) > 1 else 0
+        lens = np.diff(m['list_offsets']).astype(np.float64)
+        self.biased_list_len = float((lens ** 2).sum() / max(lens.sum(), 1.0))
         self.nlist = len(m['list_offsets']) - 1
         self.phi, self.nprobe = m['phi'], m['nprobe']
         self._set_coarse(torch.from_numpy(m['centroids']).cuda())

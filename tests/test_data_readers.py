@@ -116,3 +116,4 @@ def test_dataset_collate_and_hard_negatives(tmp_path):
     from lightningdot_amd.synthetic import synthetic_itm_batches
     syn, _ = synthetic_itm_batches(4, caps_per_img=1, batch_size=4, num_hard_negatives=2)
     assert set(syn[0]) == set(b) and all(set(syn[0][k]) == set(b[k]) for k in ('txts', 'imgs', 'caps'))
+

@@ -127,7 +127,7 @@ def test_one_call_ivf_search_equals_coarse_search_plus_list_scan():
     ivf.index_tensor(list(range(30000)), torch.from_numpy(x))
     for nq in (1, 16, 300):                                   # narrow coarse search, its widest batch, more than one 256-query chunk
         q = torch.from_numpy((x[rng.integers(0, 30000, nq)] + 0.2 * rng.standard_normal((nq, 64))).astype(np.float32)).cuda()
-        s1, l1 = ivf.search_knn_tensors(q, 20)
+        s1, l1 = ivf.search_knn_tensors(q, 20, exact_when_cheaper=False)
         qa = torch.cat([q, torch.zeros(nq, 1, device='cuda'), torch.ones(nq, 1, device='cuda')], 1)
         _, probes = ivf.coarse.search_tensors(qa, 9)
         s2, l2 = ivf.search_lists_tensors(q, probes, 20)
@@ -192,3 +192,19 @@ def test_ivf_search_rejects_a_mismatched_coarse_index():
     rc = ix._lib.ldot_ivf_search(ix._h, bad._h, ctypes.c_void_p(q.data_ptr()), 1, L.F32, 0, ctypes.c_void_p(offs.data_ptr()), 16, 1, 4,
                                  ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(l.data_ptr()), L.DEVICE, None)
     assert rc != 0 and b'coarse' in ix._lib.ldot_last_error()
+
+
+def test_large_batches_are_answered_by_the_exact_search_when_that_is_cheaper():
+    import torch
+    from lightningdot_amd.ivf import DenseIVFFlatIndexer
+    x, rng = _clustered(200000, 64, 400, 13)
+    ivf = DenseIVFFlatIndexer(64, nlist=400, nprobe=64)
+    ivf.index_tensor(list(range(200000)), torch.from_numpy(x))
+    qb = torch.from_numpy((x[rng.integers(0, 200000, 2000)] + 0.1 * rng.standard_normal((2000, 64))).astype(np.float32)).cuda()
+    sb, lb = ivf.search_knn_tensors(qb, 10)                       # 2000 queries x 64 of 400 lists: scanning costs more than the exact search
+    assert ivf.last_route == 'exact'
+    se, le = ivf.index.search_tensors(qb, 10)
+    assert torch.equal(lb, le) and torch.equal(sb, se)
+    sl, ll = ivf.search_knn_tensors(qb, 10, exact_when_cheaper=False)
+    assert ivf.last_route == 'lists'
+    assert float((ll[:, 0] == le[:, 0]).float().mean()) > 0.95

@@ -32,11 +32,14 @@ def lat(fn, reps=100):
 print(json.dumps(dict(rows=N, nlist=ivf.nlist, longest_list=ivf.max_list_len, build_s=build,
                       exact_ms_1q=lat(lambda: flat.search_knn_tensors(q[:1], K)), exact_ms_16q=lat(lambda: flat.search_knn_tensors(q[:16], K)))), flush=True)
 for nprobe in (4, 8, 16, 32, 64):
-    s, l = ivf.search_knn_tensors(q, K, nprobe)
+    s, l = ivf.search_knn_tensors(q, K, nprobe, exact_when_cheaper=False)
     orig = torch.where(l >= 0, inv[l.clamp_min(0)], l)
     recall = float(sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(orig, el)) / (512 * K))
     r1 = float((orig[:, 0] == el[:, 0]).float().mean())
     print(json.dumps(dict(nprobe=nprobe, recall_at_10=recall, rank1_agreement=r1,
-                          ms_1q=lat(lambda: ivf.search_knn_tensors(q[:1], K, nprobe)),
-                          ms_16q=lat(lambda: ivf.search_knn_tensors(q[:16], K, nprobe)),
-                          ms_512q=lat(lambda: ivf.search_knn_tensors(q, K, nprobe), 20))), flush=True)
+                          ms_1q=lat(lambda: ivf.search_knn_tensors(q[:1], K, nprobe, exact_when_cheaper=False)),
+                          ms_16q=lat(lambda: ivf.search_knn_tensors(q[:16], K, nprobe, exact_when_cheaper=False)),
+                          ms_512q=lat(lambda: ivf.search_knn_tensors(q, K, nprobe, exact_when_cheaper=False), 20),
+                          # default routing: the exact search answers when the cost model says it is faster
+                          routed={n: (round(lat(lambda: ivf.search_knn_tensors(q[:n], K, nprobe), 20), 4), ivf.last_route)
+                                  for n in (1, 4, 16, 512)})), flush=True)
