@@ -121,7 +121,8 @@ int ldot_index_search_finish(ldot_index_t* ix, const float* floor, float* out_sc
  * (-1 = skip) and the k best of those are returned in descending score order with their row labels (LDOT_PAD_LABEL / LDOT_PAD_SCORE
  * when the lists hold fewer than k rows).  list_offsets [nlist+1] int64 and probes [nq*nprobe] int32 are DEVICE memory, the queries
  * are DEVICE memory of `dtype`; max_list_len = the longest list.  (The coarse step — which lists to probe — is an ordinary
- * ldot_index_search over the list centroids.) */
+ * ldot_index_search over the list centroids.)  The call synchronises `stream` once per chunk of 256 queries, also with DEVICE outputs:
+ * a query whose candidate buffer filled up (thousands of equal scores) is noticed there and redone (stats[1] counts them). */
 int ldot_index_search_lists(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int normalize, const int64_t* list_offsets,
                             int nlist, int64_t max_list_len, const int32_t* probes, int nprobe, int k, float* out_scores,
                             int64_t* out_labels, int out_mem, void* stream);
@@ -129,7 +130,7 @@ int ldot_index_search_lists(ldot_index_t* ix, const void* queries, int64_t nq, i
  * nlist = ntotal(coarse) list centroids in the augmented space of the reference's HNSW indexer (faiss_indexers.py:114-131) plus one
  * coordinate: row l = [c_l, sqrt(phi - |c_l|^2), -|c~_l|^2 / 2] (dimension d + 2), so that its inner product with [q, 0, 1] ranks the
  * lists by L2 distance to the query.  Queries are DEVICE memory of `dtype`, list_offsets [nlist+1] int64 DEVICE memory; the result is
- * that of ldot_index_search_lists with probes = the nprobe nearest lists. */
+ * that of ldot_index_search_lists with probes = the nprobe nearest lists (nprobe <= LDOT_MAX_K). */
 int ldot_ivf_search(ldot_index_t* ix, ldot_index_t* coarse, const void* queries, int64_t nq, int dtype, int normalize,
                     const int64_t* list_offsets, int64_t max_list_len, int nprobe, int k, float* out_scores, int64_t* out_labels,
                     int out_mem, void* stream);
