@@ -130,7 +130,7 @@ int ldot_index_search_lists(ldot_index_t* ix, const void* queries, int64_t nq, i
  * nlist = ntotal(coarse) list centroids in the augmented space of the reference's HNSW indexer (faiss_indexers.py:114-131) plus one
  * coordinate: row l = [c_l, sqrt(phi - |c_l|^2), -|c~_l|^2 / 2] (dimension d + 2), so that its inner product with [q, 0, 1] ranks the
  * lists by L2 distance to the query.  Queries are DEVICE memory of `dtype`, list_offsets [nlist+1] int64 DEVICE memory; the result is
- * that of ldot_index_search_lists with probes = the nprobe nearest lists (nprobe <= LDOT_MAX_K). */
+ * that of ldot_index_search_lists with probes = the nprobe nearest lists (nprobe <= 2048, the largest k of a search). */
 int ldot_ivf_search(ldot_index_t* ix, ldot_index_t* coarse, const void* queries, int64_t nq, int dtype, int normalize,
                     const int64_t* list_offsets, int64_t max_list_len, int nprobe, int k, float* out_scores, int64_t* out_labels,
                     int out_mem, void* stream);
