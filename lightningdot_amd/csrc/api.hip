@@ -592,6 +592,7 @@ static int dense_scan_all(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, in
 // geometrically growing fused-filter launches, each followed by the pool select that raises the thresholds.
 // Queries are processed in chunks of kFusedQueryChunk (bounds the candidate pools: 196 KiB per query at 128 sub-pools).
 constexpr int64_t kFusedQueryChunk = 16384;
+constexpr int64_t kFewSelectMaxQueries = 256;   // one query block: sub-pools folded by 16 waves per query + one merge
 constexpr int64_t kFewBlockGrowthPct = 1600;   // launch growth with ONE query block (65 .. 256 queries): 2-3 % faster than growing
                                                // straight to the pool bound (tools/fewgrowth_sweep.py: 0.657 vs 0.675 ms at 100 queries)
 
@@ -644,7 +645,7 @@ static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_p
                                  (uint4*)ix->w_pool.p, (int32_t*)ix->w_pool_cnt.p, st);
         prof_end(ix, st);
         if (rc) return rc;
-        if (nq <= 64 && nsubs >= 512 && kp + 512 + 32 <= 1024) {
+        if (nq <= kFewSelectMaxQueries && nsubs >= 512 && kp + 512 + 32 <= 1024) {
             // few queries: G waves per query fold the sub-pools into partial lists, one merge joins them with the running list
             const int G = 16;
             if ((rc = ix->w_part_s.ensure((size_t)G * nq * kp * 4))) return rc;
