@@ -112,6 +112,19 @@ def test_config3_full_size_properties():
     ix.set_option(L.OPT_MODE, L.MODE_DENSE)
     sd, ld = ix.search_tensors(q[:512], k)
     assert torch.equal(ld, l[:512]) and torch.equal(sd, s[:512])
+    # the serving shapes (1 / 16 / 64 queries: narrow search) at full size == the batch result of the same queries (fused scan),
+    # and == the fp64 top-k of an exhaustive device scan
+    ix.set_option(L.OPT_MODE, L.MODE_AUTO)
+    for m in (1, 16, 64):
+        sn, ln = ix.search_tensors(q[:m], k)
+        stn = ix.last_stats()
+        assert stn['fused_pairs'] == 0 and stn['dense_pairs'] == m * n and stn['overflowed_queries'] == 0
+        assert torch.equal(ln, l[:m]) and torch.equal(sn, s[:m])
+    full = q[:4].double() @ x.double().T
+    ts, tl = torch.topk(full, k, dim=1)
+    assert torch.equal(tl, l[:4])
+    assert float((ts - s[:4].double()).abs().max()) < 1e-3
+    del full
     # row-sharded == whole: merge of per-shard top-k (the multi-GPU decomposition) on a query sample
     qs = q[:256].cpu().numpy()
     parts = []
