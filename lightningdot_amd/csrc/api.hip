@@ -475,7 +475,7 @@ static int dense_scan_wide(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, i
                    (double)nrows * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * nrows * 4);
         if (narrow_ok(ix, nq))   // <= 64 queries: HBM-speed wave-per-group scan, no query-tile padding
             rc = launch_score_narrow(ix->w_q16b.p, ix->x16b, ix->ld16(), r, nrows, (float*)ix->w_S.p, nrows_pad, (int)nq, nullptr, 0,
-                                     0, st);
+                                     0, 0, st);
         else
             rc = launch_score_dense(ix->w_q16b.p, ix->ld16(), kBM, ix->x16b, ix->ld16(), r, nrows_pad, (int)ix->ld16(),
                                     (float*)ix->w_S.p, nrows_pad, nq, st);
@@ -550,15 +550,16 @@ static int narrow_search(ldot_index* ix, int64_t nq, int kp, hipStream_t st) {
         const int64_t nrows = std::min(wide, ix->ntotal - r), nrows_pad = round_up(nrows, 16);
         int sh, nruns;
         narrow_plan(nrows, kp, &sh, &nruns);
-        if ((rc = ix->w_S.ensure((size_t)nq * nrows_pad * sizeof(float)))) return rc;
+        const int qgroups = nq <= 16 ? 1 : nq <= 32 ? 2 : 4;   // S in 1-KiB tiles of 16 queries x 16 rows (coalesced stores)
+        if ((rc = ix->w_S.ensure((size_t)qgroups * 16 * nrows_pad * sizeof(float)))) return rc;
         prof_begin(ix, st, 2.0 * nq * nrows * ix->d, (double)nrows * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * nrows * 4);
         rc = launch_score_narrow(ix->w_q16b.p, ix->x16b, ix->ld16(), r, nrows, (float*)ix->w_S.p, nrows_pad, (int)nq, M,
-                                 kNarrowMaxRuns, sh, st);
+                                 kNarrowMaxRuns, sh, 1, st);
         prof_end(ix, st);
         if (rc) return rc;
         if ((rc = launch_narrow_tau(M, kNarrowMaxRuns, nruns, (int)nq, kp, tk, st))) return rc;
         if ((rc = launch_narrow_collect((const float*)ix->w_S.p, nrows_pad, M, kNarrowMaxRuns, nruns, 16 << sh, nrows, r, (int)nq, tk,
-                                        (uint64_t*)ix->w_ncand.p, cap, (int32_t*)ix->w_ncnt.p, nullptr, 0, st)))
+                                        (uint64_t*)ix->w_ncand.p, cap, (int32_t*)ix->w_ncnt.p, nullptr, 0, qgroups, st)))
             return rc;
         ix->stats[2] += nrows * nq;
     }
@@ -992,7 +993,7 @@ static int lists_search_impl(ldot_index* ix, const void* queries, int64_t nq, in
             if ((rc = launch_narrow_tau(M, nruns, (int)nruns, (int)n, kp, tk, st))) return rc;
             if ((rc = launch_narrow_collect((const float*)ix->w_S.p, max_cols, M, nruns, (int)nruns, run, max_cols, 0, (int)n, tk,
                                             (uint64_t*)ix->w_ncand.p, kNarrowCandCap, (int32_t*)ix->w_ncnt.p, cstart + nprobe, nprobe + 1,
-                                            st)))
+                                            0, st)))
                 return rc;
             if ((rc = launch_ivf_final((const uint64_t*)ix->w_ncand.p, kNarrowCandCap, (int32_t*)ix->w_ncnt.p, n, rowbase, cstart, nprobe, k,
                                        ds, dl, ix->d_nover, st)))

@@ -45,15 +45,16 @@ constexpr int kNarrowCandCap = 16384;   // candidate keys per query (128 KiB of 
 constexpr int kNarrowCntStride = 64;    // ints between the candidate counters of two queries (atomics on one cache line serialise)
 // M (optional, zero on entry) [nq][ldm]: ascending keys (~desc_key) of the per-run maxima over the valid rows, run = 16 << run_shift rows
 int launch_score_narrow(const void* q16b, const void* x16b, int64_t ld_elems, int64_t xrow0, int64_t nrows, float* S,
-                        int64_t lds_elems, int nq, uint32_t* M, int64_t ldm, int run_shift, hipStream_t st);
+                        int64_t lds_elems, int nq, uint32_t* M, int64_t ldm, int run_shift, int tiled, hipStream_t st);
 // selection from the run maxima (select_narrow.hip): threshold key per query, candidate collection (leaves M zero again), final
 // sorted lists.  cnt [nq * kNarrowCntStride] must be zero before the first collect of a search (the final kernel leaves it zero); over[q] = 1 marks a
 // query whose candidate buffer was full (its list is unusable).
 int launch_narrow_tau(const uint32_t* M, int64_t ldm, int nruns, int nq, int kp, uint32_t* tau_key, hipStream_t st);
-// nrows_q (optional): per-query row counts nrows_q[q * nrows_q_stride] instead of nrows
+// nrows_q (optional): per-query row counts nrows_q[q * nrows_q_stride] instead of nrows; tiled_qg: 0 = S is row-major [q][lds_elems],
+// else the number of query groups of the tiled layout launch_score_narrow(tiled = 1) writes
 int launch_narrow_collect(const float* S, int64_t lds_elems, uint32_t* M, int64_t ldm, int nruns, int run_rows, int64_t nrows,
                           int64_t row0, int nq, const uint32_t* tau_key, uint64_t* cand, int cap, int32_t* cnt, const int32_t* nrows_q,
-                          int64_t nrows_q_stride, hipStream_t st);
+                          int64_t nrows_q_stride, int tiled_qg, hipStream_t st);
 int launch_narrow_final(const uint64_t* cand, int cap, int32_t* cnt, int nq, float* list_s, int32_t* list_i, int kp, float* tau,
                         int32_t* over, hipStream_t st);
 

@@ -21,12 +21,13 @@
 
 namespace ldot {
 
-// UNR blocks in flight per wave, QG groups of 16 queries (1, 2 or 4), THREADS per workgroup
-template <int UNR, int QG, int THREADS>
+// UNR blocks per chunk, PF chunk buffers per wave (PF - 1 chunks in flight while one is multiplied), QG groups of 16 queries (1, 2 or
+// 4), THREADS per workgroup
+template <int UNR, int QG, int THREADS, int PF>
 __global__ __launch_bounds__(THREADS) void score_narrow_kernel(const char* __restrict__ Q16b, const char* __restrict__ X16b,
                                                                int nslab, int64_t g0, int64_t ngroups, int per, int64_t nrows,
                                                                float* __restrict__ S, int64_t lds_elems, int nq,
-                                                               uint32_t* __restrict__ M, int64_t ldm, int run_shift) {
+                                                               uint32_t* __restrict__ M, int64_t ldm, int run_shift, int tiled) {
     // QG * nslab KiB: query blocks 0 .. QG-1 of the blocked query shadow (block (g, s) at (g * nslab + s) KiB, like the source)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -40,17 +41,23 @@ __global__ __launch_bounds__(THREADS) void score_narrow_kernel(const char* __res
     if (gbeg >= gend) return;
     const int lo = (lane & 15) * 64 + (lane >> 4) * 16;
     const int nc = nslab / UNR;                               // chunks of UNR blocks per group
-    const char* xp = X16b + (g0 + gbeg) * (int64_t)nslab * 1024 + lo;   // current chunk
+    const char* xi = X16b + (g0 + gbeg) * (int64_t)nslab * 1024 + lo;   // next chunk to ISSUE
     const char* qb = smem + lo;
     const int qstride = nslab * 1024;                         // LDS bytes between two query groups
-    int64_t left = (gend - gbeg) * nc;                        // chunks left, the current one included
+    int64_t left = (gend - gbeg) * nc;                        // chunks left to multiply
+    int64_t to_issue = left;                                  // chunks left to issue
 
-    bf16x8_t a[2][UNR];
-    auto load = [&](bf16x8_t (&dst)[UNR], const char* p) {
+    bf16x8_t a[PF][UNR];
+    // (unconditional: a load under a branch makes the compiler's vmcnt bookkeeping assume it did not happen and wait for everything;
+    // past the end of the stream the wave re-reads its last chunk and drops it)
+    auto issue = [&](bf16x8_t (&dst)[UNR]) {
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) dst[u] = __builtin_nontemporal_load((const bf16x8_t*)(p + u * 1024));
+        for (int u = 0; u < UNR; ++u) dst[u] = __builtin_nontemporal_load((const bf16x8_t*)(xi + u * 1024));
+        if (to_issue > 1) xi += UNR * 1024;
+        --to_issue;
     };
-    load(a[0], xp);
+#pragma unroll
+    for (int b = 0; b < PF - 1; ++b) issue(a[b]);
     int64_t g = gbeg;
     int c = 0;
     float m[QG];
@@ -61,20 +68,17 @@ __global__ __launch_bounds__(THREADS) void score_narrow_kernel(const char* __res
         acc[qg][0] = acc[qg][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     for (;;) {
-        // (two chunks per trip so that the register double buffer is indexed statically)
+        // (PF chunks per trip so that the register buffers are indexed statically)
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            // (unconditional: a load under a branch makes the compiler's vmcnt bookkeeping assume it did not happen and wait
-            // for everything; at the end of the stream the wave re-reads its last chunk and drops it)
-            const char* xn = left > 1 ? xp + UNR * 1024 : xp;
-            load(a[half ^ 1], xn);
+        for (int b = 0; b < PF; ++b) {
+            issue(a[(b + PF - 1) % PF]);
             const char* qc = qb + c * UNR * 1024;
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
 #pragma unroll
                 for (int qg = 0; qg < QG; ++qg)
                     acc[qg][u & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        a[half][u], *(const bf16x8_t*)(qc + qg * qstride + u * 1024), acc[qg][u & 1], 0, 0, 0);
+                        a[b][u], *(const bf16x8_t*)(qc + qg * qstride + u * 1024), acc[qg][u & 1], 0, 0, 0);
             }
             if (++c == nc) {   // the group is complete
                 c = 0;
@@ -87,7 +91,13 @@ __global__ __launch_bounds__(THREADS) void score_narrow_kernel(const char* __res
                     const f32x4 v = acc[qg][0] + acc[qg][1];
                     acc[qg][0] = acc[qg][1] = f32x4{0.f, 0.f, 0.f, 0.f};
                     const int q = qg * 16 + (lane & 15);
-                    if (q < nq) *(f32x4*)(S + (int64_t)q * lds_elems + col) = v;
+                    if (tiled) {
+                        // tile (group, query group) = 16 queries x 16 rows = 1 KiB, query-major: the wave's store instruction covers
+                        // the tile exactly once — eight full 128-B lines instead of sixteen 64-B pieces of sixteen different rows
+                        if (q < nq) *(f32x4*)(S + ((g * QG + qg) * 256 + (lane & 15) * 16 + (lane >> 4) * 4)) = v;
+                    } else if (q < nq) {
+                        *(f32x4*)(S + (int64_t)q * lds_elems + col) = v;
+                    }
                     if (M != nullptr) {
                         m[qg] = fmaxf(m[qg], fmaxf(fmaxf(valid > 0 ? v[0] : -INFINITY, valid > 1 ? v[1] : -INFINITY),
                                                    fmaxf(valid > 2 ? v[2] : -INFINITY, valid > 3 ? v[3] : -INFINITY)));
@@ -103,7 +113,6 @@ __global__ __launch_bounds__(THREADS) void score_narrow_kernel(const char* __res
                 ++g;
             }
             if (--left == 0) return;
-            xp = xn;
         }
     }
 }
@@ -112,10 +121,12 @@ static bool g_narrow_attr[9][64];   // hipFuncSetAttribute once per kernel varia
 
 // q16b / x16b: the BLOCKED shadows; xrow0 a multiple of 16; scores of rows [xrow0, xrow0 + 16 * ceil(nrows / 16)) are written to
 // S[q][row - xrow0] for q < nq <= 64 (the caller's row stride lds_elems covers the rounded-up count).
+// tiled != 0: S is written as 1-KiB tiles instead, tile (group g, query group qg) at ((g * QG + qg) * 256) floats holding
+// [16 queries][16 rows] with QG = 1, 2, 4 for nq <= 16, 32, 64 (what the run-maxima selection reads; coalesced stores).
 // M (optional, all zero on entry): M[q][r] = ascending key (~desc_key) of the max score of query q over the VALID rows of
 // run r = rows [r * (16 << run_shift), (r + 1) * (16 << run_shift)) of the launch.
 int launch_score_narrow(const void* q16b, const void* x16b, int64_t ld_elems, int64_t xrow0, int64_t nrows, float* S,
-                        int64_t lds_elems, int nq, uint32_t* M, int64_t ldm, int run_shift, hipStream_t st) {
+                        int64_t lds_elems, int nq, uint32_t* M, int64_t ldm, int run_shift, int tiled, hipStream_t st) {
     if (nrows <= 0 || nq <= 0) return LDOT_OK;
     const int nslab = (int)(ld_elems / 32);
     const int qg = nq <= 16 ? 1 : nq <= 32 ? 2 : 4;
@@ -137,24 +148,24 @@ int launch_score_narrow(const void* q16b, const void* x16b, int64_t ld_elems, in
     const char* x = (const char*)x16b;
     int dev = 0;
     LDOT_HIP_CHECK(hipGetDevice(&dev));
-#define LDOT_NARROW(U, QG, T, SLOT)                                                                                            \
+#define LDOT_NARROW(U, QG, T, PFV, SLOT)                                                                                          \
     do {                                                                                                                       \
         if (dev >= 64 || !g_narrow_attr[SLOT][dev]) {                                                                          \
-            LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)score_narrow_kernel<U, QG, T>,                                     \
+            LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)score_narrow_kernel<U, QG, T, PFV>,                                     \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, kNarrowMaxLdsKiB * 1024));          \
             if (dev < 64) g_narrow_attr[SLOT][dev] = true;                                                                     \
         }                                                                                                                      \
-        hipLaunchKernelGGL((score_narrow_kernel<U, QG, T>), dim3(grid), dim3(T), lds, st, q, x, nslab, xrow0 / 16, ngroups,    \
-                           (int)per, nrows, S, lds_elems, nq, M, ldm, run_shift);                                              \
+        hipLaunchKernelGGL((score_narrow_kernel<U, QG, T, PFV>), dim3(grid), dim3(T), lds, st, q, x, nslab, xrow0 / 16, ngroups,    \
+                           (int)per, nrows, S, lds_elems, nq, M, ldm, run_shift, tiled);                                              \
     } while (0)
 #define LDOT_NARROW_U(U, SLOT)               \
     do {                                     \
         if (qg == 1)                         \
-            LDOT_NARROW(U, 1, 256, SLOT);    \
+            LDOT_NARROW(U, 1, 256, 2, SLOT);    \
         else if (qg == 2)                    \
-            LDOT_NARROW(U, 2, 256, SLOT + 1); \
+            LDOT_NARROW(U, 2, 256, 2, SLOT + 1); \
         else                                 \
-            LDOT_NARROW(U, 4, 512, SLOT + 2); \
+            LDOT_NARROW(U, 4, 512, 2, SLOT + 2); \
     } while (0)
     if (nslab % 8 == 0)
         LDOT_NARROW_U(8, 0);

@@ -69,11 +69,14 @@ __global__ __launch_bounds__(256) void narrow_collect_kernel(const float* __rest
                                                              int64_t ldm, int nruns, int run_rows, int64_t nrows, int64_t row0,
                                                              const uint32_t* __restrict__ tau_key, uint64_t* __restrict__ cand,
                                                              int cap, int32_t* __restrict__ cnt,
-                                                             const int32_t* __restrict__ nrows_q, int64_t nrows_q_stride) {
+                                                             const int32_t* __restrict__ nrows_q, int64_t nrows_q_stride,
+                                                             int tiled_qg) {
     const int q = blockIdx.y, lane = threadIdx.x & 63;
     const uint32_t tk = tau_key[q];
     if (nrows_q) nrows = nrows_q[q * nrows_q_stride];   // (per-query column counts: the inverted-file scan)
-    const float* s_row = S + (int64_t)q * lds_elems;
+    // score of column c: row-major S[q][c], or the tiled layout of the narrow scan (1 KiB per 16 queries x 16 rows)
+    const float* s_row = tiled_qg ? S + ((q >> 4) * 256 + (q & 15) * 16) : S + (int64_t)q * lds_elems;
+    const int64_t tile_stride = (int64_t)tiled_qg * 256;
     uint64_t* c_row = cand + (int64_t)q * cap;
     const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
     bool pass = false;
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void narrow_collect_kernel(const float* __rest
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t c = cb + u * 64 + lane;
-                sv[u] = c < c1 ? s_row[c] : 0.f;
+                sv[u] = c < c1 ? (tiled_qg ? s_row[(c >> 4) * tile_stride + (c & 15)] : s_row[c]) : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -151,9 +154,9 @@ int launch_narrow_tau(const uint32_t* M, int64_t ldm, int nruns, int nq, int kp,
 
 int launch_narrow_collect(const float* S, int64_t lds_elems, uint32_t* M, int64_t ldm, int nruns, int run_rows, int64_t nrows,
                           int64_t row0, int nq, const uint32_t* tau_key, uint64_t* cand, int cap, int32_t* cnt, const int32_t* nrows_q,
-                          int64_t nrows_q_stride, hipStream_t st) {
+                          int64_t nrows_q_stride, int tiled_qg, hipStream_t st) {
     hipLaunchKernelGGL(narrow_collect_kernel, dim3((nruns + 63) / 64, nq), dim3(256), 0, st, S, lds_elems, M, ldm, nruns, run_rows,
-                       nrows, row0, tau_key, cand, cap, cnt, nrows_q, nrows_q_stride);
+                       nrows, row0, tau_key, cand, cap, cnt, nrows_q, nrows_q_stride, tiled_qg);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }
