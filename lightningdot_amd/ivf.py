@@ -8,8 +8,11 @@ of the index per query — is done here with an inverted file: the rows are clus
 inner-product -> L2 space: x~ = [x, sqrt(phi - |x|^2)], phi = max |x|^2, faiss_indexers.py:114-131), stored SORTED BY LIST in an
 ordinary exact index, and a query is scored exactly (fp32, ``ldot_index_search_lists``) against the rows of the ``nprobe`` lists whose
 centroids are nearest to q~ = [q, 0].  Which lists to probe is itself an exact search over the centroids with the library
-(L2-nearest = largest q~.c~ - |c~|^2 / 2, one more coordinate).  Scores are exact inner products of the rows that were looked at;
-what is approximate is WHICH rows are looked at (recall < 1, like HNSW).  ``nprobe = nlist`` degenerates to the exact search.
+(L2-nearest = largest q~.c~ - |c~|^2 / 2, one more coordinate); coarse search, list scan (a per-query compact column space over the
+probed lists) and selection are ONE library call, ``ldot_ivf_search``.  Scores are exact inner products of the rows that were looked
+at; what is approximate is WHICH rows are looked at (recall < 1, like HNSW).  ``nprobe = nlist`` degenerates to the exact search.
+A batch for which scanning the probed lists would take longer than the exact search (which reuses every index tile across the batch)
+is answered by the exact search (``exact_when_cheaper``, on by default; ``last_route`` tells which ran).
 
 Training (k-means) is build-time host code on the device through torch (plain library GEMMs); everything on the query path is the
 HIP library.
