@@ -21,6 +21,9 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt -o k --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_profiled.json 2> $O/rocprof.err
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
+rm -rf /tmp/kts
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kts -o k --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --workload serving --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_serving_profiled.json 2>> $O/rocprof.err
+cp $(find /tmp/kts -name "*kernel_stats.csv" | head -1) $O/serving_kernel_stats.csv
 cd $GRAFT_REPO_ROOT
 for g in "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES" "TCC_HIT TCC_MISS TCC_REQ" "FETCH_SIZE" "WRITE_SIZE"; do
   bash tools/pmc2.sh "$g" >> $O/pmc.txt 2>&1
