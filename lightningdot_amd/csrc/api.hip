@@ -492,10 +492,6 @@ static int dense_scan_wide(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, i
     return LDOT_OK;
 }
 
-// <= 64 queries against any number of rows (the serving shape): the index is streamed once at HBM speed (score_narrow.hip) and the
-// lists are selected from the run maxima the scan leaves behind (select_narrow.hip) — convert + 4 kernels + re-score, no threshold
-// to learn.  Speculative like the fused scan: a query whose candidate buffer filled up (rows stored in cluster order) is counted in
-// w_over_sum and the caller redoes the search with the streaming selector.
 constexpr int64_t kListsQueryChunk = 256;   // queries per pass of the run-maxima selection (bounds its buffers and flag array)
 
 // buffers of the run-maxima selection (select_narrow.hip) for up to nq queries x ldm runs; M and the counters are kept all-zero
@@ -539,6 +535,11 @@ static bool narrow_select_ok(const ldot_index* ix, int64_t nq, int kp) {
     return nruns >= (kp <= 512 ? 2 : 4) * (int64_t)kp;
 }
 
+// <= 64 queries against any number of rows (the serving shape): the index is streamed once at HBM speed (score_narrow.hip) and the
+// lists are selected from the run maxima the scan leaves behind (select_narrow.hip) — convert + 4 kernels + re-score, no threshold
+// to learn.  Speculative like the fused scan: a query whose candidate buffer filled up (thousands of equal scores in a run of rows) is
+// flagged in device-mapped host memory (h_nover); the caller sees it at its synchronisation point and redoes the search with the
+// streaming selector.
 static int narrow_search(ldot_index* ix, int64_t nq, int kp, hipStream_t st) {
     const int64_t wide = (int64_t)1 << 22;
     const int cap = kNarrowCandCap;
