@@ -481,13 +481,13 @@ def main_s2(args, world, rank, dev, sharded):
             # (all hardware threads oversubscribe torch's intra-op pool on these boxes: take the better of all / half the threads)
             trial = {t: OT.timed(qc, xc, K, t, runs=1)[0] for t in (cores, max(1, cores // 2))}
             threads = min(trial, key=trial.get)
-            dtc, cs, cl = OT.timed(qc, xc, K, threads, runs=3)
+            dtc, cs, cl = OT.timed(qc, xc, K, threads, runs=5)
             gl = (hl[0] if name == 't2i' else hl[1]).numpy()
             cpu[name] = {'seconds': dtc, 'threads': threads, 'rank1_mismatches_vs_gpu': int((gl[:, 0] != cl.numpy()[:, 0]).sum())}
         out['cpu_baseline'] = {'value': 2 * nq / (cpu['t2i']['seconds'] + cpu['i2t']['seconds']), 'unit': 'queries/s',
                                'cores': int(cores), 'kind': 'port',
                                'sample': 'the whole step (both searches), oracle_torch.search_blocked (torch.matmul + torch.topk, '
-                                         'fp32) at the better of all / half the hardware threads, median of 3 runs after warm-up', 'detail': cpu}
+                                         'fp32) at the better of all / half the hardware threads, median of 5 runs after warm-up', 'detail': cpu}
     print(json.dumps(out), flush=True)
     if sharded:
         dist.destroy_process_group()
