@@ -73,6 +73,20 @@ void set_error(const char* fmt, ...);
         }                                                                                            \
     } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and device instead of before every launch: the call costs
+// microseconds of host time, which is on the critical path of the short searches (small indexes, few queries).  `flags` is a
+// function-local static array of the launcher; a race between two threads sets the attribute twice, which is harmless.
+constexpr int kAttrDevices = 64;
+inline hipError_t set_max_dynamic_lds_once(const void* kernel, int bytes, bool* flags) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < kAttrDevices && flags[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && dev >= 0 && dev < kAttrDevices) flags[dev] = true;
+    return e;
+}
+
 #define LDOT_REQUIRE(cond, code, ...)       \
     do {                                    \
         if (!(cond)) {                      \

@@ -146,7 +146,8 @@ int launch_score_dense(const void* q16, int64_t ldq_elems, int64_t nq_pad, const
     using Geo = RingGeom<6>;
     const int tiles_m = (int)((nq_pad + Geo::kBM - 1) / Geo::kBM), tiles_n = (int)(nrows_pad / kRBN);
     const int nunits = tiles_m * tiles_n;
-    LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)score_dense_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Geo::kLds));
+    static bool attr_set[kAttrDevices];
+    LDOT_HIP_CHECK(set_max_dynamic_lds_once((const void*)score_dense_kernel, Geo::kLds, attr_set));
     hipLaunchKernelGGL(score_dense_kernel, dim3(nunits < 256 ? nunits : 256), dim3(kRingThreads), Geo::kLds, st,
                        (const char*)q16, ldq_elems * 2, tiles_m, nq_pad, (const char*)x16, xrow0, tiles_n, dpad / kRBK, S,
                        lds_elems, nq_valid);

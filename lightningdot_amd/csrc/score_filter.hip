@@ -425,7 +425,12 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     if (variant == 2048) rk = score_filter_r6_kernel<2048>;
     if (variant == 2064) rk = score_filter_r6_kernel<2064>;   // 16 + 512: the 4 row streams of an XCD share ONE tile (everything L2-resident)
 #endif
+#ifdef LDOT_ABLATION
     LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<6>::kLds));
+#else
+    static bool attr_set[kAttrDevices];
+    LDOT_HIP_CHECK(set_max_dynamic_lds_once((const void*)rk, RingGeom<6>::kLds, attr_set));
+#endif
     const int qg = fused_query_group(nq_pad);
     const int qg_log2 = qg == 8 ? 3 : qg == 4 ? 2 : qg == 2 ? 1 : 0;
     hipLaunchKernelGGL(rk, dim3(256), dim3(kRingThreads), RingGeom<6>::kLds, st, (const char*)x16, ldx_elems * 2, row0,
