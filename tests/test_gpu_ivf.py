@@ -208,3 +208,36 @@ def test_large_batches_are_answered_by_the_exact_search_when_that_is_cheaper():
     sl, ll = ivf.search_knn_tensors(qb, 10, exact_when_cheaper=False)
     assert ivf.last_route == 'lists'
     assert float((ll[:, 0] == le[:, 0]).float().mean()) > 0.95
+
+
+def test_ivf_search_query_dtypes_and_normalisation():
+    """ldot_ivf_search ingests bf16 / fp16 queries and the opt-in L2 normalisation like the exact search does: the result equals the
+    fp32 call on the rounded (and normalised) queries"""
+    import torch
+    from lightningdot_amd import _lib as L
+    from lightningdot_amd.ivf import DenseIVFFlatIndexer
+    x, rng = _clustered(20000, 64, 80, 21)
+    ivf = DenseIVFFlatIndexer(64, nlist=100, nprobe=12)
+    ivf.index_tensor(list(range(20000)), torch.from_numpy(x))
+    q32 = torch.from_numpy((x[rng.integers(0, 20000, 40)] * 1.7 + 0.2 * rng.standard_normal((40, 64))).astype(np.float32)).cuda()
+    ix = ivf.index
+
+    def call(q, dtype, normalize):
+        s = torch.empty((q.shape[0], 10), dtype=torch.float32, device='cuda')
+        l = torch.empty((q.shape[0], 10), dtype=torch.int64, device='cuda')
+        L.check(ix._lib.ldot_ivf_search(ix._h, ivf.coarse._h, ctypes.c_void_p(q.data_ptr()), q.shape[0], dtype, normalize,
+                                        ctypes.c_void_p(ivf.list_offsets.data_ptr()), int(ivf.max_list_len), 12, 10,
+                                        ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(l.data_ptr()), L.DEVICE,
+                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return s, l
+
+    for dt, code in ((torch.bfloat16, L.BF16), (torch.float16, L.F16)):
+        qh = q32.to(dt).contiguous()
+        s_a, l_a = call(qh, code, 0)
+        s_b, l_b = call(qh.float().contiguous(), L.F32, 0)
+        assert torch.equal(l_a, l_b) and torch.equal(s_a, s_b)
+    s_n, l_n = call(q32, L.F32, 1)
+    qn = torch.nn.functional.normalize(q32.double(), dim=1).float().contiguous()
+    s_m, l_m = call(qn, L.F32, 0)
+    assert torch.equal(l_n, l_m)
+    assert float((s_n - s_m).abs().max()) < 1e-5
