@@ -60,6 +60,9 @@ def main():
     ap.add_argument('--split-bf16', action='store_true',
                     help='LDOT_OPT_PRECISION=1: split-bf16 candidate pass (3 MFMA products per element); not the headline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-events', action='store_true',
+                    help='measurement aid: do not bracket the score kernels with HIP events (the roofline object is then empty); '
+                         'shows what the events themselves cost the timed region')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to exercise the N > 1 '
                                                       'bookkeeping on a one-GPU box together with --all-on-device0)')
     ap.add_argument('--all-on-device0', action='store_true', help='debug: every rank uses cuda:0')
@@ -130,7 +133,7 @@ def main():
     if not sharded:
         ix = DenseFlatIndexer(D)
         ix.index.set_option(L.OPT_MODE, mode)
-        ix.index.set_option(L.OPT_PROFILE, 1)
+        ix.index.set_option(L.OPT_PROFILE, 0 if args.no_kernel_events else 1)
         if args.split_bf16:
             ix.index.set_option(L.OPT_PRECISION, 1)
         if args.growth:
@@ -240,6 +243,8 @@ def main():
                      'kernel_ms_per_step': prof['kernel_ms'] / max(args.steps, 1),
                      'flops_per_step': prof['flops'] / max(args.steps, 1)},
     }
+    if args.no_kernel_events:
+        out['roofline']['note'] = 'kernel events disabled (--no-kernel-events): no kernel timing in this run'
     # measured-offline HBM traffic of the dominant kernel (rocprofv3 PMC passes, tools/pmc.sh; see profiles/)
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.exists(tpath) and world == 1 and N == 1_000_000 and Q == 10_000 and D == 768:
