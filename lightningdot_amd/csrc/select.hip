@@ -387,6 +387,119 @@ __global__ __launch_bounds__(64 * QPW) void select_dense_wave_kernel(const float
     sel.finish(ls, li, tau ? tau + q : nullptr);
 }
 
+// wave-wide integer sum in 7 DPP adds + one readlane (quad swaps, row mirrors, row broadcasts: the total lands in lane 63): pure VALU —
+// counting with ballots costs scalar-unit issue slots, which the waves of a CU share, and a bpermute-based __shfl_xor reduction ~600 cycles
+__device__ __forceinline__ int wave_sum_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);   // row_mirror  -> every lane: its row's sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// dense source, rows of at most 64 * 8 * NRUN columns (4096 / 5120: the warm-up chunk of the fused scan, Flickr / COCO sized indexes):
+// the whole row sits in the wave's registers as NRUN runs of 8 CONSECUTIVE columns per lane, so every lane knows the maxima of its
+// runs without any cross-lane work.  The k'-th largest RUN MAXIMUM is a lower bound of the k'-th best score (each maximum is a score),
+// found by a bit search over NRUN keys per lane; only the ~1.1 k' scores at or above it are pushed to the selector.  The streaming
+// variant below pushes and compacts its way through every column while it learns the threshold: 164 us for 10 000 x 4096 (the fused
+// scan's warm-up), 104 us for 5000 x 5000; this kernel 68 / 50 us.
+template <int NRUN, int QPW>
+__global__ __launch_bounds__(64 * QPW) void select_dense_runs_kernel(const float* __restrict__ S, int64_t lds_elems, int64_t nq,
+                                                                     int ncols, int64_t idx_base, float* __restrict__ list_s,
+                                                                     int32_t* __restrict__ list_i, int kp, int cap,
+                                                                     float* __restrict__ tau) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
+    const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * QPW + wq;
+    if (q >= nq) return;
+    const float* row = S + q * lds_elems;
+    float v[NRUN][8];
+    uint32_t mk[NRUN];   // descending keys of the run maxima (all ones: no valid column in the run)
+#pragma unroll
+    for (int j = 0; j < NRUN; ++j) {
+        const int c = (j * 64 + lane) * 8;
+        // (rows are 16-B aligned and padded to a multiple of 256 columns by the callers: whole runs can be read; columns past ncols
+        // are masked below)
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (c < ncols) {
+            a = *(const f32x4*)(row + c);
+            b = *(const f32x4*)(row + c + 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[j][e] = a[e];
+            v[j][4 + e] = b[e];
+        }
+    }
+    WaveSelector sel;
+    sel.init(keys + (size_t)wq * cap, kp, cap);
+    float* ls = list_s + q * kp;
+    int32_t* li = list_i + q * kp;
+    sel.load_list(ls, li);
+    int nvalid = 0;
+#pragma unroll
+    for (int j = 0; j < NRUN; ++j) {
+        const int c = (j * 64 + lane) * 8;
+        // (float maxima, ONE key per run; columns past ncols do not count; a NaN score never becomes a candidate on this path)
+        float m = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m = fmaxf(m, c + e < ncols ? v[j][e] : -INFINITY);
+        mk[j] = c < ncols ? desc_key(m) : 0xffffffffu;
+        nvalid += c < ncols ? 1 : 0;
+    }
+    nvalid = wave_sum_dpp(nvalid);
+    // smallest key t with #(run maxima <= t) >= kp; 20 bits, the rest left set (a slightly lower threshold).  Fewer than kp runs:
+    // everything is a candidate.
+    uint32_t th = 0xffffffffu;
+    if (nvalid >= kp) {
+        th = 0;
+        for (int b = 31; b >= 12; --b) {
+            const uint32_t trial = th | ((1u << b) - 1u);
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < NRUN; ++j) cnt += mk[j] <= trial ? 1 : 0;
+            if (wave_sum_dpp(cnt) < kp) th |= 1u << b;
+        }
+        th |= (1u << 12) - 1u;
+    }
+    // the threshold as a score: `s >= th_f` admits exactly the scores whose key is <= th, plus the other zero of a signed-zero threshold
+    // (a superset is fine: the selector orders by key)
+    float th_f = th == 0xffffffffu ? -INFINITY : desc_key_to_float(th);
+    if (th_f != th_f) th_f = -INFINITY;   // (the 12 set low bits turn a -inf threshold into a NaN pattern)
+    // how many scores are at or above the threshold?  (~1.1 k' on ordinary rows; thousands when scores tie at the threshold)
+    int total = 0;
+#pragma unroll
+    for (int j = 0; j < NRUN; ++j) {
+        const int c = (j * 64 + lane) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) total += c + e < ncols && v[j][e] >= th_f ? 1 : 0;
+    }
+    total = wave_sum_dpp(total);
+    if (sel.n + total <= sel.cap) {
+        // the ordinary case: everything fits the key buffer, no compaction inside the (fully unrolled) loop
+#pragma unroll
+        for (int j = 0; j < NRUN; ++j) {
+            if (__ballot(mk[j] <= th)) {   // (wave-uniform)
+                const int c = (j * 64 + lane) * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    sel.push(make_key(v[j][e], (uint32_t)(idx_base + c + e)), c + e < ncols && v[j][e] >= th_f);
+            }
+        }
+    } else {
+        // ties by the thousand: stream the row again through the compacting selector (one compaction site, rolled loop)
+        for (int c0 = 0; c0 < ncols; c0 += 64) {
+            const int c = c0 + lane;
+            const float sc = c < ncols ? row[c] : 0.f;
+            sel.reserve(64);
+            sel.push(make_key(sc, (uint32_t)(idx_base + c)), c < ncols && sc >= th_f);
+        }
+    }
+    sel.finish(ls, li, tau ? tau + q : nullptr);
+}
+
 // dense source, SHORT rows (ncols <= 64 * NV, k' <= 256): the whole row of scores sits in the wave's registers (NV per lane)
 // together with the running list (4 per lane) and the k'-th best key is found by a bitwise binary search whose counts are pure VALU work
 // (per-lane compare-and-count over the registers, one DPP wave reduction per bit) — no ballots, no LDS, no scalar-unit traffic.  Used for
@@ -1046,6 +1159,18 @@ int launch_select_dense(const float* S, int64_t lds_elems, int64_t nq, int64_t n
         constexpr int QPW = 4;
         hipLaunchKernelGGL((select_dense_regs_kernel<16, QPW>), dim3((unsigned)((nq + QPW - 1) / QPW)), dim3(64 * QPW), 0, st, S,
                            lds_elems, nq, (int)ncols, idx_base, list_s, list_i, kp, tau);
+        LDOT_HIP_CHECK(hipGetLastError());
+        return LDOT_OK;
+    }
+    if (kp + 256 <= WaveSelector::kRegKeys * 64 && nq > 64 && ncols <= 64 * 8 * 10) {   // whole row in registers, run-maxima threshold
+        constexpr int QPW = 4;
+        const int wcap = WaveSelector::kRegKeys * 64;
+        if (ncols <= 64 * 8 * 8)
+            hipLaunchKernelGGL((select_dense_runs_kernel<8, QPW>), dim3((unsigned)((nq + QPW - 1) / QPW)), dim3(64 * QPW),
+                               (size_t)wcap * 8 * QPW, st, S, lds_elems, nq, (int)ncols, idx_base, list_s, list_i, kp, wcap, tau);
+        else
+            hipLaunchKernelGGL((select_dense_runs_kernel<10, QPW>), dim3((unsigned)((nq + QPW - 1) / QPW)), dim3(64 * QPW),
+                               (size_t)wcap * 8 * QPW, st, S, lds_elems, nq, (int)ncols, idx_base, list_s, list_i, kp, wcap, tau);
         LDOT_HIP_CHECK(hipGetLastError());
         return LDOT_OK;
     }
