@@ -9,7 +9,7 @@
 //
 // 1. narrow_tau_kernel      one workgroup per query: exact k'-th largest of the run maxima (bit search on the order-preserving keys,
 //                           values in registers, one barrier per bit).  A COARSER run gives a lower threshold, yet hardly more
-//                           candidates (1M unordered rows, k' = 200: 205 candidates from 256-row runs, 218 from 1024-row runs), so
+//                           candidates (1M unordered rows, k' = 128: ~135 candidates from 512-row runs), so
 //                           runs are sized for <= 2048 maxima per query (8 per thread of a 256-thread workgroup) unless k' is large
 // 2. narrow_collect_kernel  visits only the runs with maximum >= tau (~k' of them) and appends their rows with score >= tau to the
 //                           query's candidate buffer (for unordered rows ~1.01 k' candidates; rows stored in cluster order give more —
