@@ -128,6 +128,10 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     RingCtx c;
     ring_ctx_init(c);
+#ifdef LDOT_ABLATION
+    if ((VAR & 16384) && c.wave >= 4) __builtin_amdgcn_s_setprio(1);   // static priority for the later-dispatched half (guide: +0..1 %)
+    if ((VAR & 32768) && c.wave < 4) __builtin_amdgcn_s_setprio(1);
+#endif
     const int qg = 1 << qg_log2;                       // query blocks in flight per XCD
     const int nstream = 32 >> qg_log2;                 // row streams per XCD
     const int nslices = 8 * nstream;                   // row slices of the launch
@@ -420,6 +424,8 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     if (variant == 528) rk = score_filter_r6_kernel<528>;
     if (variant == 4096) rk = score_filter_r6_kernel<4096>;
     if (variant == 4112) rk = score_filter_r6_kernel<4112>;
+    if (variant == 16384) rk = score_filter_r6_kernel<16384>;
+    if (variant == 32768) rk = score_filter_r6_kernel<32768>;
     if (variant == 8192) rk = score_filter_r6_kernel<8192>;
     if (variant == 8208) rk = score_filter_r6_kernel<8208>;
     if (variant == 2048) rk = score_filter_r6_kernel<2048>;
