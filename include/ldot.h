@@ -51,7 +51,10 @@ extern "C" {
 #define LDOT_PAD_SCORE (-3.402823466e+38f)
 
 /* search-mode flags (ldot_index_set_option(LDOT_OPT_MODE, ...)) */
-#define LDOT_MODE_AUTO 0   /* dense below 32768 rows, fused filter above */
+#define LDOT_MODE_AUTO 0   /* chosen per search from the batch and index size: <= 64 queries the narrow search (one pass over the
+                            * bf16 index at HBM speed + run-maxima selection; <= 16 queries always, 17..64 when k' fits its candidate
+                            * buffer); otherwise the fused filter from 32768 rows (from 16384 rows for >= 16384 queries), with one query
+                            * block for 65..256 queries; the dense path below that */
 #define LDOT_MODE_DENSE 1  /* materialise score chunks + streaming top-k' select */
 #define LDOT_MODE_FUSED 2  /* fused MFMA score + threshold filter (never materialises Q x N) */
 
@@ -67,8 +70,12 @@ extern "C" {
                                  * MFMA products per element: ~16 mantissa bits, 3x the MFMA work and 3x the shadow) for
                                  * data whose scores crowd closer than bf16 resolves; reported scores are fp32-exact in both */
 
-#define LDOT_OPT_VERIFY 10      /* 1: after every search flag the queries whose top-k is not PROVEN exact (k-th exact score above the
-                                 * candidate threshold by a bf16 error bound), see ldot_index_last_unproven.  The default bf16
+#define LDOT_OPT_VERIFY 10      /* 1: after every search flag the queries whose top-k cannot be vouched for: the k-th exact score is not above
+                                 * the candidate threshold by E = 4 * 2^-8 * |q| * max|x| / sqrt(d), a STATISTICAL bound of the bf16
+                                 * rounding error of a d-term inner product (4 standard deviations for independent rounding errors;
+                                 * the worst case, 2^-8 * |q| * max|x|, is sqrt(d)/4 times larger and can be reached by sparse or
+                                 * concentrated vectors, for which an unflagged query is not a proof), see ldot_index_last_unproven.
+                                 * The default bf16
                                  * candidate pass is exact whenever the true top-k lies inside the bf16 top-k' (k' = k + margin);
                                  * scores that crowd closer than bf16 resolves need a larger LDOT_OPT_MARGIN or LDOT_OPT_PRECISION 1 */
 

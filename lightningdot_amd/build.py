@@ -27,17 +27,13 @@ def _stale(target, deps):
 
 def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> str:
     """ablation=True (or `--ablation`): compile the profiling variants of the kernels and their LDOT_DEBUG_* environment hooks
-    (-DLDOT_ABLATION) — a measurement build; the product library has no such hooks.  The two builds use separate object
-    directories and the ablation build always relinks, so a product build after it restores the product library."""
+    (-DLDOT_ABLATION) into a SEPARATE library, libldot_ablation.so (selected with LDOT_LIBRARY=...); the product library has no
+    such hooks and is never touched by an ablation build."""
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     objs = []
     bdir = os.path.join(PKG, 'build_ablation' if ablation else 'build')
     flags = FLAGS + (['-DLDOT_ABLATION'] if ablation else [])
-    marker = os.path.join(PKG, 'build', '.ablation_linked')
-    if ablation or os.path.exists(marker):
-        force_link = True
-    else:
-        force_link = False
+    lib = os.path.join(PKG, 'libldot_ablation.so') if ablation else LIB
     os.makedirs(bdir, exist_ok=True)
     procs = []
     for s in SOURCES:
@@ -59,21 +55,16 @@ def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> 
             sys.stderr.write(f'hipcc failed on {s}\n' + (out.decode(errors='replace') if not verbose else ''))
     if failed:
         raise RuntimeError('libldot.so build failed')
-    if force or force_link or _stale(LIB, objs):
-        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    if force or _stale(lib, objs):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
-    os.makedirs(os.path.dirname(marker), exist_ok=True)
-    if ablation:
-        open(marker, 'w').write('libldot.so currently holds the ablation build\n')
-    elif os.path.exists(marker):
-        os.remove(marker)
     # a device-side compile error can leave host stubs without their kernels: refuse a library that does not load.
     # (checked in a child process: loading it here would map the system HIP runtime before torch maps its own)
     subprocess.check_call([sys.executable, '-c',
-                           'import ctypes, os, sys; ctypes.CDLL(sys.argv[1], mode=os.RTLD_NOW | os.RTLD_LOCAL)', LIB])
-    return LIB
+                           'import ctypes, os, sys; ctypes.CDLL(sys.argv[1], mode=os.RTLD_NOW | os.RTLD_LOCAL)', lib])
+    return lib
 
 
 def build_tools(verbose: bool = True) -> str:
@@ -91,7 +82,6 @@ def build_tools(verbose: bool = True) -> str:
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv, ablation='--ablation' in sys.argv)
+    print(build(force='--force' in sys.argv, ablation='--ablation' in sys.argv))
     if '--tools' in sys.argv:
         print(build_tools())
-    print(LIB)

@@ -1161,14 +1161,27 @@ int ldot_merge_topk(const float* scores, const int64_t* labels, int nparts, int6
         return launch_select_lists(scores, labels, nq * k_in, nparts, k_in, nq, k_out, out_scores, out_labels, st);
     LDOT_REQUIRE(mem == LDOT_HOST, LDOT_EINVAL, "bad mem");
     const size_t n_in = (size_t)nparts * nq * k_in, n_out = (size_t)nq * k_out;
-    // host-side callers: a grow-only per-thread device workspace (released when the thread exits), no hipMalloc/hipFree per call
+    // host-side callers: a grow-only per-thread device workspace (released when the thread exits), no hipMalloc/hipFree per call.
+    // The buffers belong to the device they were allocated on: a thread that merges on another device afterwards gets fresh ones
+    // (device memory of GPU 0 handed to a kernel on GPU 1's stream would fault, or crawl through peer access).
     struct Ws {
         DevBuf b[4];
-        ~Ws() {
+        int device = -1;
+        void release_all() {
+            if (device < 0) return;
+            DeviceGuard g(device);
             for (DevBuf& x : b) x.release();
+            device = -1;
         }
+        ~Ws() { release_all(); }
     };
     static thread_local Ws ws;
+    int cur_dev = 0;
+    LDOT_HIP_CHECK(hipGetDevice(&cur_dev));
+    if (ws.device != cur_dev) {
+        ws.release_all();
+        ws.device = cur_dev;
+    }
     int rc = LDOT_OK;
     if ((rc = ws.b[0].ensure(n_in * 4)) || (rc = ws.b[1].ensure(n_in * 8)) || (rc = ws.b[2].ensure(n_out * 4)) ||
         (rc = ws.b[3].ensure(n_out * 8)))

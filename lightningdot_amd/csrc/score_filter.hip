@@ -213,6 +213,9 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
             if (mr == MR - 1 && !defer_burst) issue();
             return;
         }
+        // (a deferred slab is issued whole by the MODE 2 slab, after its filter blocks — round 2 issued these three pieces as well
+        // AND the whole slab there: one slab too many per tile, which is what made this variant slower than the burst)
+        if (defer_burst) return;
         if (mr & 1) piece(mr >> 1);
     };
     auto hook_pre = [&](int mr) {
@@ -229,6 +232,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
             return;
         }
         if (!(VAR & 128)) return;
+        if (defer_burst_b && !(VAR & 256)) return;   // MODE 2 with deferral: the whole slab follows the filter blocks
         if (mr == 1) piece(3);
         if (mr == 3) {
             piece(4);
@@ -421,6 +425,8 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     if (variant == 128) rk = score_filter_r6_kernel<128>;
     if (variant == 144) rk = score_filter_r6_kernel<144>;
     if (variant == 256) rk = score_filter_r6_kernel<256>;
+    if (variant == 384) rk = score_filter_r6_kernel<384>;   // spread loads, no deferral
+    if (variant == 400) rk = score_filter_r6_kernel<400>;
     if (variant == 528) rk = score_filter_r6_kernel<528>;
     if (variant == 4096) rk = score_filter_r6_kernel<4096>;
     if (variant == 4112) rk = score_filter_r6_kernel<4112>;

@@ -5,8 +5,9 @@
 
 Same arguments, same return tuple ``(loss, correct_ratio, (indexer_img, indexer_txt), (recall_txt, recall_img),
 (rank_txt_res, rank_img_res))`` and the same quirks: image queries are NOT de-duplicated before the
-search (:138-139), index sides are de-duplicated by dict key with last-write-wins (:151-152), denominators are the
-numbers of unique query ids (:179,188), ``recall_txt`` is text-query -> image retrieval (:190).
+search (:138-139) but only the result of an id's last occurrence survives in the rank dicts (:168,171) — so only that
+occurrence is searched here —, index sides are de-duplicated by dict key with last-write-wins (:151-152), denominators are
+the numbers of unique query ids (:179,188), ``recall_txt`` is text-query -> image retrieval (:190).
 
 What changed underneath: embeddings never leave the device (the per-vector ``.detach().cpu().numpy()`` of
 :135,138,151-152 is gone), both indexes are built from device tensors and searched by the fused HIP path, the searches return
@@ -32,20 +33,21 @@ def _dedup_last(ids):
 
 class RankDict(Mapping):
     """The reference's ``rank_*_res`` dict ({query id: [db ids of its top results]}, dvl/trainer.py:168,171) over a device label
-    tensor: key order = first occurrence of a query id, value = the result row of its LAST occurrence (dict-comprehension
-    semantics).  Id lists are materialised per key on access; ``labels`` / ``rows_of`` give the tensor view for device-side
-    consumers (recall above, hard-negative mining in hn.py)."""
+    tensor with ONE row per distinct query id: key order = first occurrence of a query id, value = the result of its LAST
+    occurrence (dict-comprehension semantics) — which is why only the last occurrence of every id is searched at all (the
+    reference searches the image vector of every (caption, image) pair, 5 identical searches per image at :138-139,170, and then
+    keeps one).  Id lists are materialised per key on access; ``labels`` / ``last_rows`` give the tensor view for device-side
+    consumers (recall below, hard-negative mining in hn.py)."""
 
-    def __init__(self, query_ids, labels: torch.Tensor, db_ids: list):
-        self._pos = {}
-        for i, q in enumerate(query_ids):
-            self._pos[q] = i
-        self.labels = labels                 # [nq, k] int64 row labels on the device (-1 = padding)
+    def __init__(self, keys, labels: torch.Tensor, db_ids: list):
+        self._pos = {q: i for i, q in enumerate(keys)}
+        assert len(self._pos) == labels.shape[0], 'one result row per distinct query id'
+        self.labels = labels                 # [n distinct ids, k] int64 row labels on the device (-1 = padding)
         self.db_ids = db_ids
         self._host = None
 
     def last_rows(self, query_ids):
-        """result row (= position of the last occurrence) of every id in ``query_ids``"""
+        """result row of every id in ``query_ids`` (the result of the id's last occurrence in the query stream)"""
         return [self._pos[q] for q in query_ids]
 
     def _host_labels(self):
@@ -123,18 +125,23 @@ def eval_model_on_dataloader(bi_encoder, eval_dataloader, args, img2txt: Optiona
     img_keys, img_last = _dedup_last(query_img_id)
     txt_keys, txt_last = _dedup_last(query_txt_id)
     dev = query_txt_t.device
-    indexer_img.index_tensor(img_keys, query_img_t[torch.as_tensor(img_last, device=dev)])
-    indexer_txt.index_tensor(txt_keys, query_txt_t[torch.as_tensor(txt_last, device=dev)])
+    img_vecs = query_img_t[torch.as_tensor(img_last, device=dev)]      # one row per distinct id (its last occurrence)
+    txt_vecs = query_txt_t[torch.as_tensor(txt_last, device=dev)]
+    indexer_img.index_tensor(img_keys, img_vecs)
+    indexer_txt.index_tensor(txt_keys, txt_vecs)
 
     if no_eval:
         return total_loss, correct_ratio, (indexer_img, indexer_txt), (None, None), (None, None)
 
     # Both searches stay on the device (scores / row labels [nq, num_tops]); the reference's per-result Python objects (:167-170:
     # nq x num_tops ids per direction) are built lazily, only for the ids a caller actually indexes (RankDict).
-    _, lab_txt = indexer_img.search_knn_tensors(query_txt_t, num_tops)     # text query -> image rows
-    _, lab_img = indexer_txt.search_knn_tensors(query_img_t, num_tops)     # image query -> text rows
-    rank_txt_res = RankDict(query_txt_id, lab_txt, indexer_img.index_id_to_db_id)
-    rank_img_res = RankDict(query_img_id, lab_img, indexer_txt.index_id_to_db_id)
+    # Only the LAST occurrence of every query id is searched: the reference's dict comprehensions (:168,171) keep exactly that
+    # result, so its 5x duplicated image queries (:138-139) cost 5x the work for the same rank dict.  The de-duplicated query
+    # rows are the rows just indexed on the other side (same id stream, same last-write-wins rule).
+    _, lab_txt = indexer_img.search_knn_tensors(txt_vecs, num_tops)     # text query -> image rows
+    _, lab_img = indexer_txt.search_knn_tensors(img_vecs, num_tops)     # image query -> text rows
+    rank_txt_res = RankDict(txt_keys, lab_txt, indexer_img.index_id_to_db_id)
+    rank_img_res = RankDict(img_keys, lab_img, indexer_txt.index_id_to_db_id)
 
     # Recall@{1,5,10} (:173-188) as device reductions over the label tensors.  A result list belongs to a query ID (dict
     # semantics, last occurrence wins); ids are unique per index, so "id in list[:top]" is "row label in labels[:, :top]"; a padding

@@ -76,6 +76,7 @@ class FlatIPIndex:
             self._h = h
         self.d = int(self._lib.ldot_index_dim(self._h))
         self._pending = None
+        self._opts = {}        # what the caller set through set_option (search(verify=True) restores them afterwards)
         try:
             import torch
             self.device = torch.cuda.current_device() if torch.cuda.is_available() else None   # where the library created it
@@ -96,6 +97,7 @@ class FlatIPIndex:
 
     def set_option(self, option: int, value: int):
         L.check(self._lib.ldot_index_set_option(self._h, int(option), int(value)))
+        self._opts[int(option)] = int(value)
 
     def reset(self):
         L.check(self._lib.ldot_index_reset(self._h))
@@ -112,12 +114,15 @@ class FlatIPIndex:
         """faiss-style: (scores [nq, k] float32, labels [nq, k] int64) as numpy arrays.
 
         ``verify=True``: the bf16 candidate pass is exact whenever the true top-k lies inside the bf16 top-k' (k' = k + margin).
-        With verification the library flags every query for which that is not PROVEN (LDOT_OPT_VERIFY: k-th exact score above the
-        candidate threshold by a bf16 error bound) and the flagged queries are searched again with a 4x larger margin, repeatedly,
-        up to the library's maximum; ``last_unproven`` then holds the number of queries that still could not be proven."""
+        With verification the library flags every query whose k-th exact score is not above the candidate threshold by a
+        statistical bf16 error bound (LDOT_OPT_VERIFY, see ldot.h: 4 sigma of independent rounding errors, not the worst case) and
+        the flagged queries are searched again with a 4x larger margin than the one in force, repeatedly, up to the library's
+        maximum; ``last_unproven`` then holds the number of queries that are still flagged.  Margin and verify settings made
+        through ``set_option`` are in force again when the call returns."""
         keep, ptr, nq, dt, mem = _describe(queries, self.d, self.device)
         scores = np.empty((nq, k), dtype=np.float32)
         labels = np.empty((nq, k), dtype=np.int64)
+        user_verify, user_margin = self._opts.get(L.OPT_VERIFY, 0), self._opts.get(L.OPT_MARGIN, -1)
         if verify:
             self.set_option(L.OPT_VERIFY, 1)
         try:
@@ -125,11 +130,11 @@ class FlatIPIndex:
                                                 ctypes.c_void_p(scores.ctypes.data), ctypes.c_void_p(labels.ctypes.data),
                                                 L.HOST, _stream_ptr(self.device)))
             if verify and nq:
-                self._escalate(keep, k, scores, labels)
+                self._escalate(keep, k, scores, labels, user_margin)
         finally:
             if verify:
-                self.set_option(L.OPT_VERIFY, 0)
-                self.set_option(L.OPT_MARGIN, -1)
+                self.set_option(L.OPT_VERIFY, user_verify)
+                self.set_option(L.OPT_MARGIN, user_margin)
         del keep
         return scores, labels
 
@@ -140,10 +145,10 @@ class FlatIPIndex:
         L.check(self._lib.ldot_index_last_unproven(self._h, ctypes.c_void_p(flags.ctypes.data), ctypes.byref(cnt)))
         return flags, int(cnt.value)
 
-    def _escalate(self, queries, k, scores, labels):
+    def _escalate(self, queries, k, scores, labels, user_margin=-1):
         flags, cnt = self.unproven(scores.shape[0])
         todo = np.nonzero(flags)[0]
-        margin = max(28, k // 4)
+        margin = max(28, k // 4) if user_margin < 0 else user_margin      # the margin the first search ran with
         self.last_escalations = []
         while len(todo) and margin < L.MAX_MARGIN:
             margin = min(4 * margin, L.MAX_MARGIN)
@@ -264,6 +269,12 @@ class DenseIndexer(object):
         raise NotImplementedError
 
     def search_knn(self, query_vectors: np.array, top_docs: int) -> List[Tuple[List[object], List[float]]]:
+        raise NotImplementedError
+
+    def search_knn_tensors(self, query_vectors, top_docs: int):
+        """Device-tensor variant of ``search_knn`` (what the harness, the mining and the serving path call): -> (scores [nq, k],
+        row labels [nq, k] int64, -1 = padding) as CUDA tensors, scores with the semantics of the class's ``search_knn``; labels
+        index ``index_id_to_db_id``."""
         raise NotImplementedError
 
     def serialize(self, file: str):
@@ -406,32 +417,48 @@ class DenseHNSWFlatIndexer(DenseIndexer):
         self._update_id_mapping(list(db_ids))
         self.index.add(vectors)
 
-    def _to_l2(self, q_sqnorm, ip, labels):
-        dist = q_sqnorm[:, None] + np.float32(self._phi_value) - 2.0 * ip
-        return np.where(labels >= 0, dist, np.float32(3.4028234663852886e38)).astype(np.float32)   # faiss pads with FLT_MAX
+    def search_knn_tensors(self, query_vectors, top_docs: int):
+        """(squared L2 distances of the augmented vectors [nq, k] ascending, row labels [nq, k]) as CUDA tensors: the neighbours
+        of ``search_knn`` without the per-result Python objects.  Padding: label -1, distance FLT_MAX (what faiss pads with)."""
+        import torch
+        if _is_tensor(query_vectors):
+            qt = query_vectors.detach()
+        else:
+            qt = torch.from_numpy(np.ascontiguousarray(query_vectors, dtype=np.float32))
+        if qt.dim() == 1:
+            qt = qt[None]
+        if not qt.is_cuda:
+            qt = qt.cuda(self.index.device)
+        if self._ivf is not None:
+            ip, labels = self._ivf.search_knn_tensors(qt, top_docs)
+        else:
+            ip, labels = self.index.search_tensors(qt, top_docs)
+        qn = (qt.float() ** 2).sum(dim=1)                                  # fp32 like the reference's numpy arithmetic
+        dist = qn[:, None] + torch.tensor(self._phi_value, dtype=torch.float32, device=ip.device) - 2.0 * ip
+        dist = torch.where(labels >= 0, dist, dist.new_full((), 3.4028234663852886e38))
+        return dist, labels
 
     def search_knn(self, query_vectors: np.array, top_docs: int) -> List[Tuple[List[object], List[float]]]:
-        if self._ivf is not None:
-            import torch
-            qt = query_vectors if _is_tensor(query_vectors) else torch.from_numpy(np.asarray(query_vectors, dtype=np.float32))
-            ip, indexes = self._ivf.search_knn_tensors(qt, top_docs)
-            qn = (qt.float() ** 2).sum(dim=1).cpu().numpy()
-            ip, indexes = ip.cpu().numpy(), indexes.cpu().numpy()
-        elif _is_tensor(query_vectors):
-            ip, indexes = self.index.search_tensors(query_vectors, top_docs)
-            qn = (query_vectors.float() ** 2).sum(dim=1).cpu().numpy()
-            ip, indexes = ip.cpu().numpy(), indexes.cpu().numpy()
-        else:
-            q = np.asarray(query_vectors, dtype=np.float32)
-            ip, indexes = self.index.search(q, top_docs)
-            qn = (q ** 2).sum(axis=1)
-        scores = self._to_l2(qn.astype(np.float32), ip, indexes)
+        dist, labels = self.search_knn_tensors(query_vectors, top_docs)
+        scores, indexes = dist.cpu().numpy(), labels.cpu().numpy()
         ids = self.index_id_to_db_id
         db_ids = [[ids[i] for i in query_top_idxs] for query_top_idxs in indexes.tolist()]
         return [(db_ids[i], scores[i]) for i in range(len(db_ids))]
 
+    def serialize(self, file: str):
+        """Exact-backed: the reference's two files.  ``approximate=True``: the inverted file's own two files (rows sorted by list +
+        a meta file that also carries the list offsets, the centroids, phi and nprobe — without them the rows are useless)."""
+        if self._ivf is not None:
+            return self._ivf.serialize(file)
+        return super(DenseHNSWFlatIndexer, self).serialize(file)
+
     def deserialize_from(self, file: str):
-        super(DenseHNSWFlatIndexer, self).deserialize_from(file)
+        if self._ivf is not None:
+            self._ivf.deserialize_from(file)
+            self.index = self._ivf.index
+            self.index_id_to_db_id = self._ivf.index_id_to_db_id
+        else:
+            super(DenseHNSWFlatIndexer, self).deserialize_from(file)
         # to trigger the error on subsequent indexing (:152-154)
         self.phi = 1
         phi = 0.0

@@ -54,6 +54,33 @@ def default_train_loader(train_dataset, args, epoch: int, device):
         yield batch_to_device(itm_fast_collate([train_dataset[i] for i in mine]), device)
 
 
+def _default_steps_per_epoch(train_dataset, args) -> int:
+    import torch.distributed as dist
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    return len(train_dataset) // (int(args.train_batch_size) * world)
+
+
+default_train_loader.steps_per_epoch = _default_steps_per_epoch
+
+
+class EvalLoader:
+    """Re-iterable evaluation-style loader (dvl/trainer.py:29-41 without the worker processes): consecutive items, collated and moved
+    to the device ONE batch at a time — the towers consume a batch before the next one is read, so a pass over the Flickr / COCO
+    training sets for hard-negative mining never holds more than one batch of region features."""
+
+    def __init__(self, dataset, batch_size: int, device):
+        self.dataset, self.batch_size, self.device = dataset, int(batch_size), device
+
+    def __len__(self):
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        from .data import batch_to_device, itm_fast_collate
+        ds, bs = self.dataset, self.batch_size
+        for b0 in range(0, len(ds), bs):
+            yield batch_to_device(itm_fast_collate([ds[i] for i in range(b0, min(b0 + bs, len(ds)))]), self.device)
+
+
 def TRAIN(args, bi_encoder, train_dataset, val_dataloader, val_img2txt: Dict, *, train_img2txt: Optional[Dict] = None,
           train_txt2img: Optional[Dict] = None, mining_loaders: Optional[Callable[[], Iterable]] = None,
           make_train_loader: Optional[Callable] = None, kd_teacher: Optional[Callable] = None, loss_fn: Optional[Callable] = None,
@@ -81,7 +108,11 @@ def TRAIN(args, bi_encoder, train_dataset, val_dataloader, val_img2txt: Dict, *,
 
     optimizer = get_optimizer(bi_encoder, args.learning_rate)
     broadcast_parameters(bi_encoder)                                        # C2: every rank starts from rank 0's weights
-    steps_per_epoch = sum(1 for _ in make_train_loader(train_dataset, args, 0, torch.device('cpu')))
+    # (counted, not iterated: a dry pass over the loader would read and collate every item and image feature once more)
+    if hasattr(make_train_loader, 'steps_per_epoch'):
+        steps_per_epoch = int(make_train_loader.steps_per_epoch(train_dataset, args))
+    else:
+        steps_per_epoch = sum(1 for _ in make_train_loader(train_dataset, args, 0, torch.device('cpu')))
     updates_per_epoch = steps_per_epoch // gas
     total_updates = updates_per_epoch * int(args.num_train_epochs)
     scheduler = get_schedule_linear(optimizer, int(0.1 * total_updates), total_updates)     # :172-175
@@ -176,7 +207,7 @@ def main(argv=None):
     the train / val text and image DBs named in the config are read with lightningdot_amd.data (converted FlatDb containers)."""
     import sys
     import torch.distributed as dist
-    from .data import DetectFeatDb, ItmFastDataset, TxtTokDb, batch_to_device, itm_fast_collate
+    from .data import DetectFeatDb, ItmFastDataset, TxtTokDb
     from .options import build_parser, parse_with_config
     from .synthetic import SyntheticItmDataset
     from .towers import BiEncoder, load_biencoder_checkpoint
@@ -203,8 +234,7 @@ def main(argv=None):
     bi_encoder.to(args.device)
 
     def eval_loader(ds):
-        return [batch_to_device(itm_fast_collate([ds[i] for i in range(b0, min(b0 + args.valid_batch_size, len(ds)))]), args.device)
-                for b0 in range(0, len(ds), args.valid_batch_size)]
+        return EvalLoader(ds, args.valid_batch_size, args.device)
 
     if syn:
         train_ds = SyntheticItmDataset(syn, num_hard_negatives=args.num_hard_negatives, seed=args.seed)
@@ -222,11 +252,15 @@ def main(argv=None):
 
     def mining_loaders():
         # evaluation-style items (no negatives appended) over the training set (dvl/hn.py:46-50), then the epoch's bindings back
-        saved = (train_ds.neg_imgs, train_ds.neg_txts)
-        train_ds.new_epoch()
-        loader = eval_loader(train_ds)
-        train_ds.neg_imgs, train_ds.neg_txts = saved
-        return [loader]
+        # (the loader is lazy: the evaluation-style bindings must be in force WHILE it is consumed, the epoch's afterwards)
+        def loader():
+            saved = (train_ds.neg_imgs, train_ds.neg_txts)
+            train_ds.new_epoch()
+            try:
+                yield from eval_loader(train_ds)
+            finally:
+                train_ds.neg_imgs, train_ds.neg_txts = saved
+        return [loader()]
 
     hist = TRAIN(args, bi_encoder, train_ds, eval_loader(val_ds), val_img2txt, train_img2txt=train_img2txt,
                  train_txt2img=train_txt2img, mining_loaders=mining_loaders, autocast_bf16=bool(args.fp16))
