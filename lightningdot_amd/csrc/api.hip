@@ -111,6 +111,12 @@ struct ldot_index {
     // rows stored in cluster order can fill the candidate buffer on EVERY search of an index: after an overflow the narrow search is
     // skipped for `narrow_backoff` searches, twice as many after every further overflow (reset by a search that fits)
     int narrow_backoff = 0, narrow_penalty = 16;
+    // recovery of overflowed queries (redo_flagged): indices of the flagged queries + compact copies of their operands and lists
+    struct Compact {
+        DevBuf fidx, q32, q16b, ls, li, tau;
+    } compact[2];   // (level 0: the fused re-scan, level 1: the dense last resort for what overflows even then)
+    bool overflow_was_narrow = false;   // the overflow the last check reported came from the narrow search's candidate buffers
+    int64_t redone = 0;                 // queries searched again by the last search (ldot_index_last_stats: dense_pairs stays the dense work)
     // a search in two halves (ldot_index_search_begin / _finish): what _finish needs to know
     int64_t pend_nq = 0;
     int pend_k = 0, pend_kp = 0;
@@ -206,6 +212,8 @@ int ldot_index_destroy(ldot_index_t* ix) {
     ix->w_laug.release();
     ix->w_lprobe_s.release();
     ix->w_lprobe_l.release();
+    for (auto& c : ix->compact)
+        for (DevBuf* b : {&c.fidx, &c.q32, &c.q16b, &c.ls, &c.li, &c.tau}) b->release();
     if (ix->h_over_sum) (void)hipHostFree(ix->h_over_sum);
     if (ix->h_nover) (void)hipHostFree(ix->h_nover);
     delete ix;
@@ -598,13 +606,56 @@ constexpr int64_t kFewSelectMaxQueries = 256;   // one query block: sub-pools fo
 constexpr int64_t kFewBlockGrowthPct = 1600;   // launch growth with ONE query block (65 .. 256 queries): 2-3 % faster than growing
                                                // straight to the pool bound (tools/fewgrowth_sweep.py: 0.657 vs 0.675 ms at 100 queries)
 
-static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_pad, int kp, hipStream_t st) {
+// one fused-filter launch over index rows [r, r + len) for the queries [q0, q0 + nq) + the pool select that folds its records into
+// the running lists and raises the thresholds
+static int fused_launch_and_select(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_pad, int kp, int64_t r, int64_t len,
+                                   hipStream_t st) {
     float* tau = (float*)ix->w_tau.p + q0;
     float* ls = (float*)ix->w_ls.p + q0 * kp;
     int32_t* li = (int32_t*)ix->w_li.p + q0 * kp;
-    const uint16_t* q16 = (const uint16_t*)ix->w_q16b.p + q0 * ix->ld16();   // (q0 is a multiple of 256: whole 16-row blocks)
+    const uint16_t* q16 = (const uint16_t*)ix->w_q16b.p + q0 * ix->ld16();
     int32_t* over = (int32_t*)ix->w_over.p + q0;
+    const int qg = fused_query_group(nq_pad);
+    const int64_t nslices = 256 / qg, nsubs = 4 * nslices;
     int rc;
+    prof_begin(ix, st, 2.0 * nq * len * ix->d, (double)len * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * kp * 8);
+    rc = launch_score_filter(ix->x16b, ix->ld16(), r, len, q16, ix->ld16(), nq_pad, (int)ix->ld16(), tau, (uint4*)ix->w_pool.p,
+                             (int32_t*)ix->w_pool_cnt.p, st);
+    prof_end(ix, st);
+    if (rc) return rc;
+    if (nq <= kFewSelectMaxQueries && nsubs >= 512 && kp + 512 + 32 <= 1024) {
+        // few queries: G waves per query fold the sub-pools into partial lists, one merge joins them with the running list
+        const int G = 16;
+        if ((rc = ix->w_part_s.ensure((size_t)G * nq * kp * 4))) return rc;
+        if ((rc = ix->w_part_l.ensure((size_t)G * nq * kp * 8))) return rc;
+        float* ps = (float*)ix->w_part_s.p;
+        int64_t* pl = (int64_t*)ix->w_part_l.p;
+        if ((rc = launch_select_pools_parts((const uint4*)ix->w_pool.p, (const int32_t*)ix->w_pool_cnt.p, (int)nsubs, nq, G,
+                                            (int32_t)ix->ntotal, kp, tau, ps, pl, over, (int32_t*)ix->w_over_sum.p,
+                                            (int32_t*)ix->w_qcnt.p + q0, st)))
+            return rc;
+        return launch_merge_parts_into_lists(ps, pl, G, nq, kp, ls, li, tau, st);
+    }
+    return launch_select_pools((const uint4*)ix->w_pool.p, (const int32_t*)ix->w_pool_cnt.p, (int)nsubs, nq, (int32_t)ix->ntotal, ls,
+                               li, kp, tau, over, (int32_t*)ix->w_over_sum.p, (int32_t*)ix->w_qcnt.p + q0, st);
+}
+
+// candidate pools + counters for nq_pad queries (the counters are all-zero between searches)
+static int fused_pools(ldot_index* ix, int64_t nq_pad, hipStream_t st) {
+    const int qg = fused_query_group(nq_pad);
+    const int64_t nsubs = 4 * (256 / qg);
+    int rc;
+    if ((rc = ix->w_pool.ensure((size_t)nq_pad * nsubs * kPoolCap * kPoolRecBytes))) return rc;
+    const size_t cnt_bytes = (size_t)nq_pad * nsubs * 4;
+    if (cnt_bytes > ix->w_pool_cnt.bytes) ix->pools_clean = false;
+    if ((rc = ix->w_pool_cnt.ensure(cnt_bytes))) return rc;
+    if (!ix->pools_clean) LDOT_HIP_CHECK(hipMemsetAsync(ix->w_pool_cnt.p, 0, ix->w_pool_cnt.bytes, st));
+    ix->pools_clean = false;   // until the scan that uses them has completed
+    return LDOT_OK;
+}
+
+static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_pad, int kp, hipStream_t st) {
+    int rc;   // (q0 is a multiple of 256: whole 16-row blocks of the query shadow)
     // Pool sizing rule: a launch over `len` rows after `r` scanned rows admits ~kp*len/r candidates per query,
     // spread over nsubs lane-private sub-pools of kPoolCap records.  Keeping the expectation <= 8 per sub-pool
     // (overflow probability ~1e-11 each) bounds len <= r * 8 * nsubs / kp (1024 r / kp at 128 sub-pools; 8x that for the
@@ -620,12 +671,7 @@ static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_p
     warm = std::min(ix->ntotal, warm);
     if ((rc = dense_scan_all(ix, nq, 0, warm, kp, (float*)ix->w_tau.p, nq <= 64, st, q0))) return rc;
     if (warm >= ix->ntotal) return LDOT_OK;
-    if ((rc = ix->w_pool.ensure((size_t)nq_pad * nsubs * kPoolCap * kPoolRecBytes))) return rc;
-    const size_t cnt_bytes = (size_t)nq_pad * nsubs * 4;
-    if (cnt_bytes > ix->w_pool_cnt.bytes) ix->pools_clean = false;
-    if ((rc = ix->w_pool_cnt.ensure(cnt_bytes))) return rc;
-    if (!ix->pools_clean) LDOT_HIP_CHECK(hipMemsetAsync(ix->w_pool_cnt.p, 0, ix->w_pool_cnt.bytes, st));
-    ix->pools_clean = false;   // until this scan has completed
+    if ((rc = fused_pools(ix, nq_pad, st))) return rc;
     // (the pad queries' thresholds are +inf since init_lists: they never produce candidates)
     // few query blocks: admissions are cheap, launches are not -> let the launch length grow up to the pool bound
     int64_t few_growth = kFewBlockGrowthPct;
@@ -641,30 +687,7 @@ static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_p
         len = len / (bm * nslices) * (bm * nslices);
         len = std::min(len, ix->ntotal - r);
         if (ix->ntotal - r - len < len / 4) len = ix->ntotal - r;   // no short tail launch (the pool bound has that slack)
-        prof_begin(ix, st, 2.0 * nq * len * ix->d,
-                   (double)len * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * kp * 8);
-        rc = launch_score_filter(ix->x16b, ix->ld16(), r, len, q16, ix->ld16(), nq_pad, (int)ix->ld16(), tau,
-                                 (uint4*)ix->w_pool.p, (int32_t*)ix->w_pool_cnt.p, st);
-        prof_end(ix, st);
-        if (rc) return rc;
-        if (nq <= kFewSelectMaxQueries && nsubs >= 512 && kp + 512 + 32 <= 1024) {
-            // few queries: G waves per query fold the sub-pools into partial lists, one merge joins them with the running list
-            const int G = 16;
-            if ((rc = ix->w_part_s.ensure((size_t)G * nq * kp * 4))) return rc;
-            if ((rc = ix->w_part_l.ensure((size_t)G * nq * kp * 8))) return rc;
-            float* ps = (float*)ix->w_part_s.p;
-            int64_t* pl = (int64_t*)ix->w_part_l.p;
-            if ((rc = launch_select_pools_parts((const uint4*)ix->w_pool.p, (const int32_t*)ix->w_pool_cnt.p, (int)nsubs, nq, G,
-                                                (int32_t)ix->ntotal, kp, tau, ps, pl, over, (int32_t*)ix->w_over_sum.p,
-                                                (int32_t*)ix->w_qcnt.p + q0, st)))
-                return rc;
-            if ((rc = launch_merge_parts_into_lists(ps, pl, G, nq, kp, ls, li, tau, st))) return rc;
-        } else {
-            rc = launch_select_pools((const uint4*)ix->w_pool.p, (const int32_t*)ix->w_pool_cnt.p, (int)nsubs, nq,
-                                     (int32_t)ix->ntotal, ls, li, kp, tau, over, (int32_t*)ix->w_over_sum.p,
-                                     (int32_t*)ix->w_qcnt.p + q0, st);
-            if (rc) return rc;
-        }
+        if ((rc = fused_launch_and_select(ix, q0, nq, nq_pad, kp, r, len, st))) return rc;
         ix->stats[3] += len * nq;
         r += len;
     }
@@ -701,6 +724,7 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
 static bool fused_overflow_check(ldot_index* ix) {
     if (!ix->overflow_pending) return false;
     ix->overflow_pending = false;
+    ix->overflow_was_narrow = ix->overflow_narrow > 0;
     if (ix->overflow_narrow > 0) {   // narrow search: flags written by its final kernel
         int64_t n = 0;
         for (int64_t q = 0; q < ix->overflow_narrow; ++q) n += ix->h_nover[q];
@@ -724,7 +748,71 @@ static int dense_redo(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
     float* tau = (float*)ix->w_tau.p;
     int rc;
     if ((rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, tau, nq, nq_pad, st))) return rc;
+    ix->redone += nq;
     return dense_scan_all(ix, nq, 0, ix->ntotal, kp, tau, true, st);
+}
+
+// Recovery after a fused scan in which some queries' lane-private pools overflowed (row orders that concentrate a query's best rows
+// in few tiles: cluster-sorted rows, the adversarial ramp).  ONLY the flagged queries are searched again, and cheaply: a dropped record
+// can only have LOWERED a query's threshold, so the threshold the first pass ended with is still a valid lower bound of its final k'-th
+// score — and usually a close one.  Level 0: the flagged queries are compacted into a batch of their own and scanned once more over ALL
+// rows in ONE fused launch with those thresholds: hardly more than their true top-k' rows are admitted, so the pools hold.  Level 1:
+// queries that overflow even then (rows in ascending score order: the dropped records were the BEST ones and the threshold is far too
+// low) are compacted again and take the always-correct dense path.  `st` is synchronised.
+static int redo_flagged(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStream_t st, int level = 0) {
+    if (level == 0 && ix->overflow_was_narrow) return dense_redo(ix, nq, nq_pad, kp, st);   // (<= 64 queries: the streaming selector is cheap)
+    int rc;
+    std::vector<int32_t> flags((size_t)nq), fidx;
+    LDOT_HIP_CHECK(hipMemcpyAsync(flags.data(), ix->w_over.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    LDOT_HIP_CHECK(hipStreamSynchronize(st));
+    for (int64_t q = 0; q < nq; ++q)
+        if (flags[(size_t)q]) fidx.push_back((int32_t)q);
+    const int64_t nf = (int64_t)fidx.size(), nf_pad = round_up(std::max<int64_t>(nf, 1), kBM);
+    if (nf == 0) return LDOT_OK;
+    if (level == 0) ix->redone += nf;
+    ldot_index::Compact& c = ix->compact[level];
+    if ((rc = c.fidx.ensure((size_t)nf * 4))) return rc;
+    if ((rc = c.q32.ensure((size_t)nf_pad * ix->dpad * 4))) return rc;
+    if ((rc = c.q16b.ensure((size_t)nf_pad * ix->ld16() * 2))) return rc;
+    if ((rc = c.ls.ensure((size_t)nf_pad * kp * 4))) return rc;
+    if ((rc = c.li.ensure((size_t)nf_pad * kp * 4))) return rc;
+    if ((rc = c.tau.ensure((size_t)nf_pad * 4))) return rc;
+    const int32_t* didx = (const int32_t*)c.fidx.p;
+    LDOT_HIP_CHECK(hipMemcpyAsync(c.fidx.p, fidx.data(), (size_t)nf * 4, hipMemcpyHostToDevice, st));
+    if ((rc = launch_gather_rows_f32((const float*)ix->w_q32.p, ix->dpad, didx, nf, nf_pad, (float*)c.q32.p, st))) return rc;
+    if ((rc = launch_convert_rows(c.q32.p, LDOT_F32, ix->dpad, nf, nf_pad, ix->d, ix->dpad, 0, nullptr, nullptr, ix->precision ? 2 : 0,
+                                  (uint16_t*)c.q16b.p, 0, st)))
+        return rc;
+    if ((rc = launch_init_lists((float*)c.ls.p, (int32_t*)c.li.p, nf_pad * kp, (float*)c.tau.p, nf, nf_pad, st))) return rc;
+    if (level == 0 && (rc = launch_gather_tau((const float*)ix->w_tau.p, didx, nf, (float*)c.tau.p, st))) return rc;
+    // the compact batch stands where the search's operands and lists are, for the duration of its own scan
+    auto swap_in = [&]() {
+        std::swap(ix->w_q32, c.q32);
+        std::swap(ix->w_q16b, c.q16b);
+        std::swap(ix->w_ls, c.ls);
+        std::swap(ix->w_li, c.li);
+        std::swap(ix->w_tau, c.tau);
+    };
+    swap_in();
+    rc = [&]() -> int {
+        int r2;
+        LDOT_HIP_CHECK(hipMemsetAsync(ix->w_over.p, 0, ix->w_over.bytes, st));
+        LDOT_HIP_CHECK(hipMemsetAsync(ix->w_over_sum.p, 0, 16, st));
+        if (level == 1) return dense_scan_all(ix, nf, 0, ix->ntotal, kp, (float*)ix->w_tau.p, true, st);
+        if ((r2 = fused_pools(ix, nf_pad, st))) return r2;
+        if ((r2 = fused_launch_and_select(ix, 0, nf, nf_pad, kp, 0, ix->ntotal, st))) return r2;
+        ix->pools_clean = true;
+        ix->stats[3] += ix->ntotal * nf;
+        LDOT_HIP_CHECK(hipMemcpyAsync(ix->h_over_sum, ix->w_over_sum.p, 4, hipMemcpyDeviceToHost, st));
+        LDOT_HIP_CHECK(hipStreamSynchronize(st));
+        if (ix->h_over_sum[0] > 0) return redo_flagged(ix, nf, nf_pad, kp, st, 1);
+        return LDOT_OK;
+    }();
+    swap_in();   // (back)
+    ix->flags_clean = true;
+    if (rc) return rc;
+    return launch_scatter_lists((const float*)c.ls.p, (const int32_t*)c.li.p, (const float*)c.tau.p, didx, nf, kp, (float*)ix->w_ls.p,
+                                (int32_t*)ix->w_li.p, (float*)ix->w_tau.p, st);
 }
 
 // defer_check: enqueue a fused scan speculatively and leave the overflow check to the caller's own synchronisation point
@@ -744,6 +832,7 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
     LDOT_REQUIRE(queries != nullptr, LDOT_EINVAL, "NULL buffer");
     DeviceGuard guard(ix->device);
     for (int i = 0; i < 4; ++i) ix->stats[i] = 0;
+    ix->redone = 0;
     const int kp = candidate_len(ix, k);
     const int64_t nq_pad = round_up(nq, kBM);
     int rc;
@@ -777,7 +866,7 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
         if ((rc = narrow_search(ix, nq, kp, st))) return rc;
         if (!defer_check) {
             LDOT_HIP_CHECK(hipStreamSynchronize(st));
-            if (fused_overflow_check(ix) && (rc = dense_redo(ix, nq, nq_pad, kp, st))) return rc;
+            if (fused_overflow_check(ix) && (rc = redo_flagged(ix, nq, nq_pad, kp, st))) return rc;
         }
     } else if (ix->ntotal > 0) {
         // AUTO: the fused scan pays off from ~32k rows (tools/auto_threshold.py); very large batches (COCO-5k sized image->text
@@ -792,7 +881,7 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
             if ((rc = fused_scan(ix, nq, nq_pad, kp, st))) return rc;
             if (!defer_check) {
                 LDOT_HIP_CHECK(hipStreamSynchronize(st));
-                if (fused_overflow_check(ix) && (rc = dense_redo(ix, nq, nq_pad, kp, st))) return rc;
+                if (fused_overflow_check(ix) && (rc = redo_flagged(ix, nq, nq_pad, kp, st))) return rc;
             }
         } else if ((rc = dense_scan_all(ix, nq, 0, ix->ntotal, kp, tau, true, st))) {
             return rc;
@@ -890,8 +979,8 @@ int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dty
     if ((rc = search_finish_impl(ix, nullptr, out_scores, out_labels, out_mem, check, st))) return rc;
     if (!check) return LDOT_OK;
     if (out_mem == LDOT_DEVICE) LDOT_HIP_CHECK(hipStreamSynchronize(st));
-    if (fused_overflow_check(ix)) {   // adversarial row order: redo everything with the always-correct dense path
-        if ((rc = dense_redo(ix, nq, round_up(nq, kBM), ix->pend_kp, st))) return rc;
+    if (fused_overflow_check(ix)) {   // unfriendly row order: the flagged queries are searched again (redo_flagged), the rest re-scored as is
+        if ((rc = redo_flagged(ix, nq, round_up(nq, kBM), ix->pend_kp, st))) return rc;
         return search_finish_impl(ix, nullptr, out_scores, out_labels, out_mem, false, st);
     }
     ix->pend_nq = 0;

@@ -158,6 +158,63 @@ int launch_augment_queries(const void* src, int dtype, int d, int64_t n, int nor
     return LDOT_OK;
 }
 
+// ---- recovery of overflowed queries (api.hip: redo_flagged): compact copies of the flagged queries' rows / thresholds, and the
+// way back for their finished lists ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_f32_kernel(const float* __restrict__ src, int64_t ld, const int32_t* __restrict__ idx,
+                                                              int64_t n, int64_t n_pad, float* __restrict__ dst) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_pad) return;
+    const float* s = row < n ? src + (int64_t)idx[row] * ld : nullptr;
+    for (int64_t c = lane; c < ld; c += 64) dst[row * ld + c] = s ? s[c] : 0.f;
+}
+
+// thresholds of the flagged queries, lowered by a hair: the threshold is the k'-th best score the FIRST pass saw, partly computed by
+// another kernel (the dense warm-up) whose fp32 summation order may differ in the last bits from the filter kernel's
+__global__ __launch_bounds__(256) void gather_tau_kernel(const float* __restrict__ tau, const int32_t* __restrict__ idx, int64_t n,
+                                                         float* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float t = tau[idx[i]];
+    dst[i] = t - fabsf(t) * 1e-5f - 1e-30f;
+}
+
+__global__ __launch_bounds__(256) void scatter_lists_kernel(const float* __restrict__ cs, const int32_t* __restrict__ ci,
+                                                            const float* __restrict__ ctau, const int32_t* __restrict__ idx,
+                                                            int64_t n, int kp, float* __restrict__ ls, int32_t* __restrict__ li,
+                                                            float* __restrict__ tau) {
+    const int64_t q = blockIdx.x;
+    if (q >= n) return;
+    const int64_t dst = idx[q];
+    for (int c = threadIdx.x; c < kp; c += 256) {
+        ls[dst * kp + c] = cs[q * kp + c];
+        li[dst * kp + c] = ci[q * kp + c];
+    }
+    if (threadIdx.x == 0) tau[dst] = ctau[q];
+}
+
+int launch_gather_rows_f32(const float* src, int64_t ld, const int32_t* idx, int64_t n, int64_t n_pad, float* dst, hipStream_t st) {
+    if (n_pad <= 0) return LDOT_OK;
+    hipLaunchKernelGGL(gather_rows_f32_kernel, dim3((unsigned)((n_pad + 3) / 4)), dim3(256), 0, st, src, ld, idx, n, n_pad, dst);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+int launch_gather_tau(const float* tau, const int32_t* idx, int64_t n, float* dst, hipStream_t st) {
+    if (n <= 0) return LDOT_OK;
+    hipLaunchKernelGGL(gather_tau_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tau, idx, n, dst);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+int launch_scatter_lists(const float* cs, const int32_t* ci, const float* ctau, const int32_t* idx, int64_t n, int kp, float* ls,
+                         int32_t* li, float* tau, hipStream_t st) {
+    if (n <= 0) return LDOT_OK;
+    hipLaunchKernelGGL(scatter_lists_kernel, dim3((unsigned)n), dim3(256), 0, st, cs, ci, ctau, idx, n, kp, ls, li, tau);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
 int launch_convert_rows(const void* src, int dtype, int64_t ld_src, int64_t n, int64_t n_pad, int d, int dpad,
                         int normalize, float* dst32, uint16_t* dst16, int split, uint16_t* dst16b, int64_t row0b,
                         hipStream_t st) {

@@ -32,6 +32,13 @@ int launch_convert_rows(const void* src, int dtype, int64_t ld_src, int64_t n, i
                         int normalize, float* dst32, uint16_t* dst16, int split, uint16_t* dst16b, int64_t row0b,
                         hipStream_t st);
 
+// recovery of overflowed queries: dst row i = src row idx[i] (rows [n, n_pad) zero); their thresholds (lowered by a hair); and the
+// way back for finished lists: list / threshold of compact query i -> query idx[i]
+int launch_gather_rows_f32(const float* src, int64_t ld, const int32_t* idx, int64_t n, int64_t n_pad, float* dst, hipStream_t st);
+int launch_gather_tau(const float* tau, const int32_t* idx, int64_t n, float* dst, hipStream_t st);
+int launch_scatter_lists(const float* cs, const int32_t* ci, const float* ctau, const int32_t* idx, int64_t n, int kp, float* ls,
+                         int32_t* li, float* tau, hipStream_t st);
+
 // q16 / x16 are the BLOCKED shadows (launch_convert_rows dst16b), nq_pad a multiple of 256, xrow0 a multiple of 16
 int launch_score_dense(const void* q16, int64_t ldq_elems, int64_t nq_pad, const void* x16, int64_t ldx_elems,
                        int64_t xrow0, int64_t nrows_pad, int dpad, float* S, int64_t lds_elems, int64_t nq_valid,

@@ -8,10 +8,11 @@
 // v_cmp per 4 scores with an exec-masked, almost never taken, append.
 //
 // Appends go to lane-private sub-pools in HBM (cursor in a VGPR, no atomics, no LDS): for a query q each of the
-// 4 lanes x (row slices) that can produce candidates owns the entries pool[q][e][sub], e = 0..kPoolCap-1.  The layout
-// is entry-major ([q][e][sub], one 8-byte {score, row} word per entry) so that the select kernel, which folds the
-// pools into the running top-k' list between launches and raises tau, reads the few used entry levels of all
-// sub-pools as contiguous 8-byte words instead of one cache line per entry.
+// 4 lanes x (row slices) that can produce candidates owns kPoolCap RECORDS.  A record is what a lane holds when its
+// max-of-8 test fires: the 8 scores of accumulator registers 8h..8h+7 (rows rb + {0,1,2,3,8,9,10,11}) and rb — three 16-byte
+// planes, stored entry-major and plane-major, pool[((q * kPoolCap + e) * 3 + plane) * nsubs + sub] in 16-byte units, so that the
+// select kernel, which folds the pools into the running top-k' list between launches and raises tau, reads one entry level of
+// all sub-pools as contiguous 16-byte words instead of one cache line per record.
 //
 // Work decomposition (256 persistent workgroups, block b observed on XCD b % 8; qg = query blocks per XCD):
 //   XCD x, slot s in [0,32): qsub = s % qg, nsub = s / qg;  row stream = x*(32/qg) + nsub (nstreams = 256 / qg).

@@ -6,6 +6,7 @@ the hot path.
                                                              fp16 -> fp32, first nbb regions)
     ItmFastDataset    <- dvl/data/itm.py:30-122             (new_epoch with per-item hard negatives, item layout)
     itm_fast_collate  <- dvl/data/itm.py:203-288            (batch dict consumed by BiEncoder.forward / train_step)
+    EvalLoader        <- dvl/trainer.py:29-41               (build_dataloader(is_train=False): consecutive batches, moved to the device)
 
 The reference keeps its records in LMDB environments.  The `lmdb`, `lz4` and `msgpack_numpy` packages are not part of this image, so
 the CONTAINER is replaced and the VALUES are read as they are:
@@ -74,7 +75,41 @@ def _lz4_block_decode(src: bytes, out: bytearray) -> None:
                 out.append(out[start + k])
 
 
+_P1, _P2, _P3, _P4, _P5, _M32 = 2654435761, 2246822519, 3266489917, 668265263, 374761393, 0xffffffff
+
+
+def xxh32(data: bytes, seed: int = 0) -> int:
+    """XXH32 (the checksum of the LZ4 frame format: header, optional per-block and content checksums)"""
+    n, i = len(data), 0
+    rotl = lambda x, r: ((x << r) | (x >> (32 - r))) & _M32
+    if n >= 16:
+        v1, v2, v3, v4 = (seed + _P1 + _P2) & _M32, (seed + _P2) & _M32, seed & _M32, (seed - _P1) & _M32
+        for a, b, c, d in struct.iter_unpack('<4I', data[:n - n % 16]):
+            v1 = rotl((v1 + a * _P2) & _M32, 13) * _P1 & _M32
+            v2 = rotl((v2 + b * _P2) & _M32, 13) * _P1 & _M32
+            v3 = rotl((v3 + c * _P2) & _M32, 13) * _P1 & _M32
+            v4 = rotl((v4 + d * _P2) & _M32, 13) * _P1 & _M32
+        i = n - n % 16
+        h = (rotl(v1, 1) + rotl(v2, 7) + rotl(v3, 12) + rotl(v4, 18)) & _M32
+    else:
+        h = (seed + _P5) & _M32
+    h = (h + n) & _M32
+    while i + 4 <= n:
+        h = rotl((h + struct.unpack_from('<I', data, i)[0] * _P3) & _M32, 17) * _P4 & _M32
+        i += 4
+    while i < n:
+        h = rotl((h + data[i] * _P5) & _M32, 11) * _P1 & _M32
+        i += 1
+    h ^= h >> 15
+    h = h * _P2 & _M32
+    h ^= h >> 13
+    h = h * _P3 & _M32
+    return h ^ (h >> 16)
+
+
 def lz4_frame_decompress(data: bytes) -> bytes:
+    """One LZ4 frame -> its content.  Header, block and content checksums are verified when the frame carries them, the content size
+    when it is stored (what ``lz4.frame.decompress`` does: a damaged record raises instead of decoding to garbage)."""
     data = bytes(data)
     if len(data) < 7 or struct.unpack_from('<I', data, 0)[0] != _LZ4_MAGIC:
         raise ValueError('not an LZ4 frame')
@@ -82,11 +117,15 @@ def lz4_frame_decompress(data: bytes) -> bytes:
     if (flg >> 6) != 1:
         raise ValueError('unsupported LZ4 frame version')
     block_checksum, content_size, content_checksum, dict_id = flg & 0x10, flg & 0x08, flg & 0x04, flg & 0x01
+    want_size = None
     if content_size:
+        want_size = struct.unpack_from('<Q', data, pos)[0]
         pos += 8
     if dict_id:
         pos += 4
-    pos += 1                                        # header checksum byte
+    if data[pos] != (xxh32(data[4:pos]) >> 8) & 0xff:
+        raise ValueError('corrupt LZ4 frame: header checksum mismatch')
+    pos += 1
     out = bytearray()
     while True:
         size = struct.unpack_from('<I', data, pos)[0]
@@ -96,15 +135,23 @@ def lz4_frame_decompress(data: bytes) -> bytes:
         stored = size & 0x80000000
         size &= 0x7fffffff
         blk = data[pos:pos + size]
+        if len(blk) != size:
+            raise ValueError('truncated LZ4 frame')
         pos += size
         if block_checksum:
+            if struct.unpack_from('<I', data, pos)[0] != xxh32(blk):
+                raise ValueError('corrupt LZ4 frame: block checksum mismatch')
             pos += 4
         if stored:
             out += blk
         else:
             _lz4_block_decode(blk, out)
     if content_checksum:
+        if struct.unpack_from('<I', data, pos)[0] != xxh32(bytes(out)):
+            raise ValueError('corrupt LZ4 frame: content checksum mismatch')
         pos += 4
+    if want_size is not None and want_size != len(out):
+        raise ValueError('corrupt LZ4 frame: content size mismatch')
     return bytes(out)
 
 
@@ -254,20 +301,6 @@ def convert_lmdb(lmdb_dir: str, out_prefix: str) -> int:
     return n
 
 
-def _dist_rank_size():
-    """(rank, world) when several NODES take part — the reference strides the ids only then (data.py:36-41,185-186: hvd.size() !=
-    hvd.local_size()); one process group on one node reads everything and shards by sampler instead."""
-    try:
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            local = int(os.environ.get('LOCAL_WORLD_SIZE', dist.get_world_size()))
-            if dist.get_world_size() != local:
-                return dist.get_rank(), dist.get_world_size()
-    except Exception:
-        pass
-    return 0, 1
-
-
 # ---------------------------------------------------------------------------------------------------------------------------
 # text side
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -275,14 +308,18 @@ class TxtTokDb:
     """uniter_model/data/data.py:177-214.  ``db_dir`` holds id2len.json, meta.json, txt2img.json, img2txts.json (as the reference's
     DB folders do) and the converted record store ``data.bin`` / ``data.idx.json``."""
 
-    def __init__(self, db_dir: str, max_txt_len: int = 60):
+    def __init__(self, db_dir: str, max_txt_len: int = 60, shard=None):
+        """``shard=(rank, world)`` keeps ids[rank::world] like the reference does under horovod (data.py:185-186; its guard
+        ``hvd.size() != hvd.local_size`` compares with the function object and is therefore always true, :36-41).  Default: all
+        ids — here the training loader hands every rank its share of each batch (train_itm.default_train_loader), and striding
+        the ids as well would shard twice."""
         self.id2len = json.load(open(f'{db_dir}/id2len.json'))
         if max_txt_len == -1:
             ids = list(self.id2len.keys())
         else:
             ids = [id_ for id_, len_ in self.id2len.items() if len_ <= max_txt_len]
-        rank, world = _dist_rank_size()
-        if world > 1:
+        if shard is not None:
+            rank, world = shard
             ids = ids[rank::world]
         self.ids = ids
         self.db_dir = db_dir
@@ -384,7 +421,7 @@ class ItmFastDataset(torch.utils.data.Dataset):
         self._img_of = [self.txt_db[id_]['img_fname'] for id_ in self.ids]
         self.all_imgs = list(set(self._img_of))
         self.num_hard_negatives, self.img_meta, self.tokenizer = num_hard_negatives, img_meta, tokenizer
-        self.train_imgs = self.neg_imgs = None
+        self.train_imgs = self.neg_imgs = self.train_txts = self.neg_txts = None      # bound by new_epoch
         self.lens = [tl + self.img_db.name2nbb[f] for tl, f in zip(self.txt_lens, self._img_of)]
 
     def __len__(self):
@@ -519,3 +556,20 @@ def batch_to_device(batch: dict, device):
         else:
             out[k] = v.to(device, non_blocking=True) if torch.is_tensor(v) else v
     return out
+
+
+class EvalLoader:
+    """Re-iterable evaluation-style loader (dvl/trainer.py:29-41 without the worker processes): consecutive items, collated and moved
+    to the device ONE batch at a time — the towers consume a batch before the next one is read, so a pass over the Flickr / COCO
+    training sets for hard-negative mining never holds more than one batch of region features."""
+
+    def __init__(self, dataset, batch_size: int, device):
+        self.dataset, self.batch_size, self.device = dataset, int(batch_size), device
+
+    def __len__(self):
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        ds, bs = self.dataset, self.batch_size
+        for b0 in range(0, len(ds), bs):
+            yield batch_to_device(itm_fast_collate([ds[i] for i in range(b0, min(b0 + bs, len(ds)))]), self.device)

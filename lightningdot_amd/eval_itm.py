@@ -8,9 +8,10 @@ sequence-length guard (:68-71), ``inf_minibatch_size = 400``, ``vector_size = pr
 with the pre-training prefix fallback (:97-107), per-partition evaluation and the same prints (:130-152) — including the
 reference's naming swap: what is printed as "image retrieval recall" is text-query -> image retrieval.
 
-The LMDB readers (uniter_model/data, §8f rank 2) need lmdb / lz4 / msgpack_numpy, which are not installed; a
-``dataloader_factory(args, txt_db, img_db) -> (dataloader, img2txt)`` is injected by the caller, or ``--synthetic`` feeds
-random batches in the reference collate layout (smoke / throughput runs; the recalls are then meaningless)."""
+The partitions' text / image DBs are read with lightningdot_amd.data (``db_dataloader`` below = load_dataset(is_train=False) +
+build_dataloader of dvl/trainer.py:29-41,193-209 over the converted FlatDb containers); a different
+``dataloader_factory(args, txt_db, img_db) -> (dataloader, img2txt)`` can be injected, and ``--synthetic`` feeds random batches in
+the reference collate layout (smoke / throughput runs; the recalls are then meaningless)."""
 import os
 import sys
 import time
@@ -34,6 +35,17 @@ def _hparams_from_dirname(args):
          args.caption_score_weight) = 0, 0, 0, 0, 0
     if len(parsed) >= 4:
         args.hard_negatives_sampling = parsed[3]
+
+
+def db_dataloader(args, txt_db, img_db):
+    """eval_itm.py:137-142 -> dvl/trainer.py:203-207 (``TxtTokLmdb(txt_db, -1)``, ``ItmFastDataset(..., args.inf_minibatch_size, ...)``),
+    ``dataset.new_epoch()``, ``build_dataloader(dataset, itm_fast_collate, False, args)`` and the partition's img2txts.json"""
+    from .data import DetectFeatDb, EvalLoader, ItmFastDataset, TxtTokDb
+    img = DetectFeatDb(img_db, args.conf_th, args.max_bb, args.min_bb, args.num_bb, bool(getattr(args, 'compressed_db', False)))
+    txt = TxtTokDb(txt_db, -1)
+    dataset = ItmFastDataset(txt, img, args.inf_minibatch_size, getattr(args, 'img_meta', None), getattr(args, 'tokenizer', None))
+    dataset.new_epoch()
+    return EvalLoader(dataset, args.valid_batch_size, args.device), txt.img2txts
 
 
 def EVAL_MODEL(config: str, checkpoint: str, dataloader_factory=None, synthetic_images: int = 0, cmds=None):
@@ -73,11 +85,8 @@ def EVAL_MODEL(config: str, checkpoint: str, dataloader_factory=None, synthetic_
             dataloader, img2txt = synthetic_itm_batches(synthetic_images, batch_size=args.valid_batch_size,
                                                         txt_len=min(args.max_txt_len, 30), num_bb=args.num_bb,
                                                         device=args.device, seed=args.seed)
-        elif dataloader_factory is not None:
-            dataloader, img2txt = dataloader_factory(args, txt_db, img_db)
         else:
-            raise RuntimeError('no LMDB reader in this build (lmdb / lz4 / msgpack_numpy are not installed): pass a '
-                               'dataloader_factory or --synthetic N')
+            dataloader, img2txt = (dataloader_factory or db_dataloader)(args, txt_db, img_db)
         start_time = time.time()
         with torch.autocast('cuda', dtype=torch.bfloat16, enabled=bool(args.fp16)):
             loss_val, correct_ratio_val, (indexer_img, indexer_txt), (recall_img, recall_txt), _ = \

@@ -61,3 +61,55 @@ def rerank_recall(rankings: Dict[object, List], score: Callable[[object, object]
                 recall[top] += bool(is_hit(qid, kept[:top]))
         out[threshold] = {t: v / float(den) for t, v in recall.items()}
     return out
+
+
+# ---- device path: candidates stay label tensors, the external scores come as a matrix ----------------------------------------------
+def first_stage_candidates(bi_encoder, indexer_img, indexer_txt, dataloader: Iterable, img2txt: Dict, txt2img: Dict):
+    """rerank.py:168-204 without per-result Python objects: encodes the loader, searches top-max(RECALL_TOPS) both ways on the device
+    and returns ``dict(txt_ids, img_ids, labels_img [n_txt, 100], labels_txt [n_img_queries, 100], pos_img [n_txt, 1],
+    pos_txt [n_img_queries, P], recall_img, recall_txt, total_len)`` — label tensors index ``indexer_*.index_id_to_db_id``; the
+    recall counters are the reference's (hits over every query occurrence, :195-204)."""
+    n_top = max(RECALL_TOPS)
+    txt_ids, img_ids, lab_img, lab_txt = [], [], [], []
+    for batch in dataloader:
+        with torch.no_grad():
+            txt_vec, img_vec, _ = bi_encoder(batch)
+        lab_img.append(indexer_img.search_knn_tensors(txt_vec.detach(), n_top)[1])
+        lab_txt.append(indexer_txt.search_knn_tensors(img_vec.detach(), n_top)[1])
+        txt_ids.extend(batch['txt_index'])
+        img_ids.extend(batch['img_fname'])
+    lab_img, lab_txt = torch.cat(lab_img), torch.cat(lab_txt)
+    dev = lab_img.device
+    img_row = {k: r for r, k in enumerate(indexer_img.index_id_to_db_id)}
+    txt_row = {k: r for r, k in enumerate(indexer_txt.index_id_to_db_id)}
+    pos_img = torch.as_tensor([[img_row.get(txt2img[t], -2)] for t in txt_ids], dtype=torch.int64, device=dev)
+    ncap = max([len(img2txt[i]) for i in img_ids] + [1])
+    pos_txt = torch.full((len(img_ids), ncap), -2, dtype=torch.int64)
+    for j, i in enumerate(img_ids):
+        rows = [txt_row.get(t, -2) for t in img2txt[i]]
+        pos_txt[j, :len(rows)] = torch.as_tensor(rows, dtype=torch.int64)
+    pos_txt = pos_txt.to(dev)
+
+    def hits(labels, pos):
+        return {top: int((labels[:, :top, None] == pos[:, None, :]).any(dim=2).any(dim=1).sum().item()) for top in RECALL_TOPS}
+    return dict(txt_ids=txt_ids, img_ids=img_ids, labels_img=lab_img, labels_txt=lab_txt, pos_img=pos_img, pos_txt=pos_txt,
+                recall_img=hits(lab_img, pos_img), recall_txt=hits(lab_txt, pos_txt), total_len=len(txt_ids))
+
+
+def rerank_recall_device(labels: torch.Tensor, ext_scores: torch.Tensor, positives: torch.Tensor,
+                         thresholds: Sequence[int] = THRESHOLDS, denominator: int = None, missing: float = -1000.0):
+    """rerank.py:256-290 on the device, for an external scorer given as a matrix (the reference's ``scores_mat`` form, :229-233):
+    ``labels`` [nq, K] first-stage candidates (index rows, -1 = padding), ``ext_scores`` [nq, n_db] the cross-encoder's score of
+    (query, index row), ``positives`` [nq, P] the rows that count as hits (-2 = unused).  For every threshold the scorer's top 10 of
+    the first ``threshold`` candidates are kept and Recall@{1,5,10} counted.  -> {threshold: {1: r, 5: r, 10: r}}"""
+    den = labels.shape[0] if denominator is None else denominator
+    out = {}
+    for threshold in thresholds:
+        cand = labels[:, :threshold]
+        s = torch.gather(ext_scores, 1, cand.clamp_min(0))
+        s = torch.where(cand >= 0, s, s.new_full((), missing))
+        idx = s.topk(min(10, cand.shape[1]), dim=1).indices
+        kept = torch.gather(cand, 1, idx)
+        out[threshold] = {top: int((kept[:, :top, None] == positives[:, None, :]).any(dim=2).any(dim=1).sum().item()) / float(den)
+                          for top in (1, 5, 10)}
+    return out

@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from .train import allreduce_gradients, broadcast_parameters, get_optimizer, get_schedule_linear
+from .data import EvalLoader          # noqa: F401  (re-exported: the evaluation-style loader of the CLI below)
 from .towers import CheckpointState, save_checkpoint
 
 logger = logging.getLogger(__name__)
@@ -61,24 +62,6 @@ def _default_steps_per_epoch(train_dataset, args) -> int:
 
 
 default_train_loader.steps_per_epoch = _default_steps_per_epoch
-
-
-class EvalLoader:
-    """Re-iterable evaluation-style loader (dvl/trainer.py:29-41 without the worker processes): consecutive items, collated and moved
-    to the device ONE batch at a time — the towers consume a batch before the next one is read, so a pass over the Flickr / COCO
-    training sets for hard-negative mining never holds more than one batch of region features."""
-
-    def __init__(self, dataset, batch_size: int, device):
-        self.dataset, self.batch_size, self.device = dataset, int(batch_size), device
-
-    def __len__(self):
-        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
-
-    def __iter__(self):
-        from .data import batch_to_device, itm_fast_collate
-        ds, bs = self.dataset, self.batch_size
-        for b0 in range(0, len(ds), bs):
-            yield batch_to_device(itm_fast_collate([ds[i] for i in range(b0, min(b0 + bs, len(ds)))]), self.device)
 
 
 def TRAIN(args, bi_encoder, train_dataset, val_dataloader, val_img2txt: Dict, *, train_img2txt: Optional[Dict] = None,

@@ -43,6 +43,61 @@ class _NumpyIndexFlatIP:
         return scores, labels
 
 
+class FakeLmdb:
+    """In-memory stand-in for the `lmdb` package (lmdb==0.97, DVL.yml:101; not installed): ``open(path)`` serves the key/value dict
+    registered for that path — exactly the calls the reference makes (uniter_model/data/data.py:73-76,93,105,119,124,143-146,160:
+    ``lmdb.open(...)``, ``env.begin(buffers=True)``, ``txn.get(key_bytes)``, ``env.close()``)."""
+    registry = {}
+
+    class _Txn:
+        def __init__(self, kv):
+            self.kv = kv
+
+        def get(self, key=None, **kw):
+            v = self.kv.get(bytes(key))
+            return None if v is None else memoryview(v)          # buffers=True hands out buffer objects
+
+    class _Env:
+        def __init__(self, kv):
+            self.kv = kv
+
+        def begin(self, **kw):
+            return FakeLmdb._Txn(self.kv)
+
+        def close(self):
+            pass
+
+    @classmethod
+    def open(cls, path, **kw):
+        import os
+        return cls._Env(cls.registry[os.path.normpath(path)])
+
+
+def msgpack_numpy_patch():
+    """Restatement of what ``msgpack_numpy.patch()`` (msgpack-numpy==0.4.6.post0, DVL.yml:109; not installed) does for the calls the
+    reference makes: ``msgpack.loads`` decodes that package's ndarray dicts {nd: True, type: dtype.str, kind: '', shape, data} (keys
+    bytes or str).  Third-party format -> "parity unpinned" at this boundary, like faiss."""
+    import msgpack
+
+    def hook(obj):
+        nd = obj.get('nd', obj.get(b'nd'))
+        if nd is True:
+            t = obj.get('type', obj.get(b'type'))
+            t = t.decode() if isinstance(t, bytes) else t
+            return np.frombuffer(obj.get('data', obj.get(b'data')), dtype=np.dtype(t)).reshape(obj.get('shape', obj.get(b'shape')))
+        return obj
+
+    if getattr(msgpack.loads, '_ldot_np', False):
+        return
+    orig = msgpack.unpackb
+
+    def loads(packed, **kw):
+        kw.setdefault('object_hook', hook)
+        return orig(bytes(packed), **kw)
+    loads._ldot_np = True
+    msgpack.loads = msgpack.unpackb = loads
+
+
 def install():
     if REF_ROOT not in sys.path:
         sys.path.insert(0, REF_ROOT)
@@ -72,11 +127,11 @@ def install():
     # faiss
     mod('faiss', IndexFlatIP=_NumpyIndexFlatIP)
     # data deps
-    mod('lmdb')
+    mod('lmdb', open=FakeLmdb.open)
     mod('lz4')
     mod('lz4.frame', compress=lambda b: b, decompress=lambda b: b)
     sys.modules['lz4'].frame = sys.modules['lz4.frame']
-    mod('msgpack_numpy', patch=lambda: None)
+    mod('msgpack_numpy', patch=msgpack_numpy_patch)
     mod('toolz')
     mod('toolz.sandbox', unzip=lambda seq: zip(*seq))
     def _partition_all(n, seq):
@@ -91,3 +146,22 @@ def install():
         topt.AdamW = torch.optim.AdamW
     if 'transformers.tokenization_bert' not in sys.modules:
         mod('transformers.tokenization_bert', BertTokenizer=getattr(transformers, 'BertTokenizer', object))
+
+
+def patch_bert_encoder(ref_be):
+    """Lets the reference's ``BertEncoder`` (dvl/models/bi_encoder.py:76-128, written against transformers==2.3.0) construct under the
+    installed transformers: its ``self.init_weights()`` call is routed through ``post_init()`` (which newer PreTrainedModels need for
+    their bookkeeping and which then runs the real ``init_weights``).  Configs must carry ``return_dict=False`` (the reference unpacks
+    BertModel's output as a tuple, :110-119).  The class body — forward, [CLS] pooling, encode_proj — is the reference's own."""
+    from transformers import PreTrainedModel
+    orig = PreTrainedModel.init_weights
+
+    def shim(self):
+        if getattr(self, '_ldot_in_post', False):
+            return orig(self)
+        self._ldot_in_post = True
+        try:
+            self.post_init()
+        finally:
+            self._ldot_in_post = False
+    ref_be.BertEncoder.init_weights = shim

@@ -16,6 +16,11 @@ Golden sets:
                      + state_dict key/shape manifest of the real config (checkpoint surface)
   G6 config surface  parse_with_config                dvl/options.py:96-109
   G7 indexer wrapper DenseFlatIndexer                 dvl/indexer/faiss_indexers.py:63-87 (numpy IndexFlatIP stand-in)
+  G8 DB readers      TxtTokLmdb / DetectFeatLmdb / ItmFastDataset.new_epoch + __getitem__ / itm_fast_collate
+                                                       uniter_model/data/data.py:44-125,177-246 ; dvl/data/itm.py:30-122,203-288
+                     (the reference's own classes over an in-memory stand-in for the lmdb container)
+  G9 text tower      BertEncoder.forward              dvl/models/bi_encoder.py:76-128 (the reference class over the installed
+                     transformers.BertModel): small seeded model -> outputs + state_dict; key/shape manifest at bert-base-cased size
 """
 import argparse
 import json
@@ -358,7 +363,180 @@ def g7_indexer():
     json.dump(dict(ids=[i for i, _ in data], results=out), open(os.path.join(OUT, 'g7_indexer.json'), 'w'))
 
 
+# ------------------------------------------------------------------ G8
+class FakeTokenizer:
+    """stands in for BertTokenizer in the caption branch (dvl/data/itm.py:92-96,113-115): only encode / cls / sep are used"""
+    cls_token_id, sep_token_id = 101, 102
+
+    def encode(self, text, add_special_tokens=False):
+        return [200 + (sum(map(ord, w)) % 300) for w in text.split()]
+
+
+def _flatten_batch(b):
+    """collated batch dict -> {dotted key: ndarray} + the python-level fields"""
+    arrs, meta = {}, {}
+    for k, v in b.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                if vv is None:
+                    meta[f'{k}.{kk}'] = None
+                else:
+                    arrs[f'{k}.{kk}'] = vv.numpy()
+        else:
+            meta[k] = v
+    return arrs, meta
+
+
+def g8_itm_data():
+    import io
+    import tempfile
+    import msgpack
+    import dvl.data.itm as ref_itm
+    import uniter_model.data.data as ref_data
+    rng = np.random.default_rng(808)
+    FD, n_img, cpi = 16, 9, 4                       # small feature width: the readers / collate never look at it
+    conf_th, max_bb, min_bb = 0.2, 9, 4
+    imgs, nbb = {}, {}
+    for i in range(n_img):
+        f = f'img_{i:03d}.npz'
+        n = int(rng.integers(5, 13))
+        conf = rng.uniform(0.0, 1.0, n).astype(np.float16)
+        imgs[f] = dict(features=rng.standard_normal((n, FD)).astype(np.float16),
+                       norm_bb=rng.uniform(0, 1, (n, 6)).astype(np.float16), conf=conf)
+        nbb[f] = int(min(max_bb, max(min_bb, int((conf > conf_th).sum()))))
+        nbb[f] = min(nbb[f], n)                      # (a prepro'd nbb never exceeds the stored regions)
+    examples, id2len, txt2img, img2txts = {}, {}, {}, {}
+    for i in range(n_img):
+        f = f'img_{i:03d}.npz'
+        for c in range(cpi):
+            tid = f'{i * cpi + c}'
+            n_tok = int(rng.integers(3, 16))
+            examples[tid] = dict(id=tid, img_fname=f, sent=f'caption {c} of {i}',
+                                 input_ids=[int(t) for t in rng.integers(1000, 28000, n_tok)])
+            id2len[tid], txt2img[tid] = n_tok, f
+            img2txts.setdefault(f, []).append(tid)
+    meta = {'CLS': 101, 'SEP': 102, 'MASK': 103, 'v_range': [106, 28996]}
+    max_txt_len = 12
+    kept = [t for t in examples if id2len[t] <= max_txt_len]
+    hn_img = {t: [f for f in imgs if f != txt2img[t]][int(t) % 3:][:3] for t in kept}
+    hn_txt = {f: [t for t in kept if txt2img[t] != f][i::5][:3] for i, f in enumerate(imgs)}
+    img_meta = {f: {'caption_multiple': [f'a photo number {i}', f'second caption for {f[:7]} with more words']}
+                for i, f in enumerate(imgs)}
+
+    tmp = tempfile.mkdtemp()
+    txt_dir, img_dir = os.path.join(tmp, 'txt.db'), os.path.join(tmp, 'img')
+    os.makedirs(txt_dir)
+    os.makedirs(img_dir)
+    for name, obj in (('id2len', id2len), ('txt2img', txt2img), ('img2txts', img2txts), ('meta', meta)):
+        json.dump(obj, open(os.path.join(txt_dir, name + '.json'), 'w'))
+    json.dump(nbb, open(os.path.join(img_dir, f'nbb_th{conf_th}_max{max_bb}_min{min_bb}.json'), 'w'))
+    # the container stand-in: text values are msgpack (lz4.frame is stubbed to the identity on the reference side; the build's reader
+    # gets real LZ4 frames of the same msgpack bytes), image values npz archives / msgpack_numpy dicts
+    reg = _ref_stubs.FakeLmdb.registry
+    reg[os.path.normpath(txt_dir)] = {k.encode(): msgpack.dumps(v, use_bin_type=True) for k, v in examples.items()}
+    npz = {}
+    for f, d in imgs.items():
+        buf = io.BytesIO()
+        np.savez_compressed(buf, **d)
+        npz[f.encode()] = buf.getvalue()
+    reg[os.path.normpath(f'{img_dir}/feat_th{conf_th}_max{max_bb}_min{min_bb}_compressed')] = npz
+
+    def mnp(o):                                      # msgpack-numpy 0.4.6's ndarray layout (bytes keys, use_bin_type)
+        if isinstance(o, np.ndarray):
+            return {b'nd': True, b'type': o.dtype.str, b'kind': b'', b'shape': list(o.shape), b'data': o.tobytes()}
+        raise TypeError
+    reg[os.path.normpath(f'{img_dir}/feat_th{conf_th}_max{max_bb}_min{min_bb}')] = {
+        f.encode(): msgpack.dumps(d, default=mnp, use_bin_type=True) for f, d in imgs.items()}
+
+    out_arr, out_meta = {}, {}
+    for flavour, compress in (('npz', True), ('msgpack', False)):
+        txt_db = ref_data.TxtTokLmdb(txt_dir, max_txt_len)
+        img_db = ref_data.DetectFeatLmdb(img_dir, conf_th, max_bb, min_bb, 36, compress)
+        assert txt_db.ids == kept
+        f0 = list(imgs)[2]
+        feat, bb = img_db[f0]
+        dump = img_db.get_dump(f0)
+        out_arr[f'{flavour}.getitem.feat'], out_arr[f'{flavour}.getitem.bb'] = feat.numpy(), bb.numpy()
+        for k, v in dump.items():
+            out_arr[f'{flavour}.get_dump.{k}'] = np.asarray(v)
+        out_meta[f'{flavour}.getitem.fname'] = f0
+        cases = {}
+        # (a) evaluation style: no negatives, consecutive items
+        ds = ref_itm.ItmFastDataset(txt_db, img_db, num_hard_negatives=2)
+        ds.new_epoch()
+        cases['eval'] = ([0, 1, 2, 3, 4, 5], ds)
+        # (b) training style: nh = 2 of each kind per item, arbitrary item order
+        ds2 = ref_itm.ItmFastDataset(txt_db, img_db, num_hard_negatives=2)
+        ds2.new_epoch(hn_img, hn_txt)
+        cases['train'] = ([7, 0, 11, 3, 20], ds2)
+        # (c) with the caption branch (img_meta + tokenizer)
+        ds3 = ref_itm.ItmFastDataset(txt_db, img_db, num_hard_negatives=1, img_meta=img_meta, tokenizer=FakeTokenizer())
+        ds3.new_epoch(hn_img, hn_txt)
+        cases['caps'] = ([2, 9, 4], ds3)
+        for cname, (idx, d) in cases.items():
+            batch = ref_itm.itm_fast_collate([d[i] for i in idx])
+            arrs, m = _flatten_batch(batch)
+            for k, v in arrs.items():
+                out_arr[f'{flavour}.{cname}.{k}'] = v
+            m.update(items=idx, lens=[int(x) for x in d.lens], ids=list(d.ids), train_imgs=list(d.train_imgs),
+                     all_imgs=sorted(d.all_imgs))
+            out_meta[f'{flavour}.{cname}'] = m
+    inputs = dict(feat_dim=FD, conf_th=conf_th, max_bb=max_bb, min_bb=min_bb, max_txt_len=max_txt_len, examples=examples,
+                  id2len=id2len, txt2img=txt2img, img2txts=img2txts, meta=meta, nbb=nbb, hn_img=hn_img, hn_txt=hn_txt,
+                  img_meta=img_meta, kept=kept)
+    json.dump(dict(inputs=inputs, expected=out_meta), open(os.path.join(OUT, 'g8_itm_data.json'), 'w'))
+    img_arr = {f'img.{f}.{k}': v for f, d in imgs.items() for k, v in d.items()}
+    np.savez_compressed(os.path.join(OUT, 'g8_itm_data.npz'), **img_arr, **out_arr)
+
+
+# ------------------------------------------------------------------ G9
+def g9_text_tower():
+    """The reference's text tower: ``BertEncoder`` = transformers.BertModel + [CLS] pooling + encode_proj
+    (dvl/models/bi_encoder.py:76-128; written for transformers==2.3.0, DVL.yml:180 — constructed here with the shim of
+    _ref_stubs.patch_bert_encoder; the BertModel of the installed transformers has the same parameter names and math)."""
+    from transformers import BertConfig
+    _ref_stubs.patch_bert_encoder(ref_be)
+    torch.manual_seed(9)
+    small = dict(vocab_size=120, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                 hidden_act='gelu', hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, max_position_embeddings=64,
+                 type_vocab_size=2, initializer_range=0.02)
+    cfg = BertConfig(return_dict=False, **small)
+    cfg.output_hidden_states = False
+    model = ref_be.BertEncoder(cfg, project_dim=32).eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():        # non-trivial LayerNorm affines and biases
+            if 'LayerNorm' in n or n.endswith('.bias') or 'encode_proj' in n:
+                p.add_(torch.randn_like(p) * 0.05)
+    g = torch.Generator().manual_seed(99)
+    B, L = 4, 11
+    ids = torch.randint(1, 120, (B, L), generator=g)
+    attn = torch.ones(B, L, dtype=torch.long)
+    attn[1, 7:] = 0
+    attn[3, 4:] = 0
+    ids = ids * attn                                 # pad id 0 like pad_sequence in the collate
+    pos = torch.arange(0, L, dtype=torch.long).unsqueeze(0)
+    with torch.no_grad():
+        seq, pooled, hidden = model(ids, attn, pos)
+    assert hidden is None and model.get_out_size is not None
+    sd = {('sd__' + k): v.numpy() for k, v in model.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, 'g9_text_tower_small.npz'), cfg=json.dumps(small), project_dim=np.int64(32),
+                        input_ids=ids.numpy(), attention_mask=attn.numpy(), position_ids=pos.numpy(), seq=seq.numpy(),
+                        pooled=pooled.numpy(), **sd)
+    # strict-load surface of the real text tower: BertEncoder at bert-base-cased size (vocab 28996), as BiEncoder.txt_model holds it
+    with torch.device('meta'):
+        rcfg = BertConfig(vocab_size=28996, return_dict=False)
+        rcfg.output_hidden_states = False
+        real = ref_be.BertEncoder(rcfg, project_dim=768)
+    manifest = {('txt_model.' + k): list(v.shape) for k, v in real.state_dict().items()}
+    json.dump(manifest, open(os.path.join(OUT, 'g9_txt_tower_manifest.json'), 'w'), indent=0)
+
+
 if __name__ == '__main__':
+    only = set(sys.argv[1:])
+    if only:
+        for name in sorted(only):
+            globals()[name]()
+        sys.exit(0)
     g1_loss()
     g2_train_step()
     g3_recall()
@@ -366,5 +544,7 @@ if __name__ == '__main__':
     g5_pool_proj()
     g6_config()
     g7_indexer()
+    g8_itm_data()
+    g9_text_tower()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -3,6 +3,7 @@
 negatives, batch layout.  The DB is written by tools/make_db_fixture.py (committed) into tmp_path."""
 import importlib.util
 import os
+from struct import error as struct_error
 
 import numpy as np
 import pytest
@@ -36,11 +37,63 @@ def test_lz4_frame_roundtrip_and_known_frames():
     assert D.lz4_frame_decompress(ref) == b'hello ' * 5 + b'hello'
     # the same payload as a STORED block (high bit of the block size) and with the content-size field present (FLG 0x68)
     payload = b'hello ' * 5 + b'hello'
-    stored = bytes.fromhex('04224d18' '6870') + (35).to_bytes(8, 'little') + b'\x00' + (35 | 0x80000000).to_bytes(4, 'little') + \
-        payload + bytes(4)
+    desc = bytes.fromhex('6870') + (35).to_bytes(8, 'little')
+    hc = bytes([(D.xxh32(desc) >> 8) & 0xff])                  # header checksum = second byte of XXH32(descriptor) (xxh32 is pinned below)
+    stored = bytes.fromhex('04224d18') + desc + hc + (35 | 0x80000000).to_bytes(4, 'little') + payload + bytes(4)
     assert D.lz4_frame_decompress(stored) == payload
     with pytest.raises(ValueError):
         D.lz4_frame_decompress(b'not a frame at all')
+
+
+def test_lz4_frames_written_by_liblz4(golden_dir):
+    """Frames produced by the REAL liblz4 (oracle/gen_lz4_vectors.py: LZ4F_compressFrame with explicit preferences — python-lz4's
+    defaults, linked 64 KiB blocks with matches across block borders, independent blocks, block + content checksums, HC level, stored
+    blocks, empty input) decode to their payloads; a flipped bit anywhere in a checksummed frame is detected."""
+    import base64
+    import hashlib
+    import json
+    g = json.load(open(os.path.join(golden_dir, 'lz4_frames.json')))
+    assert len(g['vectors']) >= 8
+    for v in g['vectors']:
+        frame = base64.b64decode(v['frame_b64'])
+        out = D.lz4_frame_decompress(frame)
+        assert len(out) == v['length'] and hashlib.sha256(out).hexdigest() == v['sha256'], v['name']
+        if 'payload_b64' in v:
+            assert out == base64.b64decode(v['payload_b64'])
+        if v['prefs'].get('content_checksum') and v['length']:
+            bad = bytearray(frame)
+            bad[len(bad) // 2] ^= 0x10
+            with pytest.raises((ValueError, IndexError, struct_error)):
+                D.lz4_frame_decompress(bytes(bad))
+    rec = next(v for v in g['vectors'] if v['name'] == 'record_default')
+    import msgpack
+    ex = msgpack.loads(D.lz4_frame_decompress(base64.b64decode(rec['frame_b64'])), raw=False)
+    assert ex['img_fname'] == 'flickr30k_000000001234.npz' and len(ex['input_ids']) == 17
+
+
+def test_xxh32_known_answers_and_library():
+    # published XXH32 test values (xxHash repository's sanity checks): empty input, seed 0 / seed 0x9E3779B1
+    assert D.xxh32(b'') == 0x02CC5D05 and D.xxh32(b'', 0x9E3779B1) == 0x36B78AE7
+    xxhash = pytest.importorskip('xxhash')
+    rng = np.random.default_rng(1)
+    for n in (1, 3, 4, 15, 16, 17, 31, 32, 33, 100, 4099):
+        b = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        assert D.xxh32(b) == xxhash.xxh32(b).intdigest() and D.xxh32(b, 77) == xxhash.xxh32(b, seed=77).intdigest()
+
+
+def test_frames_written_here_are_read_by_liblz4():
+    """the other direction, live, where the system's liblz4 is present (it is in this image): what lz4_frame_compress writes
+    (fixtures, converted DBs) is a valid frame for the real library"""
+    import ctypes.util
+    if ctypes.util.find_library('lz4') is None:
+        pytest.skip('no system liblz4')
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('gen_lz4_vectors', os.path.join(ROOT, 'oracle', 'gen_lz4_vectors.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lib = mod.liblz4()
+    for name, payload in mod.payloads().items():
+        assert mod.decompress(lib, D.lz4_frame_compress(payload), len(payload) + 1) == payload, name
 
 
 def test_text_db_reader(tmp_path):

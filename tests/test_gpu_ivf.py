@@ -241,3 +241,27 @@ def test_ivf_search_query_dtypes_and_normalisation():
     s_m, l_m = call(qn, L.F32, 0)
     assert torch.equal(l_n, l_m)
     assert float((s_n - s_m).abs().max()) < 1e-5
+
+
+def test_hnsw_surface_approximate_roundtrip(tmp_path):
+    """DenseHNSWFlatIndexer(approximate=True).serialize / deserialize_from carry the inverted file (list offsets, centroids, phi,
+    nprobe), not just the list-sorted rows: a loaded index answers like the one that was saved and refuses re-indexing."""
+    import torch
+    from lightningdot_amd.indexer import DenseHNSWFlatIndexer
+    g = torch.Generator(device='cpu').manual_seed(3)
+    cent = torch.randn(40, 64, generator=g) * 3
+    x = (cent[torch.randint(0, 40, (6000,), generator=g)] + torch.randn(6000, 64, generator=g)).cuda()
+    q = x[::300] + 0.1 * torch.randn(20, 64, generator=g).cuda()
+    a = DenseHNSWFlatIndexer(64, ef_search=32, approximate=True)
+    a.index_tensor([f'r{i}' for i in range(6000)], x)
+    want = a.search_knn(q, 10)
+    a.serialize(str(tmp_path / 'apx'))
+    b = DenseHNSWFlatIndexer(64, ef_search=32, approximate=True)
+    b.deserialize_from(str(tmp_path / 'apx'))
+    got = b.search_knn(q, 10)
+    assert [w[0] for w in want] == [g_[0] for g_ in got]
+    np.testing.assert_allclose(np.stack([w[1] for w in want]), np.stack([g_[1] for g_ in got]), rtol=1e-5, atol=1e-3)
+    d, lab = b.search_knn_tensors(q, 10)
+    assert [[b.index_id_to_db_id[i] for i in row] for row in lab.cpu().tolist()] == [g_[0] for g_ in got]
+    with pytest.raises(RuntimeError):
+        b.index_tensor(['x'], x[:1])

@@ -115,3 +115,106 @@ def test_mining_at_flickr_train_scale():
     for i in ('i0', 'i28999'):
         assert len(hn_txt[i]) == 3 and not (set(hn_txt[i]) & set(img2txt[i]))
     assert dt < 4.0, dt
+
+
+def test_harness_and_mining_with_hnsw_index_flag():
+    """args.hnsw_index=True (dvl/trainer.py:122-127): the harness and the mining go through DenseHNSWFlatIndexer.search_knn_tensors;
+    exact-backed, so rank lists and recalls equal the flat run's."""
+    import torch
+    from lightningdot_amd.harness import eval_model_on_dataloader
+    from lightningdot_amd.hn import sampled_hard_negatives
+    from lightningdot_amd.indexer import DenseHNSWFlatIndexer
+    from lightningdot_amd.synthetic import s2_embeddings
+    img, txt = s2_embeddings(50, 64, 5, seed=11, device='cuda')
+    batches, img2txt, txt2img = _loader(img, txt, 5, 64)
+    out = {}
+    for hnsw in (False, True):
+        args = types.SimpleNamespace(hnsw_index=hnsw, vector_size=64, caption_score_weight=0.0, num_hard_negatives=2)
+        loss, ratio, (ix_img, ix_txt), recalls, (rank_txt, rank_img) = eval_model_on_dataloader(FakeEncoder(), batches, args, img2txt, 20)
+        out[hnsw] = (loss, ratio, recalls, {k: rank_txt[k] for k in rank_txt}, {k: rank_img[k] for k in rank_img})
+        if hnsw:
+            assert isinstance(ix_img, DenseHNSWFlatIndexer) and isinstance(ix_txt, DenseHNSWFlatIndexer)
+            d, lab = ix_img.search_knn_tensors(txt[:9], 7)                  # squared L2 in the augmented space, ascending
+            assert d.is_cuda and lab.is_cuda and bool((d[:, 1:] >= d[:, :-1]).all())
+            host = ix_img.search_knn(txt[:9].cpu().numpy(), 7)
+            np.testing.assert_allclose(np.stack([h[1] for h in host]), d.cpu().numpy(), rtol=1e-5, atol=1e-3)
+            assert [h[0] for h in host] == [[ix_img.index_id_to_db_id[i] for i in row] for row in lab.cpu().tolist()]
+        g = torch.Generator(device='cuda').manual_seed(2)
+        hn_txt, hn_img = sampled_hard_negatives([batches], args, FakeEncoder(), img2txt, txt2img, generator=g)
+        assert set(hn_img) == set(txt2img) and all(len(v) == 2 for v in hn_txt.values())
+    assert out[False] == out[True]
+
+
+def test_rank_dicts_hold_the_last_occurrence_of_duplicated_query_ids():
+    """dvl/trainer.py:168,171: {id: result} comprehensions keep the result of an id's LAST occurrence; the harness searches only that
+    occurrence.  Image vectors that differ between occurrences of the same id make the rule observable."""
+    import torch
+    from oracle import oracle_np as O
+    from lightningdot_amd.harness import eval_model_on_dataloader
+    from lightningdot_amd.synthetic import s2_embeddings
+    img, txt = s2_embeddings(30, 64, 5, seed=4, device='cuda')
+    batches, img2txt, txt2img = _loader(img, txt, 5, 40)
+    g = torch.Generator(device='cpu').manual_seed(0)
+    for b in batches:                                              # every occurrence of an image gets its own perturbation
+        b['_ctx'] = b['_ctx'] + 0.3 * torch.randn(b['_ctx'].shape, generator=g).cuda()
+    args = types.SimpleNamespace(hnsw_index=False, vector_size=64, caption_score_weight=0.0)
+    _, _, (ix_img, ix_txt), _, (rank_txt, rank_img) = eval_model_on_dataloader(FakeEncoder(), batches, args, img2txt, 10)
+    allq = torch.cat([b['_ctx'] for b in batches]).cpu().numpy()
+    ids = sum([b['img_fname'] for b in batches], [])
+    last = {k: i for i, k in enumerate(ids)}
+    ref = O.FlatIP(64)
+    ref.add(ix_txt.index.get_rows(0, ix_txt.index.ntotal))
+    _, el = ref.search(allq, 10)                                   # the reference searches EVERY occurrence ...
+    want = {k: [ix_txt.index_id_to_db_id[j] for j in el[i]] for k, i in last.items()}     # ... and keeps the last one
+    assert list(rank_img) == list(dict.fromkeys(ids))
+    assert {k: rank_img[k] for k in rank_img} == want
+
+
+def test_reranker_candidate_export_on_device_equals_host_loops():
+    """rerank.py:168-204,256-290: first-stage candidates at top-100 both ways + re-ranking of the first {10, 20, 50, 100} candidates
+    with an external scorer (a fake score matrix): the device path (label tensors, gather + topk) gives the recalls of the host
+    loops that mirror the reference."""
+    import torch
+    from lightningdot_amd.harness import eval_model_on_dataloader
+    from lightningdot_amd.rerank import (RECALL_TOPS, first_stage_candidates, first_stage_rankings, rerank_recall,
+                                         rerank_recall_device)
+    from lightningdot_amd.synthetic import s2_embeddings
+    img, txt = s2_embeddings(150, 64, 5, seed=13, device='cuda')
+    txt = txt + 1.5 * torch.randn(txt.shape, generator=torch.Generator().manual_seed(1)).cuda()      # make the first stage imperfect
+    batches, img2txt, txt2img = _loader(img, txt, 5, 128)
+    args = types.SimpleNamespace(hnsw_index=False, vector_size=64, caption_score_weight=0.0)
+    _, _, (ix_img, ix_txt), _, _ = eval_model_on_dataloader(FakeEncoder(), batches, args, img2txt, no_eval=True)   # rerank.py:149-150
+    host = first_stage_rankings(FakeEncoder(), ix_img, ix_txt, batches, img2txt, txt2img)
+    devr = first_stage_candidates(FakeEncoder(), ix_img, ix_txt, batches, img2txt, txt2img)
+    assert devr['labels_img'].shape == (750, 100) and devr['labels_txt'].shape == (750, 100)
+    assert devr['recall_img'] == host[2] and devr['recall_txt'] == host[3] and devr['total_len'] == host[4]
+    assert 0 < host[2][1] < host[2][100]                                   # (the first stage is neither perfect nor useless)
+    # the exported candidate lists are the host path's lists
+    lab = devr['labels_img'].cpu().tolist()
+    assert all(host[0][t] == [ix_img.index_id_to_db_id[r] for r in lab[j]] for j, t in enumerate(devr['txt_ids']))
+    # external scorer: a fixed random matrix with a bonus on the true pairs (a cross-encoder that is better than the first stage)
+    g = torch.Generator().manual_seed(7)
+    n_txt, n_img = len(ix_txt.index_id_to_db_id), len(ix_img.index_id_to_db_id)
+    mat = torch.randn(n_txt, n_img, generator=g)
+    txt_row = {k: r for r, k in enumerate(ix_txt.index_id_to_db_id)}
+    img_row = {k: r for r, k in enumerate(ix_img.index_id_to_db_id)}
+    for t, i in txt2img.items():
+        mat[txt_row[t], img_row[i]] += 8.0
+    # image retrieval: query = text, db = images
+    q_rows = torch.as_tensor([txt_row[t] for t in devr['txt_ids']])
+    got_ir = rerank_recall_device(devr['labels_img'], mat[q_rows].cuda(), devr['pos_img'])
+    want_ir = rerank_recall(host[0], lambda t, i: float(mat[txt_row[t], img_row[i]]), lambda t, ids: txt2img[t] in ids)
+    assert got_ir == want_ir
+    # a scorer that always ranks the true pair first turns the first stage's R@threshold into R@1 (rerank.py's point)
+    assert all(got_ir[t][1] == host[2][t] / 750 for t in (10, 20, 50, 100)) and got_ir[100][1] > host[2][1] / 750
+    # text retrieval: query = image (every occurrence, like the reference's loop), db = texts
+    q_rows = torch.as_tensor([img_row[i] for i in devr['img_ids']])
+    got_tr = rerank_recall_device(devr['labels_txt'], mat.T[q_rows].contiguous().cuda(), devr['pos_txt'], denominator=150)
+    want_tr = rerank_recall(host[1], lambda i, t: float(mat[txt_row[t], img_row[i]]), lambda i, ids: any(t in ids for t in img2txt[i]),
+                            denominator=150)
+    # (host[1] holds one list per distinct image = the last occurrence; all occurrences of an image carry the same vector here)
+    uniq_last = {i: j for j, i in enumerate(devr['img_ids'])}
+    sel = torch.as_tensor(list(uniq_last.values()))
+    got_tr_u = rerank_recall_device(devr['labels_txt'][sel.cuda()], mat.T[q_rows[sel]].contiguous().cuda(), devr['pos_txt'][sel.cuda()],
+                                    denominator=150)
+    assert got_tr_u == want_tr and all(abs(got_tr[t][k] - 5 * want_tr[t][k]) < 1e-9 for t in got_tr for k in (1, 5, 10))

@@ -156,6 +156,34 @@ def test_fused_adversarial_order_falls_back(L):
     assert_topk_matches(q, x, s, l, 100)
 
 
+def test_overflow_recovery_redoes_only_the_flagged_queries(L):
+    """Rows stored in cluster order (what the inverted-file index keeps): a contiguous block of 40 000 similar rows overflows the
+    lane-private pools of the few queries that match it.  Only those queries are searched again — one fused launch with their
+    (valid) thresholds, no dense pass at all — and the results equal the dense path's bit for bit."""
+    rng = np.random.default_rng(33)
+    n, d, nq, nb = 200000, 64, 2048, 24
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    v = rng.standard_normal(d).astype(np.float32)
+    v *= 4.0 / np.linalg.norm(v)
+    x[100000:140000] += v                                   # the block: 104 tiles of 384 rows = more than 3 per row slice
+    q, g = planted_queries(x, nq)
+    q[:nb] = v + 0.7 * rng.standard_normal((nb, d)).astype(np.float32)     # queries that match every row of the block
+    ix = _index(x, mode=L.MODE_FUSED, warm_rows=4096)
+    s, l = ix.search(q, 100)
+    st = ix.last_stats()
+    assert nb <= st['overflowed_queries'] < 4 * nb, st
+    assert st['dense_pairs'] == 4096 * nq, st               # the warm-up only: nobody took the dense path
+    assert st['fused_pairs'] == (n - 4096) * nq + n * st['overflowed_queries'], st
+    assert_topk_matches(q, x, s, l, 100)
+    ixd = _index(x, mode=L.MODE_DENSE)
+    sd, ld = ixd.search(q, 100)
+    np.testing.assert_array_equal(l, ld)
+    np.testing.assert_array_equal(s, sd)
+    # a second search on the same handle (flags and counters were left clean)
+    s2, l2 = ix.search(q, 100)
+    np.testing.assert_array_equal(l2, l)
+
+
 def test_no_rescore_reports_bf16_input_scores(L):
     rng = np.random.default_rng(12)
     x = rng.standard_normal((4000, 768)).astype(np.float32)
@@ -541,6 +569,14 @@ def test_verify_flags_crowded_scores_and_escalates(L):
     ixc.set_option(L.OPT_VERIFY, 0)
     ixc.search(qc, 10, verify=True)
     assert ixc.last_escalations and ixc.last_escalations[0][1] == 40       # all 40 were re-searched with a larger margin
+    # settings made through set_option survive a verified search, and the escalation starts from the margin in force
+    ixc.set_option(L.OPT_MARGIN, 200)
+    ixc.set_option(L.OPT_VERIFY, 1)
+    ixc.search(qc, 10, verify=True)
+    assert ixc.last_escalations[0][0] == 800
+    assert ixc._opts[L.OPT_MARGIN] == 200 and ixc._opts[L.OPT_VERIFY] == 1
+    ixc.search(qc, 10)
+    assert ixc.unproven(40)[1] == 40                       # verification is still on (the user's setting), margin 200 again
 
 
 def test_last_stats_counts_filter_records(L):

@@ -200,3 +200,107 @@ def test_train_itm_loop_on_gpu(tmp_path):
     assert train_ds.neg_imgs[0] is not None and len(train_ds.neg_imgs[0]) == 2 and train_ds.txt2img[train_ds.ids[0]] not in train_ds.neg_imgs[0]
     after = torch.cat([p.detach().reshape(-1) for p in be.parameters()])
     assert float((after - before).abs().max()) > 0
+
+
+def test_text_tower_on_gpu_matches_reference_bert_encoder_golden(golden_dir):
+    """a1 on the device: golden G9 (outputs of the reference's BertEncoder over transformers.BertModel) — strict load, cuda forward
+    with the HIP [CLS] pooling branch (no_grad) and with autograd on."""
+    import json
+    import os
+    from lightningdot_amd.towers import TowerConfig, TowerEncoder
+    g = np.load(os.path.join(golden_dir, 'g9_text_tower_small.npz'))
+    enc = TowerEncoder(TowerConfig(**json.loads(str(g['cfg']))), project_dim=int(g['project_dim']), with_image=False)
+    enc.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd__')}, strict=True)
+    enc = enc.cuda().eval()
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    valid = g['attention_mask'].astype(bool)
+    with torch.no_grad():
+        seq, pooled, _ = enc(t('input_ids'), t('attention_mask'), t('position_ids'))
+    np.testing.assert_allclose(seq.cpu().numpy()[valid], g['seq'][valid], rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(pooled.cpu().numpy(), g['pooled'], rtol=1e-4, atol=5e-5)
+    _, pooled2, _ = enc(t('input_ids'), t('attention_mask'), t('position_ids'))
+    np.testing.assert_allclose(pooled2.detach().cpu().numpy(), g['pooled'], rtol=1e-4, atol=5e-5)
+
+
+def _write_small_configs(tmp_path, db, **extra):
+    import json
+    small = dict(vocab_size=28996, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                 max_position_embeddings=512, type_vocab_size=2, hidden_act='gelu', hidden_dropout_prob=0.0,
+                 attention_probs_dropout_prob=0.0, initializer_range=0.02)
+    (tmp_path / 'img_small.json').write_text(json.dumps(small))
+    cfg = dict(txt_model_config='bert-base-cased', img_model_config=str(tmp_path / 'img_small.json'), itm_global_file=None,
+               seed=42, output_dir=str(tmp_path / 'out'), max_txt_len=60, conf_th=0.2, max_bb=100, min_bb=10, num_bb=36,
+               project_dim=64, val_txt_db=str(db / 'txt_db'), val_img_db=str(db / 'img_db'), test_txt_db=str(db / 'txt_db'),
+               test_img_db=str(db / 'img_db'), project_name='itm-debug', n_workers=0, fp16=False, valid_batch_size=16)
+    cfg.update(extra)
+    (tmp_path / 'cfg.json').write_text(json.dumps(cfg))
+    return str(tmp_path / 'cfg.json')
+
+
+def _db_fixture(tmp_path, n_img, cpi):
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('make_db_fixture', os.path.join(root, 'tools', 'make_db_fixture.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    db = tmp_path / 'db'
+    return db, mod.make(str(db), n_img=n_img, cpi=cpi, seed=5)
+
+
+@pytest.mark.parametrize('compressed', [True, False])
+def test_eval_model_from_on_disk_dbs(tmp_path, capsys, compressed):
+    """f-2 -> hot path end to end (eval_itm.py:130-152): text DB (LZ4-framed msgpack records) + region-feature DB (npz / msgpack fp16) on
+    disk -> readers -> ItmFastDataset -> itm_fast_collate -> towers on cuda -> HIP pooling / loss / index / search -> Recall@k.
+    The recalls are checked against the oracle harness fed with the towers' own embeddings of the same batches."""
+    import os
+    from lightningdot_amd import data as D
+    from lightningdot_amd.eval_itm import EVAL_MODEL, db_dataloader
+    from lightningdot_amd.options import build_parser, parse_with_config
+    from lightningdot_amd.towers import BiEncoder, save_checkpoint
+    db, (examples, feats, nbb) = _db_fixture(tmp_path, 12, 3)
+    if not compressed:                                        # the 'all' flavour is keyed by the thresholded name in real DB folders
+        for ext in ('.bin', '.idx.json'):
+            os.rename(db / 'img_db' / ('all' + ext), db / 'img_db' / ('feat_th0.2_max100_min10' + ext))
+    cfg = _write_small_configs(tmp_path, db, **({'compressed_db': True} if compressed else {}))
+    args = parse_with_config(build_parser(), ['--config', cfg])
+    torch.manual_seed(1)
+    be = BiEncoder(args, project_dim=64)
+    ckdir = tmp_path / 'run_0.001_16_0_none_0.0_x'
+    ckdir.mkdir()
+    ck = save_checkpoint(be, None, None, 0, 0, str(ckdir / 'biencoder.last.pt'))
+    res = EVAL_MODEL(cfg, ck)
+    out = capsys.readouterr().out
+    n_txt = len(examples)                                     # (max_txt_len = -1 for evaluation: nothing is filtered, trainer.py:206)
+    assert set(res) == {'dev', 'test'} and f'indexed  {len(feats)} data' in out
+    # the same batches through the same towers, scored by the oracle harness
+    args.device = torch.device('cuda')
+    args.inf_minibatch_size, args.vector_size = 400, 64
+    loader, img2txt = db_dataloader(args, args.val_txt_db, args.val_img_db)
+    be = be.cuda().eval()
+    stream = []
+    for b in loader:
+        with torch.no_grad():
+            q, c, _ = be(b)
+        stream.append(dict(txt_index=b['txt_index'], img_fname=b['img_fname'], q=q.cpu().numpy(), ctx=c.cpu().numpy()))
+    assert sum(len(s['txt_index']) for s in stream) == n_txt
+    l2, a2, _, (o_txt, o_img), _ = O.eval_on_stream(stream, 64, img2txt, 100, 0.0)
+    # (EVAL_MODEL keeps the reference's naming swap: its "recall_img" is text-query -> image retrieval, eval_itm.py:143,150)
+    assert res['dev']['recall_img'] == o_txt and res['dev']['recall_txt'] == o_img
+    assert res['dev']['loss'] == pytest.approx(l2, rel=1e-4, abs=1e-5) and res['dev']['accuracy'] == a2
+    assert res['test'] == res['dev']                          # same DBs
+
+
+def test_train_itm_cli_from_on_disk_dbs(tmp_path):
+    """train_itm.main on on-disk DBs (no --synthetic): TxtTokDb / DetectFeatDb / ItmFastDataset feed one epoch of the fine-tuning
+    loop with mined hard negatives, per-epoch evaluation and checkpoints (train_itm.py:176-358)."""
+    import os
+    from lightningdot_amd.train_itm import main
+    db, (examples, feats, nbb) = _db_fixture(tmp_path, 16, 3)
+    cfg = _write_small_configs(tmp_path, db, train_txt_dbs=[str(db / 'txt_db')], train_img_dbs=[str(db / 'img_db')],
+                               train_batch_size=8, num_train_epochs=2, learning_rate=1e-3, num_hard_negatives=2,
+                               sample_init_hard_negatives=True, hard_negatives_sampling='top', compressed_db=True)
+    hist = main(['--config', cfg])
+    assert [h['epoch'] for h in hist] == [0, 1] and all(h['hard_negatives'] for h in hist)
+    assert all(np.isfinite(h['loss']) and set(h['recall']) == {1, 5, 10} for h in hist)
+    assert os.path.exists(tmp_path / 'out' / 'biencoder.last.pt')

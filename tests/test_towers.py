@@ -38,6 +38,26 @@ def test_small_tower_matches_reference_outputs(golden_dir):
     np.testing.assert_allclose(tpooled.numpy(), g['txt_pooled'], rtol=1e-4, atol=2e-5)
 
 
+def test_text_tower_matches_the_reference_bert_encoder(golden_dir):
+    """Golden G9: the reference's BertEncoder (transformers.BertModel + [CLS] pooling + encode_proj, bi_encoder.py:76-128) with seeded
+    weights -> its state_dict loads STRICTLY into TowerEncoder(with_image=False) and the outputs agree (padded batch)."""
+    g = np.load(os.path.join(golden_dir, 'g9_text_tower_small.npz'))
+    cfg = TowerConfig(**json.loads(str(g['cfg'])))
+    enc = TowerEncoder(cfg, project_dim=int(g['project_dim']), with_image=False)
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd__')}
+    res = enc.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    enc.eval()
+    t = lambda k: torch.from_numpy(g[k])
+    with torch.no_grad():
+        seq, pooled, hidden = enc(t('input_ids'), t('attention_mask'), t('position_ids'))
+    assert hidden is None
+    valid = t('attention_mask').bool()
+    # (padded QUERY positions are never read downstream; HF masks keys with finfo.min, the 2.3.0 code with -10000: same softmax)
+    np.testing.assert_allclose(seq[valid].numpy(), g['seq'][valid.numpy()], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(pooled.numpy(), g['pooled'], rtol=1e-4, atol=2e-5)
+
+
 def test_checkpoint_key_manifest_of_real_config(golden_dir):
     manifest = json.load(open(os.path.join(golden_dir, 'g5_img_tower_manifest.json')))
     with torch.device('meta'):
@@ -46,9 +66,10 @@ def test_checkpoint_key_manifest_of_real_config(golden_dir):
     mine = {k: list(v.shape) for k, v in be.state_dict().items()}
     img = {k: v for k, v in mine.items() if k.startswith('img_model.')}
     assert img == manifest                                   # every key and shape of the reference image tower
-    txt = {k[len('txt_model.'):] for k in mine if k.startswith('txt_model.')}
-    ref_txt = {k[len('img_model.'):] for k in manifest if 'img_embeddings' not in k}
-    assert txt == ref_txt                                    # HF BertModel names = image tower minus img_embeddings
+    # text tower: every key and shape of the reference's BertEncoder (HF BertModel + encode_proj) at bert-base-cased size (G9)
+    txt_manifest = json.load(open(os.path.join(golden_dir, 'g9_txt_tower_manifest.json')))
+    assert {k: v for k, v in mine.items() if k.startswith('txt_model.')} == txt_manifest
+    assert set(mine) == set(img) | set(txt_manifest)         # flickr-ft.pt['model_dict'] = exactly these two towers
     assert sum(int(np.prod(s)) for s in img.values()) == 112263424     # SURVEY §5 (measured on the reference)
 
 
