@@ -117,6 +117,7 @@ struct ldot_index {
     } compact[2];   // (level 0: the fused re-scan, level 1: the dense last resort for what overflows even then)
     bool overflow_was_narrow = false;   // the overflow the last check reported came from the narrow search's candidate buffers
     int64_t redone = 0;                 // queries searched again by the last search (ldot_index_last_stats: dense_pairs stays the dense work)
+    bool pend_done = false;             // the narrow search's finish kernel has already written the caller's outputs
     // a search in two halves (ldot_index_search_begin / _finish): what _finish needs to know
     int64_t pend_nq = 0;
     int pend_k = 0, pend_kp = 0;
@@ -548,13 +549,49 @@ static bool narrow_select_ok(const ldot_index* ix, int64_t nq, int kp) {
 // to learn.  Speculative like the fused scan: a query whose candidate buffer filled up (thousands of equal scores in a run of rows) is
 // flagged in device-mapped host memory (h_nover); the caller sees it at its synchronisation point and redoes the search with the
 // streaming selector.
-static int narrow_search(ldot_index* ix, int64_t nq, int kp, hipStream_t st) {
+// device-visible destination of a search's final top-k (device memory, or pinned host memory mapped into the device's address space)
+struct DirectOut {
+    float* scores;
+    int64_t* labels;
+    int k;
+};
+
+static int narrow_search(ldot_index* ix, int64_t nq, int kp, hipStream_t st, const DirectOut* direct = nullptr) {
     const int64_t wide = (int64_t)1 << 22;
     const int cap = kNarrowCandCap;
     int rc;
     if ((rc = narrow_buffers(ix, kNarrowMaxQueries, kNarrowMaxRuns, st))) return rc;
     uint32_t* M = (uint32_t*)ix->w_nmax.p;
     uint32_t* tk = (uint32_t*)ix->w_ntau.p;
+    // <= 16 queries over one scan chunk: everything after the scan is ONE launch (narrow_finish_kernel: threshold, collect, top-k', exact
+    // re-score, final order, output) instead of threshold + collect + final + re-score kernels — 38 -> ~12 us on the GPU for one query
+    {
+        int sh, nruns;
+        narrow_plan(ix->ntotal, kp, &sh, &nruns);
+        if (nq <= 16 && ix->ntotal <= wide && nruns <= 2048 && kp <= 512) {
+            const int64_t nrows = ix->ntotal, nrows_pad = round_up(nrows, 16);
+            if ((rc = ix->w_S.ensure((size_t)16 * nrows_pad * sizeof(float)))) return rc;
+            prof_begin(ix, st, 2.0 * nq * nrows * ix->d, (double)nrows * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * nrows * 4);
+            rc = launch_score_narrow(ix->w_q16b.p, ix->x16b, ix->ld16(), 0, nrows, (float*)ix->w_S.p, nrows_pad, (int)nq, M,
+                                     kNarrowMaxRuns, sh, 1, st);
+            prof_end(ix, st);
+            if (rc) return rc;
+            if ((rc = launch_narrow_finish((const float*)ix->w_S.p, 1, nrows_pad, M, kNarrowMaxRuns, nruns, 16 << sh, nrows, (int)nq,
+                                           (const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, kp,
+                                           direct ? direct->k : std::min(kp, 1), ix->rescore, (float*)ix->w_ls.p, (int32_t*)ix->w_li.p,
+                                           (float*)ix->w_tau.p, direct ? direct->scores : nullptr, direct ? direct->labels : nullptr,
+                                           ix->d_nover, st)))
+                return rc;
+            ix->stats[2] += nrows * nq;
+            ix->narrow_clean = true;
+            ix->pend_done = direct != nullptr;
+            if (ix->ntotal > 4096) {   // (kFinishCap candidates: an index that fits the buffer cannot fill it)
+                ix->overflow_pending = true;
+                ix->overflow_narrow = nq;
+            }
+            return LDOT_OK;
+        }
+    }
     for (int64_t r = 0; r < ix->ntotal; r += wide) {
         const int64_t nrows = std::min(wide, ix->ntotal - r), nrows_pad = round_up(nrows, 16);
         int sh, nruns;
@@ -687,6 +724,13 @@ static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_p
         len = len / (bm * nslices) * (bm * nslices);
         len = std::min(len, ix->ntotal - r);
         if (ix->ntotal - r - len < len / 4) len = ix->ntotal - r;   // no short tail launch (the pool bound has that slack)
+#ifdef LDOT_ABLATION
+        // LDOT_DEBUG_MAXLEN: cap on the rows of one launch (experiment: launches whose row range fits the 256 MB Infinity Cache)
+        if (const char* e = getenv("LDOT_DEBUG_MAXLEN")) {
+            const int64_t cap = atoll(e) / (bm * nslices) * (bm * nslices);
+            if (cap > 0 && len > cap) len = cap;
+        }
+#endif
         if ((rc = fused_launch_and_select(ix, q0, nq, nq_pad, kp, r, len, st))) return rc;
         ix->stats[3] += len * nq;
         r += len;
@@ -817,13 +861,14 @@ static int redo_flagged(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipS
 
 // defer_check: enqueue a fused scan speculatively and leave the overflow check to the caller's own synchronisation point
 static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k,
-                             float* tau_out, bool defer_check, hipStream_t st) {
+                             float* tau_out, bool defer_check, hipStream_t st, const DirectOut* direct = nullptr) {
     LDOT_REQUIRE(ix != nullptr, LDOT_EINVAL, "index is NULL");
     LDOT_REQUIRE(nq >= 0, LDOT_EINVAL, "negative query count");
     LDOT_REQUIRE(k >= 1 && k <= kMaxK, LDOT_EINVAL, "k must be in [1, %d] (got %d)", kMaxK, k);
     LDOT_REQUIRE(dtype >= 0 && dtype <= 2, LDOT_EINVAL, "bad dtype %d", dtype);
     LDOT_REQUIRE(mem == LDOT_HOST || mem == LDOT_DEVICE, LDOT_EINVAL, "bad memory space");
     ix->pend_nq = 0;
+    ix->pend_done = false;
     ix->overflow_pending = false;
     ix->overflow_narrow = 0;
     ix->qcnt_n = 0;
@@ -863,7 +908,7 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
     if (!narrow && (rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, tau, nq, nq_pad, st))) return rc;
 
     if (narrow) {
-        if ((rc = narrow_search(ix, nq, kp, st))) return rc;
+        if ((rc = narrow_search(ix, nq, kp, st, direct))) return rc;
         if (!defer_check) {
             LDOT_HIP_CHECK(hipStreamSynchronize(st));
             if (fused_overflow_check(ix) && (rc = redo_flagged(ix, nq, nq_pad, kp, st))) return rc;
@@ -972,9 +1017,36 @@ int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dty
     hipStream_t st = (hipStream_t)stream;
     // the fused scan is enqueued speculatively and the re-score behind it: ONE synchronisation per search (host outputs need it
     // anyway; device outputs pay a 4-byte round trip) instead of one in the middle that drains the stream before the re-score
-    int rc = search_begin_impl(ix, queries, nq, dtype, mem, normalize, k, nullptr, true, st);
+    // where the final top-k may be written by a kernel directly (device memory, or pinned host memory through its device mapping):
+    // a few-query search then ends in ONE kernel after the scan (narrow_finish_kernel)
+    DirectOut direct{nullptr, nullptr, k};
+    if (nq > 0 && ix && !ix->verify) {
+        if (out_mem == LDOT_DEVICE) {
+            direct.scores = out_scores;
+            direct.labels = out_labels;
+        } else {
+            void *ms = nullptr, *ml = nullptr;
+            if (hipHostGetDevicePointer(&ms, out_scores, 0) == hipSuccess && ms && hipHostGetDevicePointer(&ml, out_labels, 0) == hipSuccess && ml) {
+                direct.scores = (float*)ms;
+                direct.labels = (int64_t*)ml;
+            }
+            (void)hipGetLastError();   // (a pageable buffer makes the query fail: not an error of this call)
+        }
+    }
+    int rc = search_begin_impl(ix, queries, nq, dtype, mem, normalize, k, nullptr, true, st, direct.scores ? &direct : nullptr);
     if (rc) return rc;
     if (ix->pend_nq == 0) return LDOT_OK;
+    if (ix->pend_done) {   // the results are on their way already; the one synchronisation of the search + the buffer-full check
+        ix->pend_done = false;
+        LDOT_HIP_CHECK(hipStreamSynchronize(st));
+        prof_collect(ix, st);
+        if (fused_overflow_check(ix)) {
+            if ((rc = redo_flagged(ix, nq, round_up(nq, kBM), ix->pend_kp, st))) return rc;
+            return search_finish_impl(ix, nullptr, out_scores, out_labels, out_mem, false, st);
+        }
+        ix->pend_nq = 0;
+        return LDOT_OK;
+    }
     const bool check = ix->overflow_pending;
     if ((rc = search_finish_impl(ix, nullptr, out_scores, out_labels, out_mem, check, st))) return rc;
     if (!check) return LDOT_OK;

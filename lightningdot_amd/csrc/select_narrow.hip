@@ -140,6 +140,182 @@ __global__ __launch_bounds__(256) void narrow_final_kernel(const uint64_t* __res
     if (threadIdx.x == 0) tau[q] = n >= kp ? desc_key_to_float((uint32_t)(keys[kp - 1] >> 32)) : -INFINITY;
 }
 
+
+// ---- <= 16 queries, one scan chunk: everything after the scan in ONE launch ---------------------------------------------------------
+// threshold + collect + top-k' + exact fp32 re-score + final order + output (+ list and threshold for callers that want them), one
+// 1024-thread workgroup per query.  The four-kernel chain above costs 38 us on the GPU for one query (8 + 5 + 9 + 16) and three launch
+// gaps — more than the scan of a 123 287-row index (37 us); here:
+//   * the threshold search runs in ONE wave (<= 2048 run maxima = 32 keys per lane): ballots + scalar popcounts, no barrier per bit;
+//   * candidates are collected into LDS by all 16 waves (the qualifying runs are few: ~k' of <= 2048);
+//   * the k' best candidates and the final order come from RANK COUNTING (every thread counts the keys that beat its own — n is a
+//     few hundred) instead of bitonic stages with barriers;
+//   * the row gather of the re-score has 16 waves x 4 rows in flight; its arithmetic is the re-score kernel's (4 fmaf chains over the
+//     columns lane*4 + 256*i, pairwise sum, xor-shuffle tree), so the scores are bit-identical to the other search paths'.
+// over[q] = 1: more candidates than kFinishCap (rows stored in cluster order) — the caller redoes the search (as for narrow_final_kernel).
+constexpr int kFinishCap = 4096;      // candidate keys in LDS (32 KiB)
+constexpr int kFinishThreads = 1024;
+
+__global__ __launch_bounds__(kFinishThreads) void narrow_finish_kernel(
+    const float* __restrict__ S, int tiled_qg, int64_t lds_elems, uint32_t* __restrict__ M, int64_t ldm, int nruns, int run_rows,
+    int64_t nrows, const float* __restrict__ q32, int64_t ldq, const float* __restrict__ x32, int64_t ldx, int dpad, int kp, int k,
+    int do_rescore, float* __restrict__ list_s, int32_t* __restrict__ list_i, float* __restrict__ tau_out, float* __restrict__ out_s,
+    int64_t* __restrict__ out_l, int32_t* __restrict__ over) {
+    __shared__ __attribute__((aligned(16))) uint64_t cand[kFinishCap];
+    __shared__ __attribute__((aligned(16))) uint64_t best[1024];       // the k' best candidates, then their exact keys (kp <= 512)
+    __shared__ uint32_t tk_sh;
+    __shared__ int n_sh;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* Mq = M + (int64_t)q * ldm;
+    // ---- 1. threshold key: k'-th largest run maximum (wave 0; the other waves wait at the barrier) ------------------------------
+    if (tid == 0) n_sh = 0;
+    if (wave == 0) {
+        uint32_t res = 0xffffffffu;                     // fewer runs than list slots: every row is a candidate
+        if (nruns >= kp) {
+            uint32_t key[32];
+#pragma unroll
+            for (int v = 0; v < 32; ++v) {
+                const int r = v * 64 + lane;
+                key[v] = r < nruns ? ~Mq[r] : 0xffffffffu;
+            }
+            constexpr int kTauBits = 20;                // (as narrow_tau_kernel: the low 12 bits only lower the threshold by 2^-9 relative)
+            res = (1u << (32 - kTauBits)) - 1u;
+            for (int bit = 31; bit >= 32 - kTauBits; --bit) {
+                const uint32_t test = res | ((1u << bit) - 1u);
+                int cnt = 0;
+#pragma unroll
+                for (int v = 0; v < 32; ++v) cnt += __popcll(__ballot(key[v] <= test));
+                if (cnt < kp) res |= 1u << bit;
+            }
+        }
+        if (lane == 0) tk_sh = res;
+    }
+    __syncthreads();
+    const uint32_t tk = tk_sh;
+    // ---- 2. collect: a wave takes every 16th run; qualifying runs are scanned 256 rows at a time ----------------------------------
+    const float* s_row = tiled_qg ? S + ((q >> 4) * 256 + (q & 15) * 16) : S + (int64_t)q * lds_elems;
+    const int64_t tile_stride = (int64_t)tiled_qg * 256;
+    for (int r0 = wave * 64; r0 < nruns; r0 += 16 * 64) {
+        bool pass = false;
+        if (r0 + lane < nruns) {
+            pass = ~Mq[r0 + lane] <= tk;
+            Mq[r0 + lane] = 0;                          // (left zero for the next scan)
+        }
+        unsigned long long runs = __ballot(pass);
+        while (runs) {
+            const int r = r0 + __ffsll((long long)runs) - 1;
+            runs &= runs - 1;
+            const int64_t c0 = (int64_t)r * run_rows;
+            const int64_t c1 = c0 + run_rows < nrows ? c0 + run_rows : nrows;
+            for (int64_t cb = c0; cb < c1; cb += 256) {
+                float sv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t c = cb + u * 64 + lane;
+                    sv[u] = c < c1 ? (tiled_qg ? s_row[(c >> 4) * tile_stride + (c & 15)] : s_row[c]) : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t c = cb + u * 64 + lane;
+                    const bool hit = c < c1 && desc_key(sv[u]) <= tk;
+                    const unsigned long long hm = __ballot(hit);
+                    if (hm) {
+                        const int leader = __ffsll((long long)hm) - 1;
+                        int base = 0;
+                        if (lane == leader) base = atomicAdd(&n_sh, __popcll(hm));
+                        base = __shfl(base, leader);
+                        const int pos = base + __popcll(hm & ((1ull << lane) - 1ull));
+                        if (hit && pos < kFinishCap) cand[pos] = ((uint64_t)desc_key(sv[u]) << 32) | (uint32_t)c;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    int n = n_sh;
+    if (tid == 0) over[q] = n > kFinishCap ? 1 : 0;
+    if (n > kFinishCap) return;                         // (uniform) the caller redoes the search
+    // ---- 3. the k' best candidates by (bf16-input score desc, row asc): rank counting ---------------------------------------------
+    for (int i = tid; i < 1024; i += kFinishThreads) best[i] = ~0ull;
+    __syncthreads();
+    for (int i = tid; i < n; i += kFinishThreads) {
+        const uint64_t mine = cand[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += cand[j] < mine;   // (keys are distinct: the row is part of the key)
+        if (rank < kp) best[rank] = mine;
+    }
+    __syncthreads();
+    const int m = n < kp ? n : kp;
+    if (list_s) {                                       // the running-list view of the result (threshold exchange, LDOT_OPT_VERIFY)
+        for (int i = tid; i < kp; i += kFinishThreads) {
+            const uint64_t kv = best[i];
+            list_s[(int64_t)q * kp + i] = i < m ? desc_key_to_float((uint32_t)(kv >> 32)) : LDOT_PAD_SCORE;
+            list_i[(int64_t)q * kp + i] = i < m ? (int32_t)(uint32_t)kv : -1;
+        }
+        if (tid == 0) tau_out[q] = n >= kp ? desc_key_to_float((uint32_t)(best[kp - 1] >> 32)) : -INFINITY;
+    }
+    if (!out_s) return;
+    // ---- 4. exact fp32 scores of the m candidates (the re-score kernel's arithmetic) ---------------------------------------------
+    const float* qrow = q32 + (int64_t)q * ldq;
+    constexpr int U = 4;
+    for (int e0 = wave * U; e0 < m; e0 += (kFinishThreads / 64) * U) {
+        int32_t r[U];
+        float sc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t kv = (e0 + u < m) ? best[e0 + u] : ~0ull;
+            r[u] = (e0 + u < m) ? (int32_t)(uint32_t)kv : -1;
+            sc[u] = desc_key_to_float((uint32_t)(kv >> 32));
+        }
+        if (do_rescore) {
+            float acc[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u][0] = acc[u][1] = acc[u][2] = acc[u][3] = 0.f;
+            for (int c = lane * 4; c < dpad; c += 256) {
+                const f32x4 qv = *(const f32x4*)(qrow + c);
+                f32x4 xv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    xv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (r[u] >= 0) xv[u] = *(const f32x4*)(x32 + (int64_t)r[u] * ldx + c);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    acc[u][0] = fmaf(xv[u][0], qv[0], acc[u][0]);
+                    acc[u][1] = fmaf(xv[u][1], qv[1], acc[u][1]);
+                    acc[u][2] = fmaf(xv[u][2], qv[2], acc[u][2]);
+                    acc[u][3] = fmaf(xv[u][3], qv[3], acc[u][3]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                sc[u] = (acc[u][0] + acc[u][1]) + (acc[u][2] + acc[u][3]);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) sc[u] += __shfl_xor(sc[u], o);
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (e0 + u < m) cand[e0 + u] = ((uint64_t)desc_key(sc[u]) << 32) | (uint32_t)r[u];
+        }
+    }
+    __syncthreads();
+    // ---- 5. final order (exact score desc, row asc) by rank counting, top-k out ------------------------------------------------------
+    for (int i = tid; i < m; i += kFinishThreads) {
+        const uint64_t mine = cand[i];
+        int rank = 0;
+        for (int j = 0; j < m; ++j) rank += cand[j] < mine;
+        if (rank < k) {
+            out_s[(int64_t)q * k + rank] = desc_key_to_float((uint32_t)(mine >> 32));
+            out_l[(int64_t)q * k + rank] = (int64_t)(uint32_t)mine;
+        }
+    }
+    for (int e = m + tid; e < k; e += kFinishThreads) {
+        out_s[(int64_t)q * k + e] = LDOT_PAD_SCORE;
+        out_l[(int64_t)q * k + e] = LDOT_PAD_LABEL;
+    }
+}
+
 int launch_narrow_tau(const uint32_t* M, int64_t ldm, int nruns, int nq, int kp, uint32_t* tau_key, hipStream_t st) {
     LDOT_REQUIRE(nruns >= 1 && nruns <= kNarrowMaxRuns && nq >= 1, LDOT_EINVAL, "bad run count");
     if (nruns <= 2048)
@@ -175,6 +351,19 @@ int launch_narrow_final(const uint64_t* cand, int cap, int32_t* cnt, int nq, flo
         if (dev < 64) g_final_attr[dev] = true;
     }
     hipLaunchKernelGGL(narrow_final_kernel, dim3(nq), dim3(256), (size_t)cap * 8, st, cand, cap, cnt, list_s, list_i, kp, tau, over);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+// nruns <= 2048, kp <= 512 (one wave holds the run maxima, the best[] buffer the k' keys).  S / M / nrows as for launch_narrow_collect
+// (M is left zero).  list_s / list_i / tau_out (optional): the list view; out_s / out_l (optional, device-visible): the final top-k.
+int launch_narrow_finish(const float* S, int tiled_qg, int64_t lds_elems, uint32_t* M, int64_t ldm, int nruns, int run_rows,
+                         int64_t nrows, int nq, const float* q32, int64_t ldq, const float* x32, int64_t ldx, int dpad, int kp, int k,
+                         int do_rescore, float* list_s, int32_t* list_i, float* tau_out, float* out_s, int64_t* out_l, int32_t* over,
+                         hipStream_t st) {
+    LDOT_REQUIRE(nruns >= 1 && nruns <= 2048 && kp <= 512 && k <= kp && nq >= 1, LDOT_EINVAL, "narrow finish: bad sizes");
+    hipLaunchKernelGGL(narrow_finish_kernel, dim3(nq), dim3(kFinishThreads), 0, st, S, tiled_qg, lds_elems, M, ldm, nruns, run_rows,
+                       nrows, q32, ldq, x32, ldx, dpad, kp, k, do_rescore, list_s, list_i, tau_out, out_s, out_l, over);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

@@ -11,7 +11,7 @@ so every rank ends with the final global top-k of the queries it contributed.  T
 shards are independent, so there is no other data-path collective.
 
 External ids stay on the rank that owns the rows: ``index_local_shard`` exchanges only the shard SIZES (row offsets); ``search_knn``
-resolves the labels of its final results on their owning ranks (two object collectives sized by the result set, not by the index).
+resolves the labels of its final results on their owning ranks (tensor all-to-alls sized by the result set, not by the index).
 
 ``local_search`` / ``merge`` are injectable for the CPU (gloo) tests of the collective logic; the defaults are the
 HIP implementations and raise without a GPU.  ``exchange`` selects the collective of step 3: 'all_to_all' (default: every
@@ -28,14 +28,23 @@ from . import _lib as L
 from .indexer import DenseFlatIndexer
 
 
-def _hip_merge(scores: torch.Tensor, labels: torch.Tensor, k: int):
-    """scores/labels: [nparts, nq, k_in] CUDA tensors -> ([nq, k], [nq, k])"""
+def _hip_merge(scores: torch.Tensor, labels: torch.Tensor, k: int, out=None):
+    """scores/labels: [nparts, nq, k_in] CUDA tensors -> ([nq, k], [nq, k]).  ``out`` = (scores, labels) PINNED host tensors: the merge
+    kernel stores the final lists straight into host memory (pinned memory is mapped into the device's address space), like the
+    re-score kernel of a single-GPU search does — no device result buffers, no copy kernels; the caller synchronises the stream."""
     lib = L.load_library()
     nparts, nq, k_in = scores.shape
     scores = scores.contiguous().float()
     labels = labels.contiguous().to(torch.int64)
-    out_s = torch.empty((nq, k), dtype=torch.float32, device=scores.device)
-    out_l = torch.empty((nq, k), dtype=torch.int64, device=scores.device)
+    if out is not None:
+        out_s, out_l = out
+        if not (out_s.is_pinned() and out_l.is_pinned() and out_s.is_contiguous() and out_l.is_contiguous()
+                and tuple(out_s.shape) == (nq, k) and tuple(out_l.shape) == (nq, k)
+                and out_s.dtype == torch.float32 and out_l.dtype == torch.int64):
+            raise ValueError('out must be pinned contiguous (float32, int64) host tensors of shape [nq, k]')
+    else:
+        out_s = torch.empty((nq, k), dtype=torch.float32, device=scores.device)
+        out_l = torch.empty((nq, k), dtype=torch.int64, device=scores.device)
     L.check(lib.ldot_merge_topk(ctypes.c_void_p(scores.data_ptr()), ctypes.c_void_p(labels.data_ptr()), nparts, nq,
                                 k_in, k, ctypes.c_void_p(out_s.data_ptr()), ctypes.c_void_p(out_l.data_ptr()), L.DEVICE,
                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
@@ -91,9 +100,24 @@ class ShardedFlatIndexer:
     def ntotal(self) -> int:
         return self.offsets[-1]
 
+    def _exchange_rows(self, send_lists: List[torch.Tensor]) -> List[torch.Tensor]:
+        """variable-size all-to-all of int64 tensors: send_lists[r] goes to rank r; returns what every rank sent here (one counts
+        exchange + one payload exchange, both tensor collectives)"""
+        dev = self._tensor_device()
+        counts = torch.tensor([t.numel() for t in send_lists], dtype=torch.int64, device=dev)
+        rcounts = torch.empty_like(counts)
+        dist.all_to_all_single(rcounts, counts, group=self.group)
+        rc = [int(c) for c in rcounts.tolist()]
+        send = torch.cat([t.to(dev) for t in send_lists]) if send_lists else torch.empty(0, dtype=torch.int64, device=dev)
+        recv = torch.empty(sum(rc), dtype=send.dtype, device=dev)
+        dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=[int(c) for c in counts.tolist()], group=self.group)
+        return list(recv.split(rc))
+
     def resolve_ids(self, labels) -> list:
         """Global row labels (nested lists / array, -1 = padding) -> external ids, resolved on the ranks that own the rows.
-        Collective: every rank must call it (with its own, possibly empty, labels)."""
+        Collective: every rank must call it (with its own, possibly empty, labels).  Tensor collectives only: the requested rows travel as
+        int64 (all-to-all by owner), the answers as int64 (integer ids) or as UTF-8 bytes + lengths (string ids); ids of any other
+        type take the pickling path."""
         import bisect
         rows = [list(map(int, r)) for r in labels]
         if self.index_id_to_db_id:
@@ -107,9 +131,35 @@ class ShardedFlatIndexer:
                     want[last_owner].add(self.ntotal - 1)
                 else:
                     want[bisect.bisect_right(self.offsets, g) - 1].add(g)
-        req = [None] * self.world
-        dist.all_gather_object(req, [sorted(w) for w in want], group=self.group)
+        want = [sorted(w) for w in want]
+        # what kind of ids does the index hold?  (agreed globally: a rank without rows has no opinion)
+        kind = 0 if not self.local_ids else (1 if all(isinstance(i, (int,)) and not isinstance(i, bool) for i in self.local_ids[:64]) else
+                                             2 if all(isinstance(i, str) for i in self.local_ids[:64]) else 3)
+        kt = torch.tensor([kind], dtype=torch.int64, device=self._tensor_device())
+        dist.all_reduce(kt, op=dist.ReduceOp.MAX, group=self.group)
+        kind = int(kt.item())
         lo = self.offsets[self.rank]
+        if kind in (1, 2):
+            asked = self._exchange_rows([torch.tensor(w, dtype=torch.int64) for w in want])      # asked[r]: rows rank r wants from me
+            mine = [[self.local_ids[int(g) - lo] for g in a.tolist()] for a in asked]
+            table = {}
+            if kind == 1:
+                got = self._exchange_rows([torch.tensor(m, dtype=torch.int64) for m in mine])
+                for r in range(self.world):
+                    table.update(zip(want[r], got[r].tolist()))
+            else:
+                enc = [[i.encode('utf-8') for i in m] for m in mine]
+                lens = self._exchange_rows([torch.tensor([len(b) for b in e], dtype=torch.int64) for e in enc])
+                data = self._exchange_rows([torch.frombuffer(bytearray(b''.join(e)), dtype=torch.uint8).to(torch.int64)
+                                            if e and sum(map(len, e)) else torch.empty(0, dtype=torch.int64) for e in enc])
+                for r in range(self.world):
+                    buf, pos = bytes(data[r].to(torch.uint8).tolist()), 0
+                    for g, n in zip(want[r], lens[r].tolist()):
+                        table[g] = buf[pos:pos + n].decode('utf-8')
+                        pos += n
+            return [[table[g if g >= 0 else self.ntotal - 1] for g in r] for r in rows]
+        req = [None] * self.world
+        dist.all_gather_object(req, want, group=self.group)
         answer = {g: self.local_ids[g - lo] for peer in req for g in peer[self.rank]}
         ans = [None] * self.world
         dist.all_gather_object(ans, answer, group=self.group)
@@ -155,8 +205,10 @@ class ShardedFlatIndexer:
         dist.all_to_all_single(recv, send, group=self.group)
         return recv
 
-    def search(self, local_queries: torch.Tensor, k: int):
-        """-> (scores [nq_local, k] fp32, GLOBAL row labels [nq_local, k] int64) for the local queries."""
+    def search(self, local_queries: torch.Tensor, k: int, out=None):
+        """-> (scores [nq_local, k] fp32, GLOBAL row labels [nq_local, k] int64) for the local queries.  ``out`` = (scores, labels)
+        pinned host tensors: the merge writes the final lists there directly and the call returns them after a stream
+        synchronisation (HIP merge only)."""
         q_all, counts = self._gather_queries(local_queries.float())
         if self._custom:
             s, l = self._local_search(q_all, k)
@@ -196,6 +248,10 @@ class ShardedFlatIndexer:
             part_l = torch.stack([t[mine] for t in gl], 0)
         if nq_mine == 0:
             return s.new_empty((0, k)), l.new_empty((0, k))
+        if out is not None:
+            res = self._merge(part_s.contiguous(), part_l.contiguous(), k, out=out)
+            torch.cuda.current_stream().synchronize()
+            return res
         return self._merge(part_s.contiguous(), part_l.contiguous(), k)
 
     def search_knn(self, local_queries, top_docs: int):

@@ -27,7 +27,11 @@ CASES = {2: dict(bounds=[0, 610, 1500], qb=[0, 11, 37]),
          3: dict(bounds=[0, 410, 1130, 1500], qb=[0, 11, 11, 37])}
 
 
-def _worker(rank, world, port, out_dir, exchange, gather_ids):
+def _mk_id(kind, i):
+    return f'id{i}' if kind == 'str' else (7 * i + 3) if kind == 'int' else ('id', i)
+
+
+def _worker(rank, world, port, out_dir, exchange, gather_ids, id_kind='str'):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -55,25 +59,27 @@ def _worker(rank, world, port, out_dir, exchange, gather_ids):
     sh = ShardedFlatIndexer(d, local_search=local_search, merge=merge, exchange=exchange)
     # the shard is added in TWO calls (a second call used to drop the first call's ids from the global map)
     mid = lo + (hi - lo) // 3
-    sh.index_local_shard([f'id{i}' for i in range(lo, mid)], None, n_rows=mid - lo, gather_ids=gather_ids)
-    sh.index_local_shard([f'id{i}' for i in range(mid, hi)], None, n_rows=hi - mid, gather_ids=gather_ids)
+    sh.index_local_shard([_mk_id(id_kind, i) for i in range(lo, mid)], None, n_rows=mid - lo, gather_ids=gather_ids)
+    sh.index_local_shard([_mk_id(id_kind, i) for i in range(mid, hi)], None, n_rows=hi - mid, gather_ids=gather_ids)
     assert sh.ntotal == n and sh.offsets == bounds
-    assert sh.local_ids == [f'id{i}' for i in range(lo, hi)]
-    assert sh.index_id_to_db_id == ([f'id{i}' for i in range(n)] if gather_ids else [])
+    assert sh.local_ids == [_mk_id(id_kind, i) for i in range(lo, hi)]
+    assert sh.index_id_to_db_id == ([_mk_id(id_kind, i) for i in range(n)] if gather_ids else [])
     s, l = sh.search(torch.from_numpy(q[qb[rank]:qb[rank + 1]]), k)
     res = sh.search_knn(torch.from_numpy(q[qb[rank]:qb[rank + 1]]), k)
     np.savez(os.path.join(out_dir, f'r{rank}.npz'), s=s.numpy(), l=l.numpy(),
-             ids=np.array([r[0] for r in res], dtype=object).reshape(len(res), k), allow_pickle=True)
+             ids=np.array([[repr(i) for i in r[0]] for r in res], dtype=object).reshape(len(res), k), allow_pickle=True)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,exchange,gather_ids', [(2, 'all_to_all', False), (3, 'all_to_all', False),
-                                                        (2, 'all_gather', True), (3, 'all_gather', False)])
-def test_sharded_search_gloo(tmp_path, world, exchange, gather_ids):
+@pytest.mark.parametrize('world,exchange,gather_ids,id_kind', [(2, 'all_to_all', False, 'str'), (3, 'all_to_all', False, 'str'),
+                                                                (2, 'all_gather', True, 'str'), (3, 'all_gather', False, 'int'),
+                                                                (3, 'all_to_all', False, 'tuple')])
+def test_sharded_search_gloo(tmp_path, world, exchange, gather_ids, id_kind):
+    # (resolve_ids: string ids travel as UTF-8 bytes, integer ids as int64 — tensor all-to-alls —, other id types are pickled)
     from oracle import oracle_np as O
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), exchange, gather_ids), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), exchange, gather_ids, id_kind), nprocs=world, join=True)
     rng = np.random.default_rng(2024)
     n, d, nq, k = 1500, 32, 37, 20
     x = rng.standard_normal((n, d)).astype(np.float32)
@@ -87,4 +93,4 @@ def test_sharded_search_gloo(tmp_path, world, exchange, gather_ids):
         assert a['l'].shape == (qb[r + 1] - qb[r], k)
         np.testing.assert_array_equal(a['l'], el[qb[r]:qb[r + 1]])
         np.testing.assert_allclose(a['s'], es[qb[r]:qb[r + 1]], rtol=1e-6, atol=1e-6)
-        assert [list(row) for row in a['ids']] == [[f'id{i}' for i in row] for row in el[qb[r]:qb[r + 1]]]
+        assert [list(row) for row in a['ids']] == [[repr(_mk_id(id_kind, int(i))) for i in row] for row in el[qb[r]:qb[r + 1]]]
