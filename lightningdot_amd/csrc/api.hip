@@ -580,7 +580,7 @@ static int narrow_search(ldot_index* ix, int64_t nq, int kp, hipStream_t st, con
                                            (const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, kp,
                                            direct ? direct->k : std::min(kp, 1), ix->rescore, (float*)ix->w_ls.p, (int32_t*)ix->w_li.p,
                                            (float*)ix->w_tau.p, direct ? direct->scores : nullptr, direct ? direct->labels : nullptr,
-                                           ix->d_nover, st)))
+                                           ix->d_nover, nullptr, 0, nullptr, nullptr, 0, st)))
                 return rc;
             ix->stats[2] += nrows * nq;
             ix->narrow_clean = true;
@@ -1152,6 +1152,13 @@ static int lists_search_impl(ldot_index* ix, const void* queries, int64_t nq, in
             if ((rc = launch_ivf_scan((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, n, rowbase, cstart, nprobe,
                                       max_cols, run_shift, (float*)ix->w_S.p, max_cols, M, nruns, st)))
                 return rc;
+            if (n <= 16 && nruns <= 2048 && kp <= 512 && (int64_t)run * kp <= 4096) {
+                // a few queries: threshold + collect + order + column -> row translation in ONE launch (narrow_finish_kernel)
+                if ((rc = launch_narrow_finish((const float*)ix->w_S.p, 0, max_cols, M, nruns, (int)nruns, run, max_cols, (int)n, nullptr, 0,
+                                               nullptr, 0, 0, kp, k, 0, nullptr, nullptr, nullptr, ds, dl, ix->d_nover, cstart + nprobe,
+                                               nprobe + 1, rowbase, cstart, nprobe, st)))
+                    return rc;
+            } else {
             if ((rc = launch_narrow_tau(M, nruns, (int)nruns, (int)n, kp, tk, st))) return rc;
             if ((rc = launch_narrow_collect((const float*)ix->w_S.p, max_cols, M, nruns, (int)nruns, run, max_cols, 0, (int)n, tk,
                                             (uint64_t*)ix->w_ncand.p, kNarrowCandCap, (int32_t*)ix->w_ncnt.p, cstart + nprobe, nprobe + 1,
@@ -1160,6 +1167,7 @@ static int lists_search_impl(ldot_index* ix, const void* queries, int64_t nq, in
             if ((rc = launch_ivf_final((const uint64_t*)ix->w_ncand.p, kNarrowCandCap, (int32_t*)ix->w_ncnt.p, n, rowbase, cstart, nprobe, k,
                                        ds, dl, ix->d_nover, st)))
                 return rc;
+            }
             ix->narrow_clean = true;
             // a full candidate buffer (thousands of equal scores) is rare but must not go unnoticed: one synchronisation per chunk
             LDOT_HIP_CHECK(hipStreamSynchronize(st));

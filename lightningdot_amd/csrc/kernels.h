@@ -67,9 +67,11 @@ int launch_narrow_final(const uint64_t* cand, int cap, int32_t* cnt, int nq, flo
 
 // <= 16 queries, ONE scan chunk, nruns <= 2048, kp <= 512: threshold + collect + top-k' + exact re-score + final order + output in one
 // launch (one 1024-thread workgroup per query).  list_* / tau_out and out_* are optional; over[q] = 1: too many candidates (redo).
+// nrows_q: per-query column counts; rowbase / cstart / nprobe: column -> row translation of the inverted-file scan (all optional).
 int launch_narrow_finish(const float* S, int tiled_qg, int64_t lds_elems, uint32_t* M, int64_t ldm, int nruns, int run_rows,
                          int64_t nrows, int nq, const float* q32, int64_t ldq, const float* x32, int64_t ldx, int dpad, int kp, int k,
                          int do_rescore, float* list_s, int32_t* list_i, float* tau_out, float* out_s, int64_t* out_l, int32_t* over,
+                         const int32_t* nrows_q, int64_t nrows_q_stride, const int64_t* rowbase, const int32_t* cstart, int nprobe,
                          hipStream_t st);
 
 // dst [n][d + 2] fp32 = [q (L2-normalised if asked), 0, 1]: the coarse query of the inverted-file search (convert.hip)

@@ -165,11 +165,15 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
         char* st = smem + (int)(issued & 3) * Geo::kStage;
         const int k0b = l_k * 1024;   // slab l_k of a 16-row group = its l_k-th KiB block
         if ((VAR & 2) && issued >= 4) return;
+        // cache policy of the two streams (ablation): bit 1 of aux = nt (non-temporal: the line is the first to leave the L2), bit 0 =
+        // sc0.  VAR & 65536: row-panel loads nt (streamed once per query group: they should not evict the query panels, which every
+        // unit re-reads); VAR & 131072: query-panel loads nt (the opposite, as a control)
+        constexpr int kAuxA = (VAR & 65536) ? 2 : 0, kAuxB = (VAR & 131072) ? 2 : 0;
         if (j < Geo::kALoads)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(sa.rsrc, (rg_lptr_t)(st + (j * 8 + c.wave) * 1024), 16, vo, k0b + j * jstep, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(sa.rsrc, (rg_lptr_t)(st + (j * 8 + c.wave) * 1024), 16, vo, k0b + j * jstep, 0, kAuxA);
         else
             __builtin_amdgcn_raw_ptr_buffer_load_lds(sb.rsrc, (rg_lptr_t)(st + Geo::kAOpBytes + ((j - Geo::kALoads) * 8 + c.wave) * 1024),
-                                                     16, vo, k0b + (j - Geo::kALoads) * jstep, 0, 0);
+                                                     16, vo, k0b + (j - Geo::kALoads) * jstep, 0, kAuxB);
     };
     auto advance = [&]() {
         ++issued;
@@ -426,6 +430,10 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     if (variant == 128) rk = score_filter_r6_kernel<128>;
     if (variant == 144) rk = score_filter_r6_kernel<144>;
     if (variant == 256) rk = score_filter_r6_kernel<256>;
+    if (variant == 65536) rk = score_filter_r6_kernel<65536>;     // row-panel loads non-temporal
+    if (variant == 65552) rk = score_filter_r6_kernel<65552>;     // ... with tau = +inf
+    if (variant == 131072) rk = score_filter_r6_kernel<131072>;   // query-panel loads non-temporal (control)
+    if (variant == 131088) rk = score_filter_r6_kernel<131088>;
     if (variant == 384) rk = score_filter_r6_kernel<384>;   // spread loads, no deferral
     if (variant == 400) rk = score_filter_r6_kernel<400>;
     if (variant == 528) rk = score_filter_r6_kernel<528>;
