@@ -1149,11 +1149,30 @@ static int lists_search_impl(ldot_index* ix, const void* queries, int64_t nq, in
             if ((rc = narrow_buffers(ix, n, nruns, st))) return rc;
             uint32_t* M = (uint32_t*)ix->w_nmax.p;
             uint32_t* tk = (uint32_t*)ix->w_ntau.p;
+            // a few queries: the lists are scanned from the bf16 shadow (half the bytes), k + margin candidates are kept and re-scored
+            // exactly — threshold, collect, column -> row translation, re-score and final order are ONE launch (narrow_finish_kernel)
+            const int kpb = candidate_len(ix, k);
+            const bool few = n <= 16 && nruns <= 2048 && (int64_t)run * kpb <= 4096 && kpb <= 512;
+            const bool scan16 = few && ix->precision == 0 && ix->rescore && (size_t)ix->dpad / 32 * 1024 + (size_t)(nprobe + 1) * 12 + 8 <= 64 * 1024;
+            if (scan16) {
+                if ((rc = ix->w_q16b.ensure((size_t)round_up(n, 16) * ix->ld16() * 2))) return rc;
+                if ((rc = launch_convert_rows(ix->w_q32.p, LDOT_F32, ix->dpad, n, round_up(n, 16), ix->d, ix->dpad, 0, nullptr, nullptr, 0,
+                                              (uint16_t*)ix->w_q16b.p, 0, st)))
+                    return rc;
+                if ((rc = launch_ivf_scan_bf16(ix->w_q16b.p, ix->x16b, ix->ld16(), n, rowbase, cstart, nprobe, max_cols, run_shift,
+                                               (float*)ix->w_S.p, max_cols, M, nruns, st)))
+                    return rc;
+                if ((rc = launch_narrow_finish((const float*)ix->w_S.p, 0, max_cols, M, nruns, (int)nruns, run, max_cols, (int)n,
+                                               (const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, kpb, k, 1, nullptr,
+                                               nullptr, nullptr, ds, dl, ix->d_nover, cstart + nprobe, nprobe + 1, rowbase, cstart, nprobe,
+                                               st)))
+                    return rc;
+            } else {
             if ((rc = launch_ivf_scan((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, n, rowbase, cstart, nprobe,
                                       max_cols, run_shift, (float*)ix->w_S.p, max_cols, M, nruns, st)))
                 return rc;
-            if (n <= 16 && nruns <= 2048 && kp <= 512 && (int64_t)run * kp <= 4096) {
-                // a few queries: threshold + collect + order + column -> row translation in ONE launch (narrow_finish_kernel)
+            if (few && kp <= kpb) {
+                // (split-bf16 shadow / re-score switched off: exact fp32 scan, same single finish launch without a re-score)
                 if ((rc = launch_narrow_finish((const float*)ix->w_S.p, 0, max_cols, M, nruns, (int)nruns, run, max_cols, (int)n, nullptr, 0,
                                                nullptr, 0, 0, kp, k, 0, nullptr, nullptr, nullptr, ds, dl, ix->d_nover, cstart + nprobe,
                                                nprobe + 1, rowbase, cstart, nprobe, st)))
@@ -1167,6 +1186,7 @@ static int lists_search_impl(ldot_index* ix, const void* queries, int64_t nq, in
             if ((rc = launch_ivf_final((const uint64_t*)ix->w_ncand.p, kNarrowCandCap, (int32_t*)ix->w_ncnt.p, n, rowbase, cstart, nprobe, k,
                                        ds, dl, ix->d_nover, st)))
                 return rc;
+            }
             }
             ix->narrow_clean = true;
             // a full candidate buffer (thousands of equal scores) is rare but must not go unnoticed: one synchronisation per chunk

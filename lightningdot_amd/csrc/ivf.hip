@@ -152,6 +152,67 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const float* __restrict__
     }
 }
 
+// ---- bf16 list scan (round 3): the probed lists are scored from the bf16 SHADOW (half the bytes of the fp32 scan above), candidates are
+// re-scored exactly afterwards (narrow_finish_kernel).  A wave takes 16 consecutive COLUMNS of the query's compact space (a run of the
+// run-maxima selection) = 16 index rows that are consecutive within a list; lane l gathers, for every 32-k slab, the 16 bytes of row
+// (l & 15), k chunk (l >> 4) from the blocked shadow (block (row >> 4, slab) + (row & 15) * 64 + (l >> 4) * 16: the four lanes of a row
+// read one 64-byte segment, consecutive rows adjacent segments) — which IS the A operand of v_mfma_f32_16x16x32_bf16 in register order.
+// The B operand is the query's 16-query block of the blocked query shadow, staged in LDS once per workgroup; column (q & 15) of the
+// result holds the query's 16 scores (lanes with (l & 15) == (q & 15): rows (l >> 4) * 4 .. + 4).
+template <int UNR>
+__global__ __launch_bounds__(256) void ivf_scan_bf16_kernel(const char* __restrict__ Q16b, const char* __restrict__ X16b, int nslab,
+                                                            const int64_t* __restrict__ rowbase, const int32_t* __restrict__ cstart,
+                                                            int nprobe, float* __restrict__ S, int64_t lds_elems,
+                                                            uint32_t* __restrict__ M, int64_t ldm, int run_shift) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t q = blockIdx.y;
+    int64_t* rb = (int64_t*)(smem + (size_t)nslab * 1024);
+    int32_t* cs = (int32_t*)(rb + nprobe);
+    const char* qsrc = Q16b + (q >> 4) * (int64_t)nslab * 1024;
+    for (int i = threadIdx.x; i < nslab * 64; i += 256) ((uint4*)smem)[i] = ((const uint4*)qsrc)[i];
+    const int32_t* cq = cstart + q * (nprobe + 1);
+    for (int i = threadIdx.x; i <= nprobe; i += 256) cs[i] = cq[i];
+    for (int i = threadIdx.x; i < nprobe; i += 256) rb[i] = rowbase[q * nprobe + i];
+    __syncthreads();
+    const int total = cs[nprobe];
+    const int lo = (lane & 15) * 64 + (lane >> 4) * 16;     // lane's byte offset inside a 1-KiB block (A and B operand alike)
+    const int qc = (int)(q & 15);
+    for (int blk = blockIdx.x * 4 + wave; blk * 16 < total; blk += gridDim.x * 4) {
+        const int c = blk * 16 + (lane & 15);               // the column whose row this lane gathers
+        int64_t r = -1;
+        if (c < total) {
+            const int j = ivf_find_probe(cs, nprobe, c);
+            r = rb[j] + (c - cs[j]);
+        }
+        // (columns past the query's last one read row 0: their scores are never stored)
+        const char* xrow = X16b + ((r < 0 ? 0 : r) >> 4) * (int64_t)nslab * 1024 + ((r < 0 ? 0 : r) & 15) * 64 + (lane >> 4) * 16;
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        for (int s0 = 0; s0 < nslab; s0 += UNR) {
+            bf16x8_t a[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) a[u] = __builtin_nontemporal_load((const bf16x8_t*)(xrow + (int64_t)(s0 + u) * 1024));
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+                acc[u & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], *(const bf16x8_t*)(smem + (s0 + u) * 1024 + lo), acc[u & 1], 0, 0, 0);
+        }
+        const f32x4 v = acc[0] + acc[1];                    // rows (lane >> 4) * 4 .. + 4 of column lane & 15
+        const int cbase = blk * 16 + (lane >> 4) * 4;
+        float m = -INFINITY;
+        if ((lane & 15) == qc) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (cbase + i < total) {
+                    S[q * lds_elems + cbase + i] = v[i];
+                    m = fmaxf(m, v[i]);
+                }
+        }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        if (lane == qc && m > -INFINITY) atomicMax(M + q * ldm + (blk >> run_shift), ~desc_key(m));
+    }
+}
+
 // one workgroup per query: candidate keys {descending score key, column} -> top k: exact scores + index rows (-1 / pad score beyond
 // the candidates); over[q] = 1 when the candidate buffer was full
 __global__ __launch_bounds__(256) void ivf_final_kernel(const uint64_t* __restrict__ cand, int cap, int32_t* __restrict__ cnt,
@@ -215,6 +276,43 @@ int launch_ivf_scan(const float* q32, int64_t ldq, const float* x32, int64_t ldx
     const unsigned gx = (unsigned)std::min<int64_t>(blocks, per_q);
     hipLaunchKernelGGL(ivf_scan_kernel, dim3(gx, (unsigned)nq), dim3(256), (size_t)(nprobe + 1) * 12, st, q32, ldq, x32, ldx, dpad,
                        rowbase, cstart, nprobe, S, lds_elems, M, ldm, run_shift);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+static bool g_ivf_bf16_attr[3][64];
+
+// the same scan from the bf16 shadow (q16b / x16b: the BLOCKED shadows, ld_elems = dpad elements per row); S receives bf16-input
+// scores — the caller re-scores its candidates exactly
+int launch_ivf_scan_bf16(const void* q16b, const void* x16b, int64_t ld_elems, int64_t nq, const int64_t* rowbase, const int32_t* cstart,
+                         int nprobe, int64_t max_cols, int run_shift, float* S, int64_t lds_elems, uint32_t* M, int64_t ldm,
+                         hipStream_t st) {
+    if (nq <= 0 || nprobe <= 0 || max_cols <= 0) return LDOT_OK;
+    const int nslab = (int)(ld_elems / 32);
+    const size_t lds = (size_t)nslab * 1024 + (size_t)(nprobe + 1) * 12 + 8;
+    LDOT_REQUIRE(run_shift >= 0 && run_shift <= 16 && ld_elems % 64 == 0 && lds <= 64 * 1024, LDOT_EINVAL, "bad bf16 list scan shape");
+    const int64_t blocks = (max_cols + 15) / 16;
+    const int64_t per_q = std::max<int64_t>(8, 2048 / nq);
+    const unsigned gx = (unsigned)std::min<int64_t>((blocks + 3) / 4, per_q);
+    int dev = 0;
+    LDOT_HIP_CHECK(hipGetDevice(&dev));
+#define LDOT_IVF16(U, SLOT)                                                                                                     \
+    do {                                                                                                                        \
+        if (dev >= 64 || !g_ivf_bf16_attr[SLOT][dev]) {                                                                          \
+            LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)ivf_scan_bf16_kernel<U>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                               64 * 1024));                                                                      \
+            if (dev < 64) g_ivf_bf16_attr[SLOT][dev] = true;                                                                     \
+        }                                                                                                                        \
+        hipLaunchKernelGGL((ivf_scan_bf16_kernel<U>), dim3(gx, (unsigned)nq), dim3(256), lds, st, (const char*)q16b,              \
+                           (const char*)x16b, nslab, rowbase, cstart, nprobe, S, lds_elems, M, ldm, run_shift);                   \
+    } while (0)
+    if (nslab % 8 == 0)
+        LDOT_IVF16(8, 0);
+    else if (nslab % 4 == 0)
+        LDOT_IVF16(4, 1);
+    else
+        LDOT_IVF16(2, 2);
+#undef LDOT_IVF16
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

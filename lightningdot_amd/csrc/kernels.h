@@ -85,6 +85,10 @@ int launch_ivf_prefix(const void* probes, int probes_are_int64, int64_t nq, int 
 int launch_ivf_scan(const float* q32, int64_t ldq, const float* x32, int64_t ldx, int dpad, int64_t nq, const int64_t* rowbase,
                     const int32_t* cstart, int nprobe, int64_t max_cols, int run_shift, float* S, int64_t lds_elems, uint32_t* M,
                     int64_t ldm, hipStream_t st);
+// the same scan from the blocked bf16 shadows (half the bytes; S = bf16-input scores, the candidates are re-scored exactly afterwards)
+int launch_ivf_scan_bf16(const void* q16b, const void* x16b, int64_t ld_elems, int64_t nq, const int64_t* rowbase, const int32_t* cstart,
+                         int nprobe, int64_t max_cols, int run_shift, float* S, int64_t lds_elems, uint32_t* M, int64_t ldm,
+                         hipStream_t st);
 int launch_ivf_final(const uint64_t* cand, int cap, int32_t* cnt, int64_t nq, const int64_t* rowbase, const int32_t* cstart,
                      int nprobe, int k, float* out_s, int64_t* out_l, int32_t* over, hipStream_t st);
 

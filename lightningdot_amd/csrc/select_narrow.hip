@@ -208,6 +208,9 @@ __global__ __launch_bounds__(kFinishThreads) void narrow_finish_kernel(
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t* Mq = M + (int64_t)q * ldm;
     if (nrows_q) nrows = nrows_q[q * nrows_q_stride];   // (per-query column counts: the inverted-file scan)
+#ifdef LDOT_ABLATION
+    if (dbg_phase == 9) return;                         // (profiling: an empty launch)
+#endif
     // ---- 1. threshold key: k'-th largest run maximum (wave 0; the other waves wait at the barrier) ------------------------------
     if (tid == 0) n_sh = nrun_sh = 0;
     int32_t* runs = (int32_t*)best;                     // (the run list lives in the best[] buffer until step 3 needs it: 2048 ints)
@@ -219,6 +222,15 @@ __global__ __launch_bounds__(kFinishThreads) void narrow_finish_kernel(
             const int r = v * 64 + lane;
             key[v] = r < nruns ? ~Mq[r] : 0xffffffffu;
         }
+#ifdef LDOT_ABLATION
+        if (dbg_phase == 8) {                           // (profiling: the key loads only)
+            uint32_t x = 0;
+#pragma unroll
+            for (int v = 0; v < 32; ++v) x ^= key[v];
+            if (x == 0x12345u) tk_sh = x;
+            nruns = 0;
+        }
+#endif
         if (nruns >= kp) {
             // per-lane counts on the VALU + ONE DPP wave reduction per bit (a ballot + scalar popcount per key costs ~40 cycles of
             // VALU -> SGPR -> SALU latency: 640 of them were 13 us; six ds_bpermute round trips per bit are no better).  The bits every
@@ -363,6 +375,17 @@ __global__ __launch_bounds__(kFinishThreads) void narrow_finish_kernel(
 #ifdef LDOT_ABLATION
     if (dbg_phase == 4) return;
 #endif
+    if (cstart) {                                       // inverted-file scan: column of the query's compact space -> index row
+        __syncthreads();
+        const int32_t* cq = cstart + (int64_t)q * (nprobe + 1);
+        for (int i = tid; i < m; i += kFinishThreads) {
+            const uint64_t kv = best[i];
+            const int col = (int)(uint32_t)kv;
+            const int j = finish_find_probe(cq, nprobe, col);
+            best[i] = (kv & 0xffffffff00000000ull) | (uint32_t)(rowbase[(int64_t)q * nprobe + j] + (col - cq[j]));
+        }
+        __syncthreads();
+    }
     // ---- 4. exact fp32 scores of the m candidates (the re-score kernel's arithmetic) ---------------------------------------------
     const float* qrow = q32 + (int64_t)q * ldq;
     constexpr int U = 4;
@@ -430,14 +453,8 @@ __global__ __launch_bounds__(kFinishThreads) void narrow_finish_kernel(
         const uint64_t mine = cand[i];
         const int rank = rank_of(mine, mpad);
         if (rank < k) {
-            int64_t row = (int64_t)(uint32_t)mine;
-            if (cstart) {                               // inverted-file scan: column of the query's compact space -> index row
-                const int32_t* cq = cstart + (int64_t)q * (nprobe + 1);
-                const int j = finish_find_probe(cq, nprobe, (int)row);
-                row = rowbase[(int64_t)q * nprobe + j] + (row - cq[j]);
-            }
             out_s[(int64_t)q * k + rank] = desc_key_to_float((uint32_t)(mine >> 32));
-            out_l[(int64_t)q * k + rank] = row;
+            out_l[(int64_t)q * k + rank] = (int64_t)(uint32_t)mine;
         }
     }
     for (int e = m + tid; e < k; e += kFinishThreads) {

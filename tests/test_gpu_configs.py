@@ -82,8 +82,15 @@ def test_config2_coco_shape_recalls():
     assert len(ix_img.index_id_to_db_id) == 5000 and len(ix_txt.index_id_to_db_id) == 25000
     l2, a2, _, (o_txt, o_img), (orank_txt, orank_img) = O.eval_on_stream(stream, 768, img2txt, 100, 0.0)
     assert r_txt == o_txt and r_img == o_img
-    keys = list(rank_txt)[:500]
-    assert all(rank_txt[k][:10] == orank_txt[k][:10] for k in keys)
+    # EVERY key of both directions (25 000 text queries, 5 000 image ids): rank-1 identical; the top-10 lists identical except where the
+    # oracle's blocked sgemm and the HIP re-score order two fp32-near-tied neighbours differently (fewer than 1 in 1000 positions)
+    for mine, ref in ((rank_txt, orank_txt), (rank_img, orank_img)):
+        assert list(mine.keys()) == list(ref.keys())
+        row_of = {k_: r for r, k_ in enumerate(mine.db_ids)}
+        want = np.array([[row_of[i] for i in ref[k_][:10]] for k_ in ref], dtype=np.int64)
+        got = mine.labels[torch.as_tensor(mine.last_rows(list(ref)), device=mine.labels.device)][:, :10].cpu().numpy()
+        assert (got[:, 0] == want[:, 0]).all()
+        assert (got != want).mean() < 1e-3, (got != want).mean()
 
 
 def test_config3_full_size_properties():

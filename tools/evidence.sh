@@ -33,5 +33,8 @@ bash tools/pmc_serving.sh > $O/pmc_serving.txt 2>&1
 bash tools/serving_timeline.sh 1000000 > $O/serving_timeline_1m.txt 2>&1
 bash tools/serving_timeline.sh 123287 > $O/serving_timeline_123287.txt 2>&1
 timeout 600 python tools/ivf_bench.py > $O/ivf_bench.jsonl 2>> $O/bench.err
+timeout 600 python tools/ivf_bench.py 1000000 curve > $O/ivf_recall_curve.jsonl 2>> $O/bench.err
+timeout 600 python tools/overflow_cases.py > $O/overflow_cases.jsonl 2>> $O/bench.err
+timeout 300 python tools/shard_floor.py > $O/shard_floor.txt 2>> $O/bench.err
 bash tools/timeline_tail.sh 8 python tools/ivf_one.py > $O/ivf_timeline.txt 2>&1
 tail -3 $O/pytest_gpu.log; cat $O/smoke.log | tail -1; cut -c1-600 $O/bench.json; cat $O/pmc.txt

@@ -3,8 +3,9 @@
 with the EXACT top-10 (not with a planted row), single-query / 16-query latency per nprobe.  Prints JSON lines.
 
     python tools/ivf_bench.py [rows] [centroid_spread]
+    python tools/ivf_bench.py [rows] curve            # recall@10 vs nprobe only, for several spreads (no latency loops)
 
-Data: a mixture of 4000 Gaussians whose centroids are spread by `centroid_spread` (default 0.12) per dimension around the origin, rows =
+Data: a mixture of 4000 Gaussians whose centroids are spread by `centroid_spread` (default 0.2) per dimension around the origin, rows =
 centroid + 0.5 N(0,1) — OVERLAPPING clusters: the inner-product advantage of a query's own cluster (768 spread^2 ~ 11) is comparable to
 the noise of the cross terms (~7), so the exact top-10 of a query is spread over several lists and recall really depends on nprobe.
 (Well separated clusters, spread 1.0, give recall 1.0 at every nprobe — uninformative.)  Queries are fresh draws from the mixture."""
@@ -15,7 +16,27 @@ from lightningdot_amd.indexer import DenseFlatIndexer
 from lightningdot_amd.ivf import DenseIVFFlatIndexer
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-SPREAD = float(sys.argv[2]) if len(sys.argv) > 2 else 0.12
+if len(sys.argv) > 2 and sys.argv[2] == 'curve':
+    for spread in (0.16, 0.2, 0.25, 0.35):
+        g = torch.Generator(device='cuda').manual_seed(0)
+        cent = spread * torch.randn(4000, 768, device='cuda', generator=g)
+        x = cent[torch.randint(0, 4000, (N,), device='cuda', generator=g)] + 0.5 * torch.randn(N, 768, device='cuda', generator=g)
+        q = cent[torch.randint(0, 4000, (512,), device='cuda', generator=g)] + 0.5 * torch.randn(512, 768, device='cuda', generator=g)
+        flat = DenseFlatIndexer(768); flat.index_tensor(list(range(N)), x)
+        _, el = flat.search_knn_tensors(q, 10)
+        ivf = DenseIVFFlatIndexer(768, nprobe=32); ivf.index_tensor(list(range(N)), x)
+        inv = torch.as_tensor(ivf.index_id_to_db_id, device='cuda')
+        row = dict(rows=N, centroid_spread=spread, nlist=ivf.nlist, longest_list=ivf.max_list_len, recall_at_10={}, rank1_agreement={})
+        for nprobe in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512):
+            _, l = ivf.search_knn_tensors(q, 10, nprobe, exact_when_cheaper=False)
+            orig = torch.where(l >= 0, inv[l.clamp_min(0)], l)
+            row['recall_at_10'][nprobe] = round(float(sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(orig, el)) / 5120), 4)
+            row['rank1_agreement'][nprobe] = round(float((orig[:, 0] == el[:, 0]).float().mean()), 4)
+        print(json.dumps(row), flush=True)
+        del flat, ivf, x
+        torch.cuda.empty_cache()
+    sys.exit(0)
+SPREAD = float(sys.argv[2]) if len(sys.argv) > 2 else 0.2
 D, K = 768, 10
 g = torch.Generator(device='cuda').manual_seed(0)
 cent = SPREAD * torch.randn(4000, D, device='cuda', generator=g)
