@@ -1149,11 +1149,19 @@ static int lists_search_impl(ldot_index* ix, const void* queries, int64_t nq, in
             if ((rc = narrow_buffers(ix, n, nruns, st))) return rc;
             uint32_t* M = (uint32_t*)ix->w_nmax.p;
             uint32_t* tk = (uint32_t*)ix->w_ntau.p;
-            // a few queries: the lists are scanned from the bf16 shadow (half the bytes), k + margin candidates are kept and re-scored
-            // exactly — threshold, collect, column -> row translation, re-score and final order are ONE launch (narrow_finish_kernel)
+            // a few queries: threshold, collect, column -> row translation, (re-score) and final order are ONE launch (narrow_finish_kernel).
+            // 8 .. 16 queries scan their lists from the bf16 shadow (half the bytes; k + margin candidates, re-scored exactly): measured
+            // against the exact fp32 scan under the same finish kernel (tools/ivf_ab.py, 32 of 4000 lists over 1M rows) 0.149 vs 0.170 ms
+            // for 16 queries, but 0.115 vs 0.106 ms for ONE query — its scan is a handful of microseconds either way and the bf16 route
+            // pays a query conversion and a row gather on top
             const int kpb = candidate_len(ix, k);
             const bool few = n <= 16 && nruns <= 2048 && (int64_t)run * kpb <= 4096 && kpb <= 512;
-            const bool scan16 = few && ix->precision == 0 && ix->rescore && (size_t)ix->dpad / 32 * 1024 + (size_t)(nprobe + 1) * 12 + 8 <= 64 * 1024;
+            bool scan16 = few && n >= 8 && ix->precision == 0 && ix->rescore &&
+                          (size_t)ix->dpad / 32 * 1024 + (size_t)(nprobe + 1) * 12 + 8 <= 64 * 1024;
+#ifdef LDOT_ABLATION
+            if (getenv("LDOT_DEBUG_IVF_FP32")) scan16 = false;   // (A/B: the exact fp32 list scan under the same finish kernel)
+            if (getenv("LDOT_DEBUG_IVF_BF16")) scan16 = few && ix->precision == 0 && ix->rescore;
+#endif
             if (scan16) {
                 if ((rc = ix->w_q16b.ensure((size_t)round_up(n, 16) * ix->ld16() * 2))) return rc;
                 if ((rc = launch_convert_rows(ix->w_q32.p, LDOT_F32, ix->dpad, n, round_up(n, 16), ix->d, ix->dpad, 0, nullptr, nullptr, 0,

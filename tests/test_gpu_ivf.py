@@ -85,29 +85,32 @@ def test_ivf_persistence_roundtrip(tmp_path):
     np.testing.assert_array_equal(np.stack([r[1] for r in ra]), np.stack([r[1] for r in rb]))
 
 
-def test_search_lists_entry_point_vs_brute_force():
-    """ldot_index_search_lists on hand-made lists (uneven, one empty, a -1 probe): equals a numpy scan of exactly those rows"""
+@pytest.mark.parametrize('nq', [33, 1, 8, 16, 17])
+def test_search_lists_entry_point_vs_brute_force(nq):
+    """ldot_index_search_lists on hand-made lists (uneven, one empty, a -1 probe): equals a numpy scan of exactly those rows.
+    33 / 17 queries: scan + threshold + collect + final kernels; 1 query: exact fp32 scan + ONE finish kernel; 8 / 16 queries: bf16
+    list scan + finish kernel with the exact re-score."""
     import torch
     from lightningdot_amd import _lib as L
     from lightningdot_amd.indexer import FlatIPIndex
     rng = np.random.default_rng(4)
     x = rng.standard_normal((5000, 200)).astype(np.float32)
-    q = rng.standard_normal((33, 200)).astype(np.float32)
+    q = rng.standard_normal((33, 200)).astype(np.float32)[:nq]
     offs = np.array([0, 700, 700, 2100, 2164, 5000], dtype=np.int64)            # 5 lists: 700, 0, 1400, 64, 2836 rows
-    probes = np.stack([rng.permutation(5)[:3] for _ in range(33)]).astype(np.int32)
-    probes[5, 1] = -1
+    probes = np.stack([rng.permutation(5)[:3] for _ in range(33)]).astype(np.int32)[:nq]
+    probes[min(5, nq - 1), 1] = -1
     ix = FlatIPIndex(200)
     ix.add(x)
     k = 20
-    s = torch.empty((33, k), dtype=torch.float32, device='cuda')
-    l = torch.empty((33, k), dtype=torch.int64, device='cuda')
+    s = torch.empty((nq, k), dtype=torch.float32, device='cuda')
+    l = torch.empty((nq, k), dtype=torch.int64, device='cuda')
     qd, od, pd = torch.from_numpy(q).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(probes).cuda()
-    L.check(ix._lib.ldot_index_search_lists(ix._h, ctypes.c_void_p(qd.data_ptr()), 33, L.F32, 0, ctypes.c_void_p(od.data_ptr()), 5,
+    L.check(ix._lib.ldot_index_search_lists(ix._h, ctypes.c_void_p(qd.data_ptr()), nq, L.F32, 0, ctypes.c_void_p(od.data_ptr()), 5,
                                             2836, ctypes.c_void_p(pd.data_ptr()), 3, k, ctypes.c_void_p(s.data_ptr()),
                                             ctypes.c_void_p(l.data_ptr()), L.DEVICE,
                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     s, l = s.cpu().numpy(), l.cpu().numpy()
-    for i in range(33):
+    for i in range(nq):
         rows = np.concatenate([np.arange(offs[p], offs[p + 1]) for p in probes[i] if p >= 0]) if (probes[i] >= 0).any() else np.array([], int)
         sc = x[rows].astype(np.float64) @ q[i].astype(np.float64)
         order = np.lexsort((rows, -sc))[:k]

@@ -485,6 +485,36 @@ def test_search_begin_finish_with_floor(L):
     assert torch.isfinite(t2).all() and torch.equal(ss, s3) and torch.equal(ll, l3)
 
 
+def test_few_query_search_all_output_routes_agree(L):
+    """<= 16 queries end in ONE kernel after the index scan (narrow_finish_kernel).  Its three uses — results written directly
+    (device outputs / pinned host outputs), list + threshold only followed by the ordinary re-score (pageable host outputs, the
+    begin / finish halves of a sharded search) — and the streaming-selector path (MODE_DENSE) give identical results; 70 000 rows
+    = runs of 64 rows, 300 000 rows = runs of 256 rows."""
+    import torch
+    for n, nq, k in ((70000, 1, 100), (70000, 16, 10), (300000, 5, 100)):
+        rng = np.random.default_rng(n + nq)
+        x = rng.standard_normal((n, 64)).astype(np.float32)
+        q, g = planted_queries(x, nq)
+        ix = _index(x)
+        qt = torch.from_numpy(q).cuda()
+        s_dev, l_dev = ix.search_tensors(qt, k)                              # direct, device outputs
+        hs, hl = torch.empty((nq, k)).pin_memory(), torch.empty((nq, k), dtype=torch.int64).pin_memory()
+        ix.search_into(qt, k, hs, hl)                                        # direct, pinned host outputs
+        s_np, l_np = ix.search(q, k)                                         # pageable host outputs: list only + re-score kernel
+        tau = ix.search_begin(qt, k)                                         # the two halves
+        s_bf, l_bf = ix.search_finish(None)
+        ixd = _index(x, mode=L.MODE_DENSE)
+        s_d, l_d = ixd.search(q, k)
+        assert (l_np[:, 0] == g).all() and torch.isfinite(tau).all()
+        assert_topk_matches(q, x, s_np, l_np, k)
+        for s_, l_ in ((s_dev.cpu().numpy(), l_dev.cpu().numpy()), (hs.numpy(), hl.numpy()), (s_bf.cpu().numpy(), l_bf.cpu().numpy()),
+                       (s_d, l_d)):
+            np.testing.assert_array_equal(l_, l_np)
+            np.testing.assert_array_equal(s_, s_np)
+        st = ix.last_stats()
+        assert st['overflowed_queries'] == 0 and st['fused_pairs'] == 0
+
+
 @pytest.mark.gpu
 def test_hnsw_indexer_surface_is_exact_backed(L, tmp_path):
     """DenseHNSWFlatIndexer (the reference's --hnsw_index alternative, faiss_indexers.py:90-154): same surface and score
