@@ -22,6 +22,7 @@
 
 #include <random>
 #include <vector>
+#include <type_traits>
 
 #include "gemm_ring.h"
 
@@ -245,6 +246,229 @@ static void run(const char* name, const char* src, int64_t region, float* sink, 
     fflush(stdout);
 }
 
+
+// MFMA-only comparison of the two dense bf16 shapes under the power limit: the same 192 accumulator registers and the same flops per
+// wave, operands in registers — 12 tiles of v_mfma_f32_32x32x16_bf16 (16 accumulator registers each, K = 16 per instruction) vs 48 tiles
+// of v_mfma_f32_16x16x32_bf16 (4 registers each, K = 32 per instruction: half the accumulator traffic per MAC, twice the operand reads)
+template <int SHAPE>
+__global__ __launch_bounds__(512, 2) void shape_kernel(const char* __restrict__ src, int iters, float* __restrict__ sink,
+                                                       uint64_t* __restrict__ ticks) {
+    const int lane = threadIdx.x & 63;
+    bf16x8_t a[8], b[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = *(const bf16x8_t*)(src + ((blockIdx.x & 7) * 65536 + i * 1024 + lane * 16));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = *(const bf16x8_t*)(src + ((blockIdx.x & 7) * 65536 + 32768 + i * 1024 + lane * 16));
+    const uint64_t t0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+    float sum = 0.f;
+    if (SHAPE == 32) {
+        f32x16 acc[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll 1
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)          // 2 x (12 tiles x 32*32*16) = one 192 x 64 x 32 slab
+#pragma unroll
+                for (int i = 0; i < 12; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(i + ks) & 7], b[(i + ks) & 3], acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += acc[i][r];
+    } else {
+        f32x4 acc[48];
+#pragma unroll
+        for (int i = 0; i < 48; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 48; ++i)            // 48 tiles x 16*16*32 = the same slab
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i & 7], b[(i >> 3) & 3], acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 48; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    }
+    const uint64_t t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+    if (sum == 12345.678f) sink[blockIdx.x * blockDim.x + threadIdx.x] = sum;
+    if (threadIdx.x == 0) {
+        ticks[blockIdx.x * 2] = t1 - t0;
+        ticks[blockIdx.x * 2 + 1] = r1 - r0;
+    }
+}
+
+template <int SHAPE>
+static void run_shape(const char* name, const char* src, float* sink, uint64_t* ticks, double target_ms) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const double flop_per_it = 2.0 * 192 * 64 * 32 * 8 * 256;   // 8 waves x 256 CUs
+    int iters = 20000;
+    float ms = 0.f;
+    for (int it = 0; it < 4; ++it) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(shape_kernel<SHAPE>, dim3(256), dim3(512), 0, 0, src, iters, sink, ticks);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (it == 0) iters = (int)(iters * target_ms / ms);
+        if (it >= 2) {
+            std::vector<uint64_t> h(512);
+            CK(hipMemcpy(h.data(), ticks, 512 * 8, hipMemcpyDeviceToHost));
+            double cyc = 0, real = 0;
+            for (int i = 0; i < 256; ++i) {
+                cyc += (double)h[2 * i];
+                real += (double)h[2 * i + 1];
+            }
+            printf("%-34s %8.3f ms  %8.1f TFLOP/s  %5.1f %% of 2500  clock %.3f GHz\n", name, ms, flop_per_it * iters / (ms * 1e-3) / 1e12,
+                   flop_per_it * iters / (ms * 1e-3) / 1e12 / 25.0, cyc / real * 0.1);
+        }
+    }
+    fflush(stdout);
+}
+
+// The slab loop of score_filter_r6 re-tiled for v_mfma_f32_16x16x32_bf16: wave tile 192 x 64 = 12 x 4 tiles of 16 x 16, ONE k-step per
+// 32-deep slab (48 MFMAs), A fragments in a ring of 6 registers-quads (reloaded in place 24 MFMAs ahead), the 4 B fragments of the next
+// slab fetched during the current one.  Fragment (16 rows x 32 k): lane l reads row l & 15, 16-byte chunk (l >> 4) ^ ((row >> 1) & 3).
+// FEED as above: 1 ds_read stream only, 2 + direct-to-LDS burst, 5 + the loads spread between the MFMAs.
+template <int FEED>
+__global__ __launch_bounds__(512, 2) void ceiling16_kernel(const char* __restrict__ src, int64_t src_region, int nslab,
+                                                           float* __restrict__ sink, uint64_t* __restrict__ ticks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int xcd = blockIdx.x & 7;
+    const char* base = src + (int64_t)xcd * src_region;
+    __amdgpu_buffer_rsrc_t rs = ring_make_rsrc_n(base, src_region);
+    const int vo = lane * 16;
+    int issued = 0, so = 0;
+    const int so_end = (int)src_region - kStage;
+    auto issue_piece = [&](const int j) {
+        char* st = smem + (issued & 3) * kStage;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (rg_lptr_t)(st + (j * 8 + wave) * 1024), 16, vo, so + (j * 8 + wave) * 1024, 0, 0);
+        if (j == 4) {
+            ++issued;
+            so += kStage;
+            if (so >= so_end) so = 0;
+        }
+    };
+    auto issue = [&]() {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) issue_piece(j);
+    };
+    issue();
+    issue();
+    issue();
+    issue();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int row = lane & 15;
+    const int foff = row * 64 + (((lane >> 4) ^ ((row >> 1) & 3)) << 4);
+    f32x4 acc[12][4];
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // A fragments in a ring of THREE (row block i uses a[i % 3], which is refilled with block i + 3 right after its four MFMAs: 12 MFMAs
+    // = 192 cycles ahead); the 4 B fragments of the next slab are fetched during the last three row blocks of the current one
+    bf16x8_t a[3], b[2][4];
+    const char* a_w0 = smem + wm * (192 * 64) + foff;
+    const char* b_w0 = smem + kAOp + wn * (64 * 64) + foff;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a[i] = *(const bf16x8_t*)(a_w0 + i * 1024);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[0][j] = b[1][j] = *(const bf16x8_t*)(b_w0 + j * 1024);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" ::: "memory");
+    const uint64_t t0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+    auto slab = [&](auto cur_tag, const char* st0, const char* st1) {
+        constexpr int cur = decltype(cur_tag)::value;
+        const char* a_cur = st0 + wm * (192 * 64) + foff;
+        const char* a_nxt = st1 + wm * (192 * 64) + foff;
+        const char* b_nxt = st1 + kAOp + wn * (64 * 64) + foff;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            if (i == 9) {   // blocks 0..11 of this slab are in registers or consumed: the stage is free, the next one must have landed
+                __builtin_amdgcn_sched_barrier(0);
+                if (FEED == 2 || FEED == 5) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(10) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i % 3], b[cur][j], acc[i][j], 0, 0, 0);
+            a[i % 3] = *(const bf16x8_t*)((i + 3 < 12 ? a_cur + (i + 3) * 1024 : a_nxt + (i + 3 - 12) * 1024));
+            if (i >= 9) {
+                b[cur ^ 1][i - 9] = *(const bf16x8_t*)(b_nxt + (i - 9) * 1024);
+                if (i == 11) b[cur ^ 1][3] = *(const bf16x8_t*)(b_nxt + 3 * 1024);
+            }
+            if (FEED == 5) {   // 5 pieces of the slab that goes into the stage just vacated: after row blocks 9, 10, 11 and 1, 3 of the next slab
+                if (i >= 9) issue_piece(i - 9);
+                if (i == 1 || i == 3) issue_piece(3 + (i >> 1));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (FEED == 2) issue();
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+#pragma unroll 1
+    for (int s = 0; s + 1 < nslab; s += 2) {
+        slab(C0{}, smem + (s & 3) * kStage, smem + ((s + 1) & 3) * kStage);
+        slab(C1{}, smem + ((s + 1) & 3) * kStage, smem + ((s + 2) & 3) * kStage);
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    const uint64_t t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sum == 12345.678f) sink[blockIdx.x * blockDim.x + threadIdx.x] = sum;
+    if (threadIdx.x == 0) {
+        ticks[blockIdx.x * 2] = t1 - t0;
+        ticks[blockIdx.x * 2 + 1] = r1 - r0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int FEED>
+static void run16(const char* name, const char* src, int64_t region, float* sink, uint64_t* ticks, double target_ms) {
+    auto k = ceiling16_kernel<FEED>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kStage));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const double flop_per_slab = 2.0 * 384 * 256 * 32 * 256;
+    int nslab = 2000;
+    float ms = 0.f;
+    for (int it = 0; it < 4; ++it) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k, dim3(256), dim3(512), 4 * kStage, 0, src, region, nslab, sink, ticks);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (it == 0) nslab = (int)(nslab * target_ms / ms);
+        if (it >= 2) {
+            std::vector<uint64_t> h(512);
+            CK(hipMemcpy(h.data(), ticks, 512 * 8, hipMemcpyDeviceToHost));
+            double cyc = 0, real = 0;
+            for (int i = 0; i < 256; ++i) {
+                cyc += (double)h[2 * i];
+                real += (double)h[2 * i + 1];
+            }
+            const double tf = flop_per_slab * nslab / (ms * 1e-3) / 1e12;
+            // 48 MFMAs of 16 cycles per slab and wave, 2 waves per SIMD
+            printf("%-34s %8.3f ms  %8.1f TFLOP/s  %5.1f %% of 2500  clock %.3f GHz  pipe-issue %.1f %%\n", name, ms, tf, tf / 25.0,
+                   cyc / real * 0.1, 48.0 * 2 * nslab * 16.0 / (cyc / 256) * 100);
+        }
+    }
+    fflush(stdout);
+}
+
 int main(int argc, char** argv) {
     const double target_ms = argc > 1 ? atof(argv[1]) : 12.0;
     const int64_t region = 16ll << 20;   // per XCD window of the slab source (8 x 16 MiB: Infinity-Cache resident)
@@ -263,6 +487,14 @@ int main(int argc, char** argv) {
     CK(hipMemset(zsrc, 0, region * 8));
     for (int rep = 0; rep < 1; ++rep) {
         printf("---- repetition %d (target %.1f ms per launch) ----\n", rep, target_ms);
+        run16<1>("T16 mfma+ds_read           random", src, region, sink, ticks, target_ms);
+        run16<2>("T16 mfma+ds_read+lds-dma   random", src, region, sink, ticks, target_ms);
+        run16<5>("T16 full, dma interleaved  random", src, region, sink, ticks, target_ms);
+        run16<2>("T16 mfma+ds_read+lds-dma   zeros", zsrc, region, sink, ticks, target_ms);
+        run_shape<32>("shape 32x32x16 mfma-only   random", src, sink, ticks, target_ms);
+        run_shape<16>("shape 16x16x32 mfma-only   random", src, sink, ticks, target_ms);
+        run_shape<32>("shape 32x32x16 mfma-only   zeros", zsrc, sink, ticks, target_ms);
+        run_shape<16>("shape 16x16x32 mfma-only   zeros", zsrc, sink, ticks, target_ms);
         run<8, 0>("W2 mfma-only            random", src, region, sink, ticks, target_ms);
         run<8, 0>("W2 mfma-only            zeros", zsrc, region, sink, ticks, target_ms);
         run<4, 0>("W1 mfma-only            random", src, region, sink, ticks, target_ms);
