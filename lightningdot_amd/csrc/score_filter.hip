@@ -68,6 +68,19 @@ __device__ __forceinline__ float max8_raw(float a0, float a1, float a2, float a3
     return m;
 }
 
+// two such maxima as two INTERLEAVED dependency chains (a dependent VALU instruction cannot issue back to back; 18 asm operands — the
+// limit is 30, so four chains do not fit one statement)
+__device__ __forceinline__ void max8x2_raw(const f32x4& a0, const f32x4& a1, const f32x4& b0, const f32x4& b1, float& ma, float& mb) {
+    asm volatile(
+        "v_max3_f32 %0, %2, %3, %4\n\tv_max3_f32 %1, %10, %11, %12\n\t"
+        "v_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %1, %1, %13, %14\n\t"
+        "v_max3_f32 %0, %0, %7, %8\n\tv_max3_f32 %1, %1, %15, %16\n\t"
+        "v_max_f32 %0, %0, %9\n\tv_max_f32 %1, %1, %17"
+        : "=&v"(ma), "=&v"(mb)
+        : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]),
+          "v"(b0[0]), "v"(b0[1]), "v"(b0[2]), "v"(b0[3]), "v"(b1[0]), "v"(b1[1]), "v"(b1[2]), "v"(b1[3]));
+}
+
 // MFMA -> VALU read hazard cover for the inline-asm accumulator reads of the stand-alone epilogue (the accumulators were written by
 // the MFMAs just issued; hipcc does not pad hazards for inline asm)
 __device__ __forceinline__ void filter_hazard_cover() {
@@ -101,19 +114,19 @@ constexpr int kT16ColBlocks = 4;    // 16-query blocks of a wave tile (64 querie
 // select thresholds them.  Record address in 16-byte units: (q * kPoolCap * 3) * nsubs + sub + (e * 3 + plane) * nsubs with
 // q = q_u + 16 j + (lane & 15) and sub = sub_u + (lane >> 4): pbase_u carries the wave-uniform part (a scalar), the lane's part is
 // derived in the rare path.
+// the compares, ONE wave-uniform branch, and the rare admissions of a pair whose maxima m are complete
 template <bool NOSTORE>
-__device__ __forceinline__ void filter_pair(const f32x4 (&lo)[kT16ColBlocks], const f32x4 (&hi)[kT16ColBlocks], int p,
-                                            const float (&tau)[kT16ColBlocks], uint32_t& curp, uint32_t pbase_u, uint32_t pstep,
-                                            uint32_t nsubs, uint4* __restrict__ pool, int32_t row_wave0) {
+__device__ __forceinline__ void filter_admit(const f32x4 (&lo)[kT16ColBlocks], const f32x4 (&hi)[kT16ColBlocks], int p,
+                                             const float (&m)[kT16ColBlocks], const float (&tau)[kT16ColBlocks], uint32_t& curp,
+                                             uint32_t pbase_u, uint32_t pstep, uint32_t nsubs, uint4* __restrict__ pool,
+                                             int32_t row_wave0) {
+    const bool any = (m[0] >= tau[0]) | (m[1] >= tau[1]) | (m[2] >= tau[2]) | (m[3] >= tau[3]);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(any) == 0, 1)) return;   // (rare otherwise: a few per tile and wave; laid out of line)
 #pragma unroll
     for (int j = 0; j < kT16ColBlocks; ++j) {
         const f32x4 a = lo[j], b = hi[j];
-        const float m = max8_raw(a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]);
-        if (__builtin_expect(m >= tau[j], 0)) {   // rare (a few per tile and wave): laid out of line, the fast path falls through
-            // Rare path: the lane's row offset and the record address are derived HERE.  Their inputs pass through an empty volatile asm,
-            // which cannot be hoisted: left to itself the compiler moves these loop-invariant per-lane computations out of the tile loop,
-            // runs out of registers, spills them — and a scratch RELOAD at a tile boundary is an s_waitcnt vmcnt(0) that drains the three
-            // slabs in flight (measured: 2 us per tile, 0.9 ms per pass).
+        if (m[j] >= tau[j]) {
+            // (the lane's row offset and the record address are derived HERE from lane_now(): see there)
             const uint32_t ln = lane_now();
             const uint32_t e = (curp >> (8 * j)) & 255u;
             if (e < 255u) curp += 1u << (8 * j);
@@ -133,6 +146,17 @@ __device__ __forceinline__ void filter_pair(const f32x4 (&lo)[kT16ColBlocks], co
             }
         }
     }
+}
+
+// maxima (two statements of two interleaved chains) + admission of a pair in one block (first pair of the fused slab, stand-alone epilogue)
+template <bool NOSTORE>
+__device__ __forceinline__ void filter_pair(const f32x4 (&lo)[kT16ColBlocks], const f32x4 (&hi)[kT16ColBlocks], int p,
+                                            const float (&tau)[kT16ColBlocks], uint32_t& curp, uint32_t pbase_u, uint32_t pstep,
+                                            uint32_t nsubs, uint4* __restrict__ pool, int32_t row_wave0) {
+    float m[kT16ColBlocks];
+    max8x2_raw(lo[0], hi[0], lo[1], hi[1], m[0], m[1]);
+    max8x2_raw(lo[2], hi[2], lo[3], hi[3], m[2], m[3]);
+    filter_admit<NOSTORE>(lo, hi, p, m, tau, curp, pbase_u, pstep, nsubs, pool, row_wave0);
 }
 
 // VAR (ablation builds): 1 no epilogue at all, 8 no record stores, 16 tau = +inf (fast path only), 256 no deferral of the slab-load
@@ -275,7 +299,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
             a[i % 3] = *(const bf16x8_t*)(i + 3 < kT16RowBlocks ? a_cur + (i + 3) * 1024 : a_nxt + (i + 3 - kT16RowBlocks) * 1024);
             if (i >= 9) b[CUR ^ 1][i - 9] = *(const bf16x8_t*)(b_nxt + (i - 9) * 1024);
             if (i == 11) b[CUR ^ 1][3] = *(const bf16x8_t*)(b_nxt + 3 * 1024);
-            if (MODE == 2 && i == 8 && !(VAR & 256) && !(VAR & 1)) {
+            if (MODE == 2 && i == 8 && !(VAR & 256) && (!(VAR & 1) || (VAR & 1024))) {
                 __builtin_amdgcn_sched_barrier(0);
                 issue();   // the burst the previous slab deferred
             }
@@ -324,7 +348,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
             slab(M0{}, C1{});
             slab(M0{}, C0{});
         }
-        defer_burst = !(VAR & 256) && !(VAR & 1) && jt + 1 < ntile_total;   // (uniform) the last slab of the tile: see MODE 2
+        defer_burst = !(VAR & 256) && (!(VAR & 1) || (VAR & 1024)) && jt + 1 < ntile_total;   // (uniform) the last slab of the tile: see MODE 2
         slab(M0{}, C1{});
         defer_burst = false;
         // tile jt is complete in acc
@@ -399,6 +423,7 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     if (variant == 128) rk = score_filter_t16_kernel<128>;  // row blocks NOT pinned in program order (the scheduler sinks the fragment loads)
     if (variant == 528) rk = score_filter_t16_kernel<528>;  // tau = +inf, only the wm = 0 waves filter (do the two waves of a SIMD hide each other's filter?)
     if (variant == 512) rk = score_filter_t16_kernel<512>;
+    if (variant == 1041) rk = score_filter_t16_kernel<1041>;  // no epilogue, but the slab-load burst deferred as if there were one
     if (variant == 48) rk = score_filter_t16_kernel<48>;    // tau = +inf, only pair 0 of the fused filter (how the fast path's cost scales)
     LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<6>::kLds));
 #else
