@@ -118,6 +118,7 @@ struct ldot_index {
     bool overflow_was_narrow = false;   // the overflow the last check reported came from the narrow search's candidate buffers
     int64_t redone = 0;                 // queries searched again by the last search (ldot_index_last_stats: dense_pairs stays the dense work)
     bool pend_done = false;             // the narrow search's finish kernel has already written the caller's outputs
+    const void* unstaged_q = nullptr;   // the last search read the caller's fp32 queries directly (DirectOut::qf32): w_q32 / w_q16b are NOT filled
     // a search in two halves (ldot_index_search_begin / _finish): what _finish needs to know
     int64_t pend_nq = 0;
     int pend_k = 0, pend_kp = 0;
@@ -554,7 +555,17 @@ struct DirectOut {
     float* scores;
     int64_t* labels;
     int k;
+    // the caller's queries when they have NOT been staged (fp32 rows in device memory, row stride = d = dpad): the one-launch narrow
+    // search converts them inside the scan kernel and re-scores from them, which saves the conversion kernel of a few-query search
+    const float* qf32 = nullptr;
 };
+
+// <= 16 queries over one scan chunk: everything after the scan is ONE launch (narrow_finish_kernel)
+static bool narrow_one_launch(const ldot_index* ix, int64_t nq, int kp) {
+    int sh, nruns;
+    narrow_plan(ix->ntotal, kp, &sh, &nruns);
+    return nq <= 16 && ix->ntotal <= ((int64_t)1 << 22) && nruns <= 2048 && kp <= 512;
+}
 
 static int narrow_search(ldot_index* ix, int64_t nq, int kp, hipStream_t st, const DirectOut* direct = nullptr) {
     const int64_t wide = (int64_t)1 << 22;
@@ -568,16 +579,17 @@ static int narrow_search(ldot_index* ix, int64_t nq, int kp, hipStream_t st, con
     {
         int sh, nruns;
         narrow_plan(ix->ntotal, kp, &sh, &nruns);
-        if (nq <= 16 && ix->ntotal <= wide && nruns <= 2048 && kp <= 512) {
+        if (narrow_one_launch(ix, nq, kp)) {
             const int64_t nrows = ix->ntotal, nrows_pad = round_up(nrows, 16);
+            const float* qf = direct ? direct->qf32 : nullptr;   // (not staged: see DirectOut)
             if ((rc = ix->w_S.ensure((size_t)16 * nrows_pad * sizeof(float)))) return rc;
             prof_begin(ix, st, 2.0 * nq * nrows * ix->d, (double)nrows * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * nrows * 4);
             rc = launch_score_narrow(ix->w_q16b.p, ix->x16b, ix->ld16(), 0, nrows, (float*)ix->w_S.p, nrows_pad, (int)nq, M,
-                                     kNarrowMaxRuns, sh, 1, st);
+                                     kNarrowMaxRuns, sh, 1, st, qf, ix->d, ix->d);
             prof_end(ix, st);
             if (rc) return rc;
             if ((rc = launch_narrow_finish((const float*)ix->w_S.p, 1, nrows_pad, M, kNarrowMaxRuns, nruns, 16 << sh, nrows, (int)nq,
-                                           (const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, kp,
+                                           qf ? qf : (const float*)ix->w_q32.p, qf ? ix->d : ix->dpad, ix->x32, ix->dpad, ix->dpad, kp,
                                            direct ? direct->k : std::min(kp, 1), ix->rescore, (float*)ix->w_ls.p, (int32_t*)ix->w_li.p,
                                            (float*)ix->w_tau.p, direct ? direct->scores : nullptr, direct ? direct->labels : nullptr,
                                            ix->d_nover, nullptr, 0, nullptr, nullptr, 0, st)))
@@ -653,14 +665,14 @@ static int fused_launch_and_select(ldot_index* ix, int64_t q0, int64_t nq, int64
     const uint16_t* q16 = (const uint16_t*)ix->w_q16b.p + q0 * ix->ld16();
     int32_t* over = (int32_t*)ix->w_over.p + q0;
     const int qg = fused_query_group(nq_pad);
-    const int64_t nslices = 256 / qg, nsubs = kPoolSubsPerSlice * nslices;
+    const int64_t nslices = 256 / qg, nsubs = 4 * nslices;
     int rc;
     prof_begin(ix, st, 2.0 * nq * len * ix->d, (double)len * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * kp * 8);
     rc = launch_score_filter(ix->x16b, ix->ld16(), r, len, q16, ix->ld16(), nq_pad, (int)ix->ld16(), tau, (uint4*)ix->w_pool.p,
                              (int32_t*)ix->w_pool_cnt.p, st);
     prof_end(ix, st);
     if (rc) return rc;
-    if (nq <= kFewSelectMaxQueries && nsubs >= 1024 && kp + 512 + 32 <= 1024) {
+    if (nq <= kFewSelectMaxQueries && nsubs >= 512 && kp + 512 + 32 <= 1024) {
         // few queries: G waves per query fold the sub-pools into partial lists, one merge joins them with the running list
         const int G = 16;
         if ((rc = ix->w_part_s.ensure((size_t)G * nq * kp * 4))) return rc;
@@ -680,7 +692,7 @@ static int fused_launch_and_select(ldot_index* ix, int64_t q0, int64_t nq, int64
 // candidate pools + counters for nq_pad queries (the counters are all-zero between searches)
 static int fused_pools(ldot_index* ix, int64_t nq_pad, hipStream_t st) {
     const int qg = fused_query_group(nq_pad);
-    const int64_t nsubs = kPoolSubsPerSlice * (256 / qg);
+    const int64_t nsubs = 4 * (256 / qg);
     int rc;
     if ((rc = ix->w_pool.ensure((size_t)nq_pad * nsubs * kPoolCap * kPoolRecBytes))) return rc;
     const size_t cnt_bytes = (size_t)nq_pad * nsubs * 4;
@@ -694,18 +706,17 @@ static int fused_pools(ldot_index* ix, int64_t nq_pad, hipStream_t st) {
 static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_pad, int kp, hipStream_t st) {
     int rc;   // (q0 is a multiple of 256: whole 16-row blocks of the query shadow)
     // Pool sizing rule: a launch over `len` rows after `r` scanned rows admits ~kp*len/r candidates per query,
-    // spread over nsubs lane-private sub-pools of kPoolCap records.  Keeping the expectation <= kPoolCap / 4 per sub-pool
-    // (overflow probability ~1e-11 each) bounds len <= r * kFill * nsubs / kp (1024 r / kp at 256 sub-pools; 8x that for the
-    // 2048 sub-pools of a single query block, whose search is then ONE fused launch); the smallest launch is one tile
-    // per row slice, hence the warm-up covers at least bm * nslices * kp / (kFill * nsubs) rows.
-    constexpr int64_t kFill = kPoolCap / 4;
+    // spread over nsubs lane-private sub-pools of kPoolCap records.  Keeping the expectation <= 8 per sub-pool
+    // (overflow probability ~1e-11 each) bounds len <= r * 8 * nsubs / kp (1024 r / kp at 128 sub-pools; 8x that for the
+    // 1024 sub-pools of a single query block, whose search is then ONE fused launch); the smallest launch is one tile
+    // per row slice, hence the warm-up covers at least bm * nslices * kp / (8 * nsubs) rows.
     const int64_t bm = fused_tile_rows();
     const int qg = fused_query_group(nq_pad);
-    const int64_t nslices = 256 / qg, nsubs = kPoolSubsPerSlice * nslices;
-    int64_t warm = std::max<int64_t>(ix->warm_rows, round_up(bm * nslices * (int64_t)kp / (kFill * nsubs), 256));
+    const int64_t nslices = 256 / qg, nsubs = 4 * nslices;
+    int64_t warm = std::max<int64_t>(ix->warm_rows, round_up(bm * nslices * (int64_t)kp / (8 * nsubs), 256));
     // few queries (serving): launches and selects cost more than dense rows -> warm up over just enough rows for ONE fused launch
-    // to cover the rest within the pool bound (len <= r * kFill * nsubs / kp)
-    if (nq <= 64) warm = std::max(warm, round_up(ix->ntotal * kp / (kp + kFill * nsubs) + 1, 256));
+    // to cover the rest within the pool bound (len <= r * 8 * nsubs / kp)
+    if (nq <= 64) warm = std::max(warm, round_up(ix->ntotal * kp / (kp + 8 * nsubs) + 1, 256));
     warm = std::min(ix->ntotal, warm);
     if ((rc = dense_scan_all(ix, nq, 0, warm, kp, (float*)ix->w_tau.p, nq <= 64, st, q0))) return rc;
     if (warm >= ix->ntotal) return LDOT_OK;
@@ -719,7 +730,7 @@ static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_p
     const int64_t growth = nq_pad <= kBM ? std::max<int64_t>(ix->growth_pct, few_growth) : ix->growth_pct;
     int64_t r = warm;
     while (r < ix->ntotal) {
-        int64_t len = std::min<int64_t>(r * growth / 100, r * kFill * nsubs / kp);
+        int64_t len = std::min<int64_t>(r * growth / 100, r * 8 * nsubs / kp);
         len = std::max<int64_t>(len, bm * nslices);
         // whole tiles for every row slice (a launch is as slow as its busiest slice); rounding DOWN keeps the pool bound
         len = len / (bm * nslices) * (bm * nslices);
@@ -860,6 +871,15 @@ static int redo_flagged(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipS
                                 (int32_t*)ix->w_li.p, (float*)ix->w_tau.p, st);
 }
 
+// the queries of a search that read them in place (ldot_index::unstaged_q) -> fp32 + bf16 staging copies, for the recovery paths
+static int stage_unstaged_queries(ldot_index* ix, int64_t nq, hipStream_t st) {
+    if (!ix->unstaged_q) return LDOT_OK;
+    const void* src = ix->unstaged_q;
+    ix->unstaged_q = nullptr;
+    return launch_convert_rows(src, LDOT_F32, ix->d, nq, round_up(nq, kBM), ix->d, ix->dpad, 0, (float*)ix->w_q32.p, nullptr, 0,
+                               (uint16_t*)ix->w_q16b.p, 0, st);
+}
+
 // defer_check: enqueue a fused scan speculatively and leave the overflow check to the caller's own synchronisation point
 static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k,
                              float* tau_out, bool defer_check, hipStream_t st, const DirectOut* direct = nullptr) {
@@ -896,9 +916,6 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
         LDOT_HIP_CHECK(hipMemcpyAsync(ix->w_stage.p, queries, bytes, hipMemcpyHostToDevice, st));
         src = ix->w_stage.p;
     }
-    if ((rc = launch_convert_rows(src, dtype, ix->d, nq, nq_pad, ix->d, ix->dpad, normalize, (float*)ix->w_q32.p,
-                                  nullptr, ix->precision ? 2 : 0, (uint16_t*)ix->w_q16b.p, 0, st)))
-        return rc;
     float* tau = (float*)ix->w_tau.p;
     // (the narrow search writes complete lists and thresholds itself)
     bool narrow = ix->ntotal > 0 && ix->mode == LDOT_MODE_AUTO && narrow_select_ok(ix, nq, kp);
@@ -906,13 +923,30 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
         --ix->narrow_backoff;
         narrow = false;
     }
+    // A few fp32 device queries answered by the one-launch narrow search with kernel-written outputs are not staged at all: the scan
+    // converts them itself (the recovery of an overflowed search stages them then, stage_unstaged_queries).
+    DirectOut direct_q;
+    ix->unstaged_q = nullptr;
+    if (narrow && direct && narrow_one_launch(ix, nq, kp) && dtype == LDOT_F32 && mem == LDOT_DEVICE && !normalize && !ix->precision &&
+        ix->d == ix->dpad && ((uintptr_t)queries & 15) == 0) {
+        direct_q = *direct;
+        direct_q.qf32 = (const float*)queries;
+        direct = &direct_q;
+        ix->unstaged_q = queries;
+    } else if ((rc = launch_convert_rows(src, dtype, ix->d, nq, nq_pad, ix->d, ix->dpad, normalize, (float*)ix->w_q32.p, nullptr,
+                                         ix->precision ? 2 : 0, (uint16_t*)ix->w_q16b.p, 0, st))) {
+        return rc;
+    }
     if (!narrow && (rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, tau, nq, nq_pad, st))) return rc;
 
     if (narrow) {
         if ((rc = narrow_search(ix, nq, kp, st, direct))) return rc;
         if (!defer_check) {
             LDOT_HIP_CHECK(hipStreamSynchronize(st));
-            if (fused_overflow_check(ix) && (rc = redo_flagged(ix, nq, nq_pad, kp, st))) return rc;
+            if (fused_overflow_check(ix)) {
+                if ((rc = stage_unstaged_queries(ix, nq, st))) return rc;
+                if ((rc = redo_flagged(ix, nq, nq_pad, kp, st))) return rc;
+            }
         }
     } else if (ix->ntotal > 0) {
         // AUTO: the fused scan pays off from ~32k rows (tools/auto_threshold.py); very large batches (COCO-5k sized image->text
@@ -1042,6 +1076,7 @@ int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dty
         LDOT_HIP_CHECK(hipStreamSynchronize(st));
         prof_collect(ix, st);
         if (fused_overflow_check(ix)) {
+            if ((rc = stage_unstaged_queries(ix, nq, st))) return rc;
             if ((rc = redo_flagged(ix, nq, round_up(nq, kBM), ix->pend_kp, st))) return rc;
             return search_finish_impl(ix, nullptr, out_scores, out_labels, out_mem, false, st);
         }

@@ -27,11 +27,27 @@ template <int UNR, int QG, int THREADS, int PF>
 __global__ __launch_bounds__(THREADS) void score_narrow_kernel(const char* __restrict__ Q16b, const char* __restrict__ X16b,
                                                                int nslab, int64_t g0, int64_t ngroups, int per, int64_t nrows,
                                                                float* __restrict__ S, int64_t lds_elems, int nq,
-                                                               uint32_t* __restrict__ M, int64_t ldm, int run_shift, int tiled) {
+                                                               uint32_t* __restrict__ M, int64_t ldm, int run_shift, int tiled,
+                                                               const float* __restrict__ Qf32, int64_t ldqf, int d) {
     // QG * nslab KiB: query blocks 0 .. QG-1 of the blocked query shadow (block (g, s) at (g * nslab + s) KiB, like the source)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
-    for (int i = tid; i < QG * nslab * 64; i += THREADS) ((uint4*)smem)[i] = ((const uint4*)Q16b)[i];
+    if (QG == 1 && Qf32 != nullptr) {
+        // (uniform) the caller's fp32 query rows, not yet staged: every workgroup builds the one blocked bf16 query block itself
+        // (convert.hip's layout and rounding: element (r, c) at block c / 32, row r, column c % 32; rows >= nq and columns >= d are zero)
+        // — a search of <= 16 queries then needs no conversion kernel in front of the scan
+        for (int i = tid; i < nslab * 64; i += THREADS) ((uint4*)smem)[i] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        for (int r = 0; r < nq; ++r)
+            for (int c = tid * 4; c < d; c += THREADS * 4) {   // (d is a multiple of 32, the rows are 16-byte aligned: caller's contract)
+                const float4 v = *(const float4*)(Qf32 + (int64_t)r * ldqf + c);
+                uint16_t* o = (uint16_t*)smem + (c >> 5) * 512 + r * 32 + (c & 31);
+                *(uint2*)o = make_uint2((uint32_t)f32_to_bf16_bits(v.x) | ((uint32_t)f32_to_bf16_bits(v.y) << 16),
+                                        (uint32_t)f32_to_bf16_bits(v.z) | ((uint32_t)f32_to_bf16_bits(v.w) << 16));
+            }
+    } else {
+        for (int i = tid; i < QG * nslab * 64; i += THREADS) ((uint4*)smem)[i] = ((const uint4*)Q16b)[i];
+    }
     __syncthreads();
     const int lane = tid & 63;
     // a wave owns `per` CONSECUTIVE groups: one contiguous stream of per * nslab KiB, and a run maximum is raised once per run the
@@ -125,9 +141,13 @@ static bool g_narrow_attr[9][64];   // hipFuncSetAttribute once per kernel varia
 // [16 queries][16 rows] with QG = 1, 2, 4 for nq <= 16, 32, 64 (what the run-maxima selection reads; coalesced stores).
 // M (optional, all zero on entry): M[q][r] = ascending key (~desc_key) of the max score of query q over the VALID rows of
 // run r = rows [r * (16 << run_shift), (r + 1) * (16 << run_shift)) of the launch.
+// qf32 (optional, nq <= 16 only): the queries as fp32 rows [nq][d] with row stride ldqf, converted by the kernel itself (q16b unused)
 int launch_score_narrow(const void* q16b, const void* x16b, int64_t ld_elems, int64_t xrow0, int64_t nrows, float* S,
-                        int64_t lds_elems, int nq, uint32_t* M, int64_t ldm, int run_shift, int tiled, hipStream_t st) {
+                        int64_t lds_elems, int nq, uint32_t* M, int64_t ldm, int run_shift, int tiled, hipStream_t st,
+                        const float* qf32, int64_t ldqf, int d) {
     if (nrows <= 0 || nq <= 0) return LDOT_OK;
+    LDOT_REQUIRE(qf32 == nullptr || (nq <= 16 && d <= ld_elems && d % 32 == 0 && ldqf % 4 == 0 && ((uintptr_t)qf32 & 15) == 0), LDOT_EINVAL,
+                 "fp32 query rows: at most 16 queries, d a multiple of 32, 16-byte aligned rows");
     const int nslab = (int)(ld_elems / 32);
     const int qg = nq <= 16 ? 1 : nq <= 32 ? 2 : 4;
     LDOT_REQUIRE(nq <= kNarrowMaxQueries && xrow0 % 16 == 0 && ld_elems % 64 == 0 && nslab * qg <= kNarrowMaxLdsKiB && run_shift >= 0,
@@ -156,7 +176,7 @@ int launch_score_narrow(const void* q16b, const void* x16b, int64_t ld_elems, in
             if (dev < 64) g_narrow_attr[SLOT][dev] = true;                                                                     \
         }                                                                                                                      \
         hipLaunchKernelGGL((score_narrow_kernel<U, QG, T, PFV>), dim3(grid), dim3(T), lds, st, q, x, nslab, xrow0 / 16, ngroups,    \
-                           (int)per, nrows, S, lds_elems, nq, M, ldm, run_shift, tiled);                                              \
+                           (int)per, nrows, S, lds_elems, nq, M, ldm, run_shift, tiled, qf32, ldqf, d);                                              \
     } while (0)
 #define LDOT_NARROW_U(U, SLOT)               \
     do {                                     \

@@ -705,8 +705,8 @@ __global__ __launch_bounds__(256) void parts_to_lists_kernel(const float* __rest
 constexpr int kPoolSelThreads = 64;
 // A step (one entry level of 64 sub-pools = 64 records of 8 scores) appends at most 512 candidates on top of a full list,
 // which sizes the LDS key buffer (cap >= kp + 512) and with it the workgroups per CU.  (LV: unused, kept for the launch sites.)
-// rows of the 8 scores of a record relative to its base row (the lane's 4 rows of a 16x16 MFMA tile and of the tile below it)
-__device__ __forceinline__ int pool_rec_row(int j) { return j < 4 ? j : j - 4 + kPoolRecHiRow; }
+// rows of the 8 scores of a record relative to its base row (accumulator registers 8h..8h+3 / 8h+4..8h+7 of a 32x32 MFMA tile)
+__device__ __forceinline__ int pool_rec_row(int j) { return j < 4 ? j : j + 4; }
 
 // Walk the records of 64 sub-pools (lane l holds the clamped count c of sub-pool sidx = s0 + l).  The counts are small and uneven
 // (1.5 on average, 6-10 at the fullest sub-pool), so walking LEVEL by level (entry e of every sub-pool per round) costs as many
@@ -759,76 +759,10 @@ __device__ __forceinline__ void walk_subpools(WaveSelector& sel, const uint4* __
             sel.push(make_key(__uint_as_float(p0.y), (uint32_t)(r + 1)), r + 1 < row_end);
             sel.push(make_key(__uint_as_float(p0.z), (uint32_t)(r + 2)), r + 2 < row_end);
             sel.push(make_key(__uint_as_float(p0.w), (uint32_t)(r + 3)), r + 3 < row_end);
-            sel.push(make_key(__uint_as_float(p1.x), (uint32_t)(r + kPoolRecHiRow + 0)), r + kPoolRecHiRow + 0 < row_end);
-            sel.push(make_key(__uint_as_float(p1.y), (uint32_t)(r + kPoolRecHiRow + 1)), r + kPoolRecHiRow + 1 < row_end);
-            sel.push(make_key(__uint_as_float(p1.z), (uint32_t)(r + kPoolRecHiRow + 2)), r + kPoolRecHiRow + 2 < row_end);
-            sel.push(make_key(__uint_as_float(p1.w), (uint32_t)(r + kPoolRecHiRow + 3)), r + kPoolRecHiRow + 3 < row_end);
-        }
-    }
-}
-
-// The same walk over FOUR groups of 64 sub-pools at once (lane l holds the clamped counts c[g] of sub-pools s0 + 64 g + l): the records of
-// 256 sub-pools are numbered by one scan (two packed 16-bit fields per register) and dealt 64 per round, so a launch that left ~200
-// records per query in 256 sub-pools costs ceil(T / 64) = 3-4 dependent round trips instead of one scan + at least one round per group
-// of 64 (the re-tiled filter kernel has 8 sub-pools per row slice: 256 per query at the large-batch geometry, 128 before).
-__device__ __forceinline__ void walk_subpools4(WaveSelector& sel, const uint4* __restrict__ base, int nsubs, int s0, const int (&c)[4],
-                                               int32_t row_end, unsigned char* slot) {
-    const int lane = threadIdx.x & 63;
-    uint32_t i01 = (uint32_t)c[0] | ((uint32_t)c[1] << 16), i23 = (uint32_t)c[2] | ((uint32_t)c[3] << 16);   // (a field sums to <= 64 * kPoolCap)
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t u01 = __shfl_up(i01, o), u23 = __shfl_up(i23, o);
-        if (lane >= o) {
-            i01 += u01;
-            i23 += u23;
-        }
-    }
-    const uint32_t t01 = __shfl(i01, 63), t23 = __shfl(i23, 63);
-    const int T0 = (int)(t01 & 0xffffu), T1 = (int)(t01 >> 16), T2 = (int)(t23 & 0xffffu), T3 = (int)(t23 >> 16);
-    int excl[4];
-    excl[0] = (int)(i01 & 0xffffu) - c[0];
-    excl[1] = T0 + (int)(i01 >> 16) - c[1];
-    excl[2] = T0 + T1 + (int)(i23 & 0xffffu) - c[2];
-    excl[3] = T0 + T1 + T2 + (int)(i23 >> 16) - c[3];
-    const int T = T0 + T1 + T2 + T3;
-    for (int w0 = 0; w0 < T; w0 += kSlotWin) {
-        WaveSelector::wave_sync();                       // the previous window's reads are done
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            for (int i = 0; i < c[g]; ++i) {
-                const int j = excl[g] + i - w0;
-                if (j >= 0 && j < kSlotWin) slot[j] = (unsigned char)(lane | (g << 6));
-            }
-        WaveSelector::wave_sync();
-        const int wend = min(T, w0 + kSlotWin);
-        uint4 n0, n1;
-        int32_t nr;
-        auto fetch = [&](int r0) {
-            const int j = r0 + lane;
-            const bool have = j < wend;
-            const int sub = have ? (int)slot[j - w0] : 0;
-            const int l = sub & 63, g = sub >> 6;
-            const int x0 = __shfl(excl[0], l), x1 = __shfl(excl[1], l), x2 = __shfl(excl[2], l), x3 = __shfl(excl[3], l);
-            const int e = j - (g == 0 ? x0 : g == 1 ? x1 : g == 2 ? x2 : x3);
-            const uint4* rec = base + (int64_t)e * kPoolPlanes * nsubs + s0 + sub;
-            n0 = have ? rec[0] : make_uint4(0u, 0u, 0u, 0u);
-            n1 = have ? rec[nsubs] : make_uint4(0u, 0u, 0u, 0u);
-            nr = have ? (int32_t)rec[2 * nsubs].x : row_end;
-        };
-        fetch(w0);
-        for (int r0 = w0; r0 < wend; r0 += 64) {
-            const uint4 p0 = n0, p1 = n1;
-            const int32_t r = nr;
-            if (r0 + 64 < wend) fetch(r0 + 64);
-            sel.reserve(8 * kPoolSelThreads + kSlotKeys);
-            sel.push(make_key(__uint_as_float(p0.x), (uint32_t)(r + 0)), r + 0 < row_end);
-            sel.push(make_key(__uint_as_float(p0.y), (uint32_t)(r + 1)), r + 1 < row_end);
-            sel.push(make_key(__uint_as_float(p0.z), (uint32_t)(r + 2)), r + 2 < row_end);
-            sel.push(make_key(__uint_as_float(p0.w), (uint32_t)(r + 3)), r + 3 < row_end);
-            sel.push(make_key(__uint_as_float(p1.x), (uint32_t)(r + kPoolRecHiRow + 0)), r + kPoolRecHiRow + 0 < row_end);
-            sel.push(make_key(__uint_as_float(p1.y), (uint32_t)(r + kPoolRecHiRow + 1)), r + kPoolRecHiRow + 1 < row_end);
-            sel.push(make_key(__uint_as_float(p1.z), (uint32_t)(r + kPoolRecHiRow + 2)), r + kPoolRecHiRow + 2 < row_end);
-            sel.push(make_key(__uint_as_float(p1.w), (uint32_t)(r + kPoolRecHiRow + 3)), r + kPoolRecHiRow + 3 < row_end);
+            sel.push(make_key(__uint_as_float(p1.x), (uint32_t)(r + 8)), r + 8 < row_end);
+            sel.push(make_key(__uint_as_float(p1.y), (uint32_t)(r + 9)), r + 9 < row_end);
+            sel.push(make_key(__uint_as_float(p1.z), (uint32_t)(r + 10)), r + 10 < row_end);
+            sel.push(make_key(__uint_as_float(p1.w), (uint32_t)(r + 11)), r + 11 < row_end);
         }
     }
 }
@@ -857,28 +791,24 @@ __global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(con
     float* ls = list_s + q * kp;
     int32_t* li = list_i + q * kp;
     int32_t* cnt = pool_cnt + q * (int64_t)nsubs;
-    // counters of the first 256 sub-pools are requested before the list so that both round trips overlap
-    int cn[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) cn[g] = g * 64 + lane < nsubs ? cnt[g * 64 + lane] : 0;
+    // counters of the first 64 sub-pools are requested before the list so that both round trips overlap
+    int cn = lane < nsubs ? cnt[lane] : 0;
     if (!(dbg & 4)) sel.load_list(ls, li);
     bool over = false;
     int nrec = 0;   // records of this query in this launch (statistics)
     // entry-major, plane-major pools: plane p of level e of all sub-pools is one contiguous run of 16-byte words -> coalesced
-    // reads of the few levels in use.  Four groups of 64 sub-pools per step (walk_subpools4), the next step's counters in flight.
+    // reads of the few levels in use.  One group of 64 sub-pools x LV entry levels per step.
     const uint4* base = pool + q * (int64_t)kPoolCap * kPoolPlanes * nsubs;
-    for (int s0 = 0; s0 < nsubs; s0 += 4 * kPoolSelThreads) {
-        int c[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int sidx = s0 + g * 64 + lane;
-            over |= cn[g] > kPoolCap;
-            c[g] = (dbg & 1) ? 0 : cn[g] < kPoolCap ? cn[g] : kPoolCap;
-            nrec += cn[g] < kPoolCap ? cn[g] : kPoolCap;
-            if (sidx < nsubs) cnt[sidx] = 0;
-            cn[g] = sidx + 4 * kPoolSelThreads < nsubs ? cnt[sidx + 4 * kPoolSelThreads] : 0;   // next step's counters
-        }
-        walk_subpools4(sel, base, nsubs, s0, c, row_end, slot);
+    // One group of 64 sub-pools per step, one entry level per iteration with the next level's record in flight (a single
+    // feed site: the selector's compaction is inlined there once).
+    for (int s0 = 0; s0 < nsubs; s0 += kPoolSelThreads) {
+        const int sidx = s0 + lane;
+        over |= cn > kPoolCap;
+        const int c = cn < kPoolCap ? cn : kPoolCap;
+        nrec += c;
+        if (sidx < nsubs) cnt[sidx] = 0;
+        cn = sidx + kPoolSelThreads < nsubs ? cnt[sidx + kPoolSelThreads] : 0;   // next step's counters
+        walk_subpools(sel, base, nsubs, s0, (dbg & 1) ? 0 : c, row_end, slot);
     }
     const bool any_over = __any(over);
     if (dbg & 2) return;

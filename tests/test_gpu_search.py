@@ -368,6 +368,14 @@ def test_narrow_search_full_candidate_buffer_falls_back(L):
     assert ix.last_stats()['overflowed_queries'] == 0
     np.testing.assert_array_equal(l, l1)
     np.testing.assert_array_equal(s, s1)
+    # the same through the route that does not stage the queries (fp32 device queries, kernel-written outputs: the scan converts them
+    # itself, the recovery stages them after the fact)
+    import torch
+    ix3 = _index(x)
+    s3, l3 = ix3.search_tensors(torch.from_numpy(q).cuda(), 200)
+    assert ix3.last_stats()['overflowed_queries'] == 2
+    np.testing.assert_array_equal(l3.cpu().numpy(), l)
+    np.testing.assert_array_equal(s3.cpu().numpy(), s)
     # an ordinary search afterwards is clean again (counters were left zero)
     x2 = rng.standard_normal((50_000, 64)).astype(np.float32)
     ix2 = _index(x2)
