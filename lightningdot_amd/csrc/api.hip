@@ -119,6 +119,11 @@ struct ldot_index {
     int64_t redone = 0;                 // queries searched again by the last search (ldot_index_last_stats: dense_pairs stays the dense work)
     bool pend_done = false;             // the narrow search's finish kernel has already written the caller's outputs
     const void* unstaged_q = nullptr;   // the last search read the caller's fp32 queries directly (DirectOut::qf32): w_q32 / w_q16b are NOT filled
+    int64_t unstaged_ld = 0;            // ... their row stride
+    // set by ldot_ivf_search around its coarse search (an internal chain, not part of the ABI): the queries are fp32 rows padded with zeros
+    // to dpad columns (row stride dpad), and a search whose finish kernel wrote the outputs returns WITHOUT the synchronisation + buffer-full
+    // check — the chain checks at its own synchronisation point (overflow_pending stays set)
+    bool q_prepadded = false, chain_defer_sync = false;
     // a search in two halves (ldot_index_search_begin / _finish): what _finish needs to know
     int64_t pend_nq = 0;
     int pend_k = 0, pend_kp = 0;
@@ -558,6 +563,7 @@ struct DirectOut {
     // the caller's queries when they have NOT been staged (fp32 rows in device memory, row stride = d = dpad): the one-launch narrow
     // search converts them inside the scan kernel and re-scores from them, which saves the conversion kernel of a few-query search
     const float* qf32 = nullptr;
+    int64_t ldqf = 0;   // ... their row stride = the number of columns the kernels read (d, or dpad for zero-padded rows)
 };
 
 // <= 16 queries over one scan chunk: everything after the scan is ONE launch (narrow_finish_kernel)
@@ -585,11 +591,11 @@ static int narrow_search(ldot_index* ix, int64_t nq, int kp, hipStream_t st, con
             if ((rc = ix->w_S.ensure((size_t)16 * nrows_pad * sizeof(float)))) return rc;
             prof_begin(ix, st, 2.0 * nq * nrows * ix->d, (double)nrows * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * nrows * 4);
             rc = launch_score_narrow(ix->w_q16b.p, ix->x16b, ix->ld16(), 0, nrows, (float*)ix->w_S.p, nrows_pad, (int)nq, M,
-                                     kNarrowMaxRuns, sh, 1, st, qf, ix->d, ix->d);
+                                     kNarrowMaxRuns, sh, 1, st, qf, qf ? direct->ldqf : 0, qf ? (int)direct->ldqf : 0);
             prof_end(ix, st);
             if (rc) return rc;
             if ((rc = launch_narrow_finish((const float*)ix->w_S.p, 1, nrows_pad, M, kNarrowMaxRuns, nruns, 16 << sh, nrows, (int)nq,
-                                           qf ? qf : (const float*)ix->w_q32.p, qf ? ix->d : ix->dpad, ix->x32, ix->dpad, ix->dpad, kp,
+                                           qf ? qf : (const float*)ix->w_q32.p, qf ? direct->ldqf : ix->dpad, ix->x32, ix->dpad, ix->dpad, kp,
                                            direct ? direct->k : std::min(kp, 1), ix->rescore, (float*)ix->w_ls.p, (int32_t*)ix->w_li.p,
                                            (float*)ix->w_tau.p, direct ? direct->scores : nullptr, direct ? direct->labels : nullptr,
                                            ix->d_nover, nullptr, 0, nullptr, nullptr, 0, st)))
@@ -876,7 +882,7 @@ static int stage_unstaged_queries(ldot_index* ix, int64_t nq, hipStream_t st) {
     if (!ix->unstaged_q) return LDOT_OK;
     const void* src = ix->unstaged_q;
     ix->unstaged_q = nullptr;
-    return launch_convert_rows(src, LDOT_F32, ix->d, nq, round_up(nq, kBM), ix->d, ix->dpad, 0, (float*)ix->w_q32.p, nullptr, 0,
+    return launch_convert_rows(src, LDOT_F32, ix->unstaged_ld, nq, round_up(nq, kBM), ix->d, ix->dpad, 0, (float*)ix->w_q32.p, nullptr, 0,
                                (uint16_t*)ix->w_q16b.p, 0, st);
 }
 
@@ -928,13 +934,15 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
     DirectOut direct_q;
     ix->unstaged_q = nullptr;
     if (narrow && direct && narrow_one_launch(ix, nq, kp) && dtype == LDOT_F32 && mem == LDOT_DEVICE && !normalize && !ix->precision &&
-        ix->d == ix->dpad && ((uintptr_t)queries & 15) == 0) {
+        (ix->d == ix->dpad || ix->q_prepadded) && ((uintptr_t)queries & 15) == 0) {
         direct_q = *direct;
         direct_q.qf32 = (const float*)queries;
+        direct_q.ldqf = ix->q_prepadded ? ix->dpad : ix->d;
         direct = &direct_q;
         ix->unstaged_q = queries;
-    } else if ((rc = launch_convert_rows(src, dtype, ix->d, nq, nq_pad, ix->d, ix->dpad, normalize, (float*)ix->w_q32.p, nullptr,
-                                         ix->precision ? 2 : 0, (uint16_t*)ix->w_q16b.p, 0, st))) {
+        ix->unstaged_ld = direct_q.ldqf;
+    } else if ((rc = launch_convert_rows(src, dtype, ix->q_prepadded ? ix->dpad : ix->d, nq, nq_pad, ix->d, ix->dpad, normalize,
+                                         (float*)ix->w_q32.p, nullptr, ix->precision ? 2 : 0, (uint16_t*)ix->w_q16b.p, 0, st))) {
         return rc;
     }
     if (!narrow && (rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, tau, nq, nq_pad, st))) return rc;
@@ -1073,6 +1081,7 @@ int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dty
     if (ix->pend_nq == 0) return LDOT_OK;
     if (ix->pend_done) {   // the results are on their way already; the one synchronisation of the search + the buffer-full check
         ix->pend_done = false;
+        if (ix->chain_defer_sync) return LDOT_OK;   // (internal chain: the caller synchronises and checks, see ldot_ivf_search)
         LDOT_HIP_CHECK(hipStreamSynchronize(st));
         prof_collect(ix, st);
         if (fused_overflow_check(ix)) {
@@ -1174,8 +1183,17 @@ static int lists_search_impl(ldot_index* ix, const void* queries, int64_t nq, in
         const char* pr = (const char*)probes + (size_t)q0 * nprobe * psz;
         float* ds = out_mem == LDOT_DEVICE ? out_scores + q0 * k : (float*)ix->w_outs.p;
         int64_t* dl = out_mem == LDOT_DEVICE ? out_labels + q0 * k : (int64_t*)ix->w_outl.p;
-        if ((rc = launch_convert_rows(src, dtype, ix->d, n, n, ix->d, ix->dpad, normalize, (float*)ix->w_q32.p, nullptr, 0, nullptr, 0,
-                                      st)))
+        // fp32 rows whose stride is the padded one are read where they are (no conversion kernel); the padded-list fallback stages them
+        const bool inplace = dtype == LDOT_F32 && !normalize && ix->d == ix->dpad && ((uintptr_t)src & 15) == 0;
+        const float* q32p = inplace ? (const float*)src : (const float*)ix->w_q32.p;
+        bool staged = !inplace;
+        auto stage = [&]() -> int {
+            if (staged) return LDOT_OK;
+            staged = true;
+            return launch_convert_rows(src, dtype, ix->d, n, n, ix->d, ix->dpad, normalize, (float*)ix->w_q32.p, nullptr, 0, nullptr, 0, st);
+        };
+        if (!inplace && (rc = launch_convert_rows(src, dtype, ix->d, n, n, ix->d, ix->dpad, normalize, (float*)ix->w_q32.p, nullptr, 0,
+                                                  nullptr, 0, st)))
             return rc;
         // validated list ids (int32) + the per-query prefix sums of the list lengths
         if ((rc = launch_ivf_prefix(pr, probes_int64 ? 1 : 0, n, nprobe, nlist, list_offsets, plist, rowbase, cstart, st)))
@@ -1200,19 +1218,19 @@ static int lists_search_impl(ldot_index* ix, const void* queries, int64_t nq, in
 #endif
             if (scan16) {
                 if ((rc = ix->w_q16b.ensure((size_t)round_up(n, 16) * ix->ld16() * 2))) return rc;
-                if ((rc = launch_convert_rows(ix->w_q32.p, LDOT_F32, ix->dpad, n, round_up(n, 16), ix->d, ix->dpad, 0, nullptr, nullptr, 0,
+                if ((rc = launch_convert_rows(q32p, LDOT_F32, ix->dpad, n, round_up(n, 16), ix->d, ix->dpad, 0, nullptr, nullptr, 0,
                                               (uint16_t*)ix->w_q16b.p, 0, st)))
                     return rc;
                 if ((rc = launch_ivf_scan_bf16(ix->w_q16b.p, ix->x16b, ix->ld16(), n, rowbase, cstart, nprobe, max_cols, run_shift,
                                                (float*)ix->w_S.p, max_cols, M, nruns, st)))
                     return rc;
                 if ((rc = launch_narrow_finish((const float*)ix->w_S.p, 0, max_cols, M, nruns, (int)nruns, run, max_cols, (int)n,
-                                               (const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, kpb, k, 1, nullptr,
+                                               q32p, ix->dpad, ix->x32, ix->dpad, ix->dpad, kpb, k, 1, nullptr,
                                                nullptr, nullptr, ds, dl, ix->d_nover, cstart + nprobe, nprobe + 1, rowbase, cstart, nprobe,
                                                st)))
                     return rc;
             } else {
-            if ((rc = launch_ivf_scan((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, n, rowbase, cstart, nprobe,
+            if ((rc = launch_ivf_scan(q32p, ix->dpad, ix->x32, ix->dpad, ix->dpad, n, rowbase, cstart, nprobe,
                                       max_cols, run_shift, (float*)ix->w_S.p, max_cols, M, nruns, st)))
                 return rc;
             if (few && kp <= kpb) {
@@ -1242,7 +1260,7 @@ static int lists_search_impl(ldot_index* ix, const void* queries, int64_t nq, in
                 }
             }
         }
-        if (redo && (rc = lists_chunk_padded(ix, n, list_offsets, nlist, lpad, plist, nprobe, k, kp, ds, dl, st))) return rc;
+        if (redo && ((rc = stage()) || (rc = lists_chunk_padded(ix, n, list_offsets, nlist, lpad, plist, nprobe, k, kp, ds, dl, st)))) return rc;
         ix->stats[2] += n * max_cols;
         if (out_mem == LDOT_HOST) {
             LDOT_HIP_CHECK(hipMemcpyAsync(out_scores + q0 * k, ds, (size_t)n * k * 4, hipMemcpyDeviceToHost, st));
@@ -1288,17 +1306,39 @@ int ldot_ivf_search(ldot_index_t* ix, ldot_index_t* coarse, const void* queries,
     DeviceGuard guard(ix->device);
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    // augmented queries [q, 0, 1] (fp32) and the coarse result (probe labels) live in workspaces of the ROW index
-    const int da = ix->d + 2;
-    if ((rc = ix->w_laug.ensure((size_t)nq * da * 4))) return rc;
+    // augmented queries [q, 0, 1] (fp32, rows padded with zeros to the coarse index's row stride: a few queries are then read in place
+    // by its scan, no conversion kernel) and the coarse result (probe labels) live in workspaces of the ROW index
+    const int da_ld = coarse->dpad;
+    if ((rc = ix->w_laug.ensure((size_t)nq * da_ld * 4))) return rc;
     if ((rc = ix->w_lprobe_s.ensure((size_t)nq * nprobe * 4))) return rc;
     if ((rc = ix->w_lprobe_l.ensure((size_t)nq * nprobe * 8))) return rc;
-    if ((rc = launch_augment_queries(queries, dtype, ix->d, nq, normalize, (float*)ix->w_laug.p, st))) return rc;
-    if ((rc = ldot_index_search(coarse, ix->w_laug.p, nq, LDOT_F32, LDOT_DEVICE, 0, nprobe, (float*)ix->w_lprobe_s.p,
-                                (int64_t*)ix->w_lprobe_l.p, LDOT_DEVICE, stream)))
-        return rc;
-    return lists_search_impl(ix, queries, nq, dtype, normalize, list_offsets, (int)nlist, max_list_len, ix->w_lprobe_l.p, true, nprobe, k,
-                             out_scores, out_labels, out_mem, st);
+    if ((rc = launch_augment_queries(queries, dtype, ix->d, nq, normalize, (float*)ix->w_laug.p, da_ld, st))) return rc;
+    // The coarse search of a few queries ends in a kernel that writes the probes itself; its synchronisation + buffer-full check is
+    // DEFERRED to the synchronisation of the list stage (one host round trip per search instead of two).  A full coarse buffer
+    // (thousands of centroids with equal scores) is then found after the fact and the search repeated the plain way.
+    coarse->q_prepadded = true;
+    coarse->chain_defer_sync = true;
+    rc = ldot_index_search(coarse, ix->w_laug.p, nq, LDOT_F32, LDOT_DEVICE, 0, nprobe, (float*)ix->w_lprobe_s.p,
+                           (int64_t*)ix->w_lprobe_l.p, LDOT_DEVICE, stream);
+    coarse->chain_defer_sync = false;
+    const bool unchecked = rc == LDOT_OK && coarse->overflow_pending;
+    if (rc == LDOT_OK)
+        rc = lists_search_impl(ix, queries, nq, dtype, normalize, list_offsets, (int)nlist, max_list_len, ix->w_lprobe_l.p, true, nprobe, k,
+                               out_scores, out_labels, out_mem, st);
+    if (rc == LDOT_OK && unchecked) {
+        LDOT_HIP_CHECK(hipStreamSynchronize(st));
+        if (fused_overflow_check(coarse)) {   // (what ldot_index_search does at its own synchronisation point)
+            if ((rc = stage_unstaged_queries(coarse, nq, st)) == LDOT_OK &&
+                (rc = redo_flagged(coarse, nq, round_up(nq, kBM), coarse->pend_kp, st)) == LDOT_OK)
+                rc = search_finish_impl(coarse, nullptr, (float*)ix->w_lprobe_s.p, (int64_t*)ix->w_lprobe_l.p, LDOT_DEVICE, false, st);
+            if (rc == LDOT_OK)
+                rc = lists_search_impl(ix, queries, nq, dtype, normalize, list_offsets, (int)nlist, max_list_len, ix->w_lprobe_l.p, true,
+                                       nprobe, k, out_scores, out_labels, out_mem, st);
+        }
+    }
+    coarse->pend_nq = 0;
+    coarse->q_prepadded = false;
+    return rc;
 }
 
 int ldot_index_last_profile(const ldot_index_t* ix, double out[4]) {

@@ -110,7 +110,7 @@ int launch_row_norm_max(const float* x32, int64_t ld, int64_t n, int d, float* o
 // distance in the augmented space.  One wave per query.
 template <int DT>
 __global__ __launch_bounds__(256) void augment_queries_kernel(const void* __restrict__ src, int d, int64_t n, int normalize,
-                                                              float* __restrict__ dst) {
+                                                              float* __restrict__ dst, int ld_dst) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void augment_queries_kernel(const void* __rest
         const double nrm = sqrt(ss);
         scale = (float)(1.0 / (nrm > 1e-12 ? nrm : 1e-12));
     }
-    float* out = dst + row * (d + 2);
+    float* out = dst + row * (int64_t)ld_dst;
     for (int c = lane; c < d; c += 64) {
         const float v = load_elem<DT>(src, row * d + c);
         out[c] = normalize ? v * scale : v;
@@ -135,20 +135,23 @@ __global__ __launch_bounds__(256) void augment_queries_kernel(const void* __rest
         out[d] = 0.f;
         out[d + 1] = 1.f;
     }
+    for (int c = d + 2 + lane; c < ld_dst; c += 64) out[c] = 0.f;   // (rows padded to the coarse index's row stride: see ldot_ivf_search)
 }
 
-int launch_augment_queries(const void* src, int dtype, int d, int64_t n, int normalize, float* dst, hipStream_t st) {
+// dst rows: [q, 0, 1, 0 ...] with row stride ld_dst >= d + 2
+int launch_augment_queries(const void* src, int dtype, int d, int64_t n, int normalize, float* dst, int ld_dst, hipStream_t st) {
     if (n <= 0) return LDOT_OK;
+    LDOT_REQUIRE(ld_dst >= d + 2, LDOT_EINVAL, "augmented row stride too short");
     const dim3 grid((unsigned)((n + 3) / 4)), block(256);
     switch (dtype) {
         case LDOT_F32:
-            hipLaunchKernelGGL(augment_queries_kernel<LDOT_F32>, grid, block, 0, st, src, d, n, normalize, dst);
+            hipLaunchKernelGGL(augment_queries_kernel<LDOT_F32>, grid, block, 0, st, src, d, n, normalize, dst, ld_dst);
             break;
         case LDOT_BF16:
-            hipLaunchKernelGGL(augment_queries_kernel<LDOT_BF16>, grid, block, 0, st, src, d, n, normalize, dst);
+            hipLaunchKernelGGL(augment_queries_kernel<LDOT_BF16>, grid, block, 0, st, src, d, n, normalize, dst, ld_dst);
             break;
         case LDOT_F16:
-            hipLaunchKernelGGL(augment_queries_kernel<LDOT_F16>, grid, block, 0, st, src, d, n, normalize, dst);
+            hipLaunchKernelGGL(augment_queries_kernel<LDOT_F16>, grid, block, 0, st, src, d, n, normalize, dst, ld_dst);
             break;
         default:
             set_error("unsupported dtype %d", dtype);

@@ -76,7 +76,7 @@ int launch_narrow_finish(const float* S, int tiled_qg, int64_t lds_elems, uint32
                          hipStream_t st);
 
 // dst [n][d + 2] fp32 = [q (L2-normalised if asked), 0, 1]: the coarse query of the inverted-file search (convert.hip)
-int launch_augment_queries(const void* src, int dtype, int d, int64_t n, int normalize, float* dst, hipStream_t st);
+int launch_augment_queries(const void* src, int dtype, int d, int64_t n, int normalize, float* dst, int ld_dst, hipStream_t st);
 // inverted-file scan (ivf.hip): per-query compact column space over the probed lists
 // plist [nq][nprobe] validated list ids, rowbase [nq][nprobe] first row of each list, cstart [nq][nprobe + 1] exclusive prefix sums of
 // the list lengths (last = column count)

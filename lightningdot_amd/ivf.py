@@ -48,6 +48,47 @@ def _kmeans_l2(x, nlist: int, iters: int, seed: int):
     return cent
 
 
+def _split_long_lists(x, cent, assign, cap: int, seed: int, max_rounds: int = 8):
+    """Bound the list length: every list longer than `cap` rows is split in two by a short 2-means on its own rows (repeated until none
+    is left or nothing changes); the halves take their means as centroids, rows never move to other lists.  k-means on real embeddings
+    leaves a heavy tail of list lengths (1M rows of an overlapping mixture in 4000 lists: longest 5472 rows against a mean of 250) and a
+    query lands in — and next to — the long lists, so 32 probes read 64 000 rows instead of 8 000; a search that reads fewer rows per
+    probe reaches the same recall with more probes at a lower cost (profiles/r03_ivf_recall_curve.jsonl).  -> (centroids, assign)"""
+    import torch
+    g = torch.Generator(device='cpu').manual_seed(seed + 1)
+    for _ in range(max_rounds):
+        counts = torch.bincount(assign, minlength=cent.shape[0])
+        big = (counts > cap).nonzero()[:, 0].tolist()
+        if not big:
+            break
+        order = torch.argsort(assign, stable=True)
+        offs = torch.cat([torch.zeros(1, dtype=torch.int64, device=x.device), counts.cumsum(0)]).tolist()
+        new_cent, changed = [], False
+        for li in big:
+            idx = order[offs[li]:offs[li + 1]]
+            xs = x[idx]
+            c2 = xs[torch.randperm(xs.shape[0], generator=g)[:2].to(x.device)].clone()
+            for _ in range(6):
+                part = _assign_l2(xs, c2)
+                for h in (0, 1):
+                    m = part == h
+                    if bool(m.any()):
+                        c2[h] = xs[m].mean(0)
+            part = _assign_l2(xs, c2)
+            n1 = int((part == 1).sum())
+            if n1 == 0 or n1 == xs.shape[0]:      # (identical rows: cannot be split by distance — cut the list in the middle)
+                part = (torch.arange(xs.shape[0], device=x.device) >= xs.shape[0] // 2).long()
+                c2 = torch.stack([xs[part == 0].mean(0), xs[part == 1].mean(0)])
+            cent[li] = c2[0]
+            assign[idx[part == 1]] = cent.shape[0] + len(new_cent)
+            new_cent.append(c2[1])
+            changed = True
+        cent = torch.cat([cent, torch.stack(new_cent)], 0)
+        if not changed:
+            break
+    return cent, assign
+
+
 def _assign_l2(x, cent, chunk: int = 131072):
     import torch
     half = 0.5 * (cent * cent).sum(1)
@@ -59,12 +100,15 @@ def _assign_l2(x, cent, chunk: int = 131072):
 
 class DenseIVFFlatIndexer(DenseIndexer):
     def __init__(self, vector_sz: int, buffer_size: int = 50000, nlist: Optional[int] = None, nprobe: int = 32,
-                 train_iters: int = 10, train_rows_per_list: int = 256, seed: int = 0):
+                 train_iters: int = 10, train_rows_per_list: int = 256, seed: int = 0, max_list_rows: Optional[int] = None):
         super().__init__(buffer_size=buffer_size)
         self.d = vector_sz
         self.index = FlatIPIndex(vector_sz)              # the rows, sorted by list
         self.nlist, self.nprobe = nlist, nprobe
         self.train_iters, self.train_rows_per_list, self.seed = train_iters, train_rows_per_list, seed
+        # longest list allowed (None: 4 x the mean list length, at least 64 rows, when nlist is chosen automatically; 0: lists as
+        # k-means leaves them)
+        self.max_list_rows = max_list_rows
         self.coarse: Optional[FlatIPIndex] = None        # the centroids in the augmented space (+ the -|c~|^2/2 coordinate)
         self.list_offsets = None                          # int64 [nlist + 1], device
         self.max_list_len = 0
@@ -102,6 +146,11 @@ class DenseIVFFlatIndexer(DenseIndexer):
         sample = aug if ntrain == n else aug[torch.randperm(n, generator=g)[:ntrain].to(x.device)]
         cent = _kmeans_l2(sample, nlist, self.train_iters, self.seed)
         assign = _assign_l2(aug, cent)
+        # (an explicit nlist is kept as asked for unless max_list_rows is given too)
+        cap = self.max_list_rows if self.max_list_rows is not None else (0 if self.nlist else max(64, 4 * -(-n // nlist)))
+        if cap > 0:
+            cent, assign = _split_long_lists(aug, cent, assign, int(cap), self.seed)
+            nlist = cent.shape[0]
         order = torch.argsort(assign, stable=True)
         counts = torch.bincount(assign, minlength=nlist)
         self.list_offsets = torch.cat([torch.zeros(1, dtype=torch.int64, device=x.device), counts.cumsum(0)]).contiguous()
@@ -122,19 +171,26 @@ class DenseIVFFlatIndexer(DenseIndexer):
 
     # ---- search ------------------------------------------------------------------------------------------------------------------
     def _exact_is_cheaper(self, nq: int, nprobe: int) -> bool:
-        """Cost model from the measured rates on MI355X (profiles/r02_ivf_bench.jsonl, r02_serving_latency.jsonl): the list scan gathers
-        fp32 rows at ~3.5 TB/s per query; the exact search streams the bf16 index once at ~6.3 TB/s for <= 64 queries (+17 % per 16
-        queries of score traffic) and runs at ~1.2 PFLOP/s plus ~0.6 ms of fixed cost for larger batches."""
+        """Cost model from the measured rates on MI355X (profiles/r03_ivf_bench.jsonl, r03_serving_latency.jsonl).  List search: ~0.08 ms
+        of launches and latency, then the probed rows once per query — fp32 rows at ~4 TB/s for a few queries, the bf16 shadow at
+        ~5.5 TB/s for 8-16 queries, fp32 rows at ~9 TB/s for batches (neighbouring queries probe the same lists: L2 hits).  Exact
+        search: the bf16 index once at ~6.3 TB/s for <= 64 queries (+17 % per 16 queries of score traffic), ~1.3 PFLOP/s plus ~0.35 ms
+        of fixed cost for larger batches."""
         n, d = self.index.ntotal, self.d
         # probed rows per query: a query lands in (and next to) a list with probability proportional to its size, so the expected
         # length of a probed list is the size-biased mean sum(len^2) / sum(len), not n / nlist — and its neighbours are long lists too
         # (measured on clustered data: twice the size-biased mean again)
         rows = min(n, 2.0 * nprobe * self.biased_list_len)
-        t_lists = 0.10e-3 + nq * rows * d * 4 / 3.5e12
+        if nq < 8:
+            t_lists = 0.08e-3 + nq * rows * d * 4 / 4.0e12
+        elif nq <= 16:
+            t_lists = 0.10e-3 + nq * rows * d * 2 / 5.5e12
+        else:
+            t_lists = 0.08e-3 + nq * 0.35e-6 + nq * rows * d * 4 / 9.0e12
         if nq <= 64:
             t_exact = 0.06e-3 + n * d * 2 / 6.3e12 * (1 + 0.17 * ((nq - 1) // 16))
         else:
-            t_exact = 0.6e-3 + 2.0 * nq * n * d / 1.2e15
+            t_exact = 0.35e-3 + 2.0 * nq * n * d / 1.3e15
         return t_exact < t_lists
 
     def search_knn_tensors(self, query_vectors, top_docs: int, nprobe: Optional[int] = None, exact_when_cheaper: bool = True):

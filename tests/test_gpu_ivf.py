@@ -268,3 +268,73 @@ def test_hnsw_surface_approximate_roundtrip(tmp_path):
     assert [[b.index_id_to_db_id[i] for i in row] for row in lab.cpu().tolist()] == [g_[0] for g_ in got]
     with pytest.raises(RuntimeError):
         b.index_tensor(['x'], x[:1])
+
+
+def test_long_lists_are_split_and_every_list_probed_is_still_exact(tmp_path):
+    """Automatic nlist: lists longer than 4 x the mean are split in two (2-means on their own rows) until none is left; the index stays
+    a partition of the rows (probing every list = the exact search), survives a save / load, and an explicit nlist is kept as given."""
+    import torch
+    from lightningdot_amd.indexer import DenseFlatIndexer
+    from lightningdot_amd.ivf import DenseIVFFlatIndexer
+    rng = np.random.default_rng(21)
+    # one dominant cluster (half of the rows) + 60 small ones: k-means leaves a few very long lists
+    big = 0.3 * rng.standard_normal((30000, 64)).astype(np.float32)
+    small, _ = _clustered(30000, 64, 60, 22, spread=0.2)
+    x = np.concatenate([big, 3.0 + small]).astype(np.float32)
+    ids = list(range(len(x)))
+    plain = DenseIVFFlatIndexer(64, nprobe=8, max_list_rows=0)
+    plain.index_tensor(ids, torch.from_numpy(x))
+    ivf = DenseIVFFlatIndexer(64, nprobe=8)
+    ivf.index_tensor(ids, torch.from_numpy(x))
+    cap = max(64, 4 * -(-len(x) // plain.nlist))
+    assert plain.max_list_len > cap                                   # (the data does produce long lists)
+    assert ivf.max_list_len <= cap and ivf.nlist > plain.nlist
+    assert int(ivf.list_offsets[-1]) == len(x) and ivf.coarse.ntotal == ivf.nlist
+    assert sorted(ivf.index_id_to_db_id) == ids
+    q = (x[rng.integers(0, len(x), 200)] + 0.1 * rng.standard_normal((200, 64))).astype(np.float32)
+    flat = DenseFlatIndexer(64)
+    flat.index_tensor(ids, torch.from_numpy(x).cuda())
+    want = flat.search_knn(q, 10)
+    ivf.nprobe = ivf.nlist
+    for (gi, gs), (wi, ws) in zip(ivf.search_knn(q, 10), want):
+        assert gi[0] == wi[0]
+        np.testing.assert_allclose(gs, ws, rtol=0, atol=2e-4)
+    ivf.nprobe = 8
+    got = ivf.search_knn(q, 10)
+    recall = np.mean([len(set(g[0]) & set(w[0])) / 10.0 for g, w in zip(got, want)])
+    assert recall > 0.8, recall
+    ivf.serialize(str(tmp_path / 'ivf'))
+    back = DenseIVFFlatIndexer(64)
+    back.deserialize_from(str(tmp_path / 'ivf'))
+    assert back.nlist == ivf.nlist and back.max_list_len == ivf.max_list_len
+    for (gi, gs), (bi, bs) in zip(got, back.search_knn(q, 10)):
+        assert gi == bi and np.array_equal(gs, bs)
+    fixed = DenseIVFFlatIndexer(64, nlist=40, nprobe=8)
+    fixed.index_tensor(ids, torch.from_numpy(x))
+    assert fixed.nlist == 40
+
+
+def test_full_coarse_candidate_buffer_is_found_after_the_deferred_check():
+    """ldot_ivf_search checks the coarse search's candidate buffer only at the synchronisation point of the list stage.  5000 IDENTICAL
+    centroids: every list scores the same, the coarse search's buffer (4096 candidates) fills up, the chain notices after the fact and
+    repeats the search the plain way — the probes are then the lists 0 .. nprobe-1 (ties: ascending), the result the exact top-k of their
+    rows."""
+    import torch
+    from lightningdot_amd.ivf import DenseIVFFlatIndexer
+    rng = np.random.default_rng(23)
+    n, d, nlist, nprobe, k = 20000, 64, 5000, 6, 10
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    ivf = DenseIVFFlatIndexer(d, nlist=nlist, nprobe=nprobe)
+    ivf.index.add(torch.from_numpy(x).cuda())
+    ivf._update_id_mapping(list(range(n)))
+    ivf.list_offsets = (torch.arange(nlist + 1, dtype=torch.int64) * (n // nlist)).cuda().contiguous()
+    ivf.max_list_len, ivf.biased_list_len, ivf.phi = n // nlist, float(n // nlist), 0.0
+    ivf._set_coarse(torch.ones(nlist, d + 1, device='cuda') * 0.1)
+    q = rng.standard_normal((3, d)).astype(np.float32)
+    s, l = ivf.search_knn_tensors(torch.from_numpy(q).cuda(), k, exact_when_cheaper=False)
+    rows = nprobe * (n // nlist)
+    full = q.astype(np.float64) @ x[:rows].astype(np.float64).T
+    want = np.argsort(-full, axis=1, kind='stable')[:, :k]
+    np.testing.assert_array_equal(l.cpu().numpy(), want)
+    np.testing.assert_allclose(s.cpu().numpy(), np.take_along_axis(full, want, 1), rtol=0, atol=2e-4)
+    assert ivf.coarse.last_stats()['overflowed_queries'] == 3

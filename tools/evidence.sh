@@ -36,5 +36,5 @@ timeout 600 python tools/ivf_bench.py > $O/ivf_bench.jsonl 2>> $O/bench.err
 timeout 600 python tools/ivf_bench.py 1000000 curve > $O/ivf_recall_curve.jsonl 2>> $O/bench.err
 timeout 600 python tools/overflow_cases.py > $O/overflow_cases.jsonl 2>> $O/bench.err
 timeout 300 python tools/shard_floor.py > $O/shard_floor.txt 2>> $O/bench.err
-bash tools/timeline_tail.sh 8 python tools/ivf_one.py > $O/ivf_timeline.txt 2>&1
+bash tools/timeline_tail.sh 10 python tools/ivf_one.py > $O/ivf_timeline.txt 2>&1
 tail -3 $O/pytest_gpu.log; cat $O/smoke.log | tail -1; cut -c1-600 $O/bench.json; cat $O/pmc.txt

@@ -4,6 +4,7 @@ with the EXACT top-10 (not with a planted row), single-query / 16-query latency 
 
     python tools/ivf_bench.py [rows] [centroid_spread]
     python tools/ivf_bench.py [rows] curve            # recall@10 vs nprobe only, for several spreads (no latency loops)
+    IVF_MAX_LIST_ROWS=0 python tools/ivf_bench.py ... # lists as k-means leaves them (no splitting of the long ones): the A/B of that step
 
 Data: a mixture of 4000 Gaussians whose centroids are spread by `centroid_spread` (default 0.2) per dimension around the origin, rows =
 centroid + 0.5 N(0,1) — OVERLAPPING clusters: the inner-product advantage of a query's own cluster (768 spread^2 ~ 11) is comparable to
@@ -16,6 +17,16 @@ from lightningdot_amd.indexer import DenseFlatIndexer
 from lightningdot_amd.ivf import DenseIVFFlatIndexer
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+CAP = int(os.environ['IVF_MAX_LIST_ROWS']) if 'IVF_MAX_LIST_ROWS' in os.environ else None
+
+
+def rows_scanned(ivf, q, nprobe):
+    """mean number of rows in the nprobe lists a query probes"""
+    qa = torch.cat([q, torch.zeros(len(q), 1, device='cuda'), torch.ones(len(q), 1, device='cuda')], 1)
+    _, pr = ivf.coarse.search_tensors(qa, min(nprobe, ivf.nlist))
+    lens = ivf.list_offsets[1:] - ivf.list_offsets[:-1]
+    return float(lens[pr.clamp_min(0)].sum(1).float().mean())
+
 if len(sys.argv) > 2 and sys.argv[2] == 'curve':
     for spread in (0.16, 0.2, 0.25, 0.35):
         g = torch.Generator(device='cuda').manual_seed(0)
@@ -24,14 +35,16 @@ if len(sys.argv) > 2 and sys.argv[2] == 'curve':
         q = cent[torch.randint(0, 4000, (512,), device='cuda', generator=g)] + 0.5 * torch.randn(512, 768, device='cuda', generator=g)
         flat = DenseFlatIndexer(768); flat.index_tensor(list(range(N)), x)
         _, el = flat.search_knn_tensors(q, 10)
-        ivf = DenseIVFFlatIndexer(768, nprobe=32); ivf.index_tensor(list(range(N)), x)
+        ivf = DenseIVFFlatIndexer(768, nprobe=32, max_list_rows=CAP); ivf.index_tensor(list(range(N)), x)
         inv = torch.as_tensor(ivf.index_id_to_db_id, device='cuda')
-        row = dict(rows=N, centroid_spread=spread, nlist=ivf.nlist, longest_list=ivf.max_list_len, recall_at_10={}, rank1_agreement={})
+        row = dict(rows=N, centroid_spread=spread, nlist=ivf.nlist, longest_list=ivf.max_list_len, recall_at_10={}, rank1_agreement={},
+                   rows_scanned={})
         for nprobe in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512):
             _, l = ivf.search_knn_tensors(q, 10, nprobe, exact_when_cheaper=False)
             orig = torch.where(l >= 0, inv[l.clamp_min(0)], l)
             row['recall_at_10'][nprobe] = round(float(sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(orig, el)) / 5120), 4)
             row['rank1_agreement'][nprobe] = round(float((orig[:, 0] == el[:, 0]).float().mean()), 4)
+            row['rows_scanned'][nprobe] = round(rows_scanned(ivf, q, nprobe))
         print(json.dumps(row), flush=True)
         del flat, ivf, x
         torch.cuda.empty_cache()
@@ -46,7 +59,7 @@ ids = list(range(N))
 flat = DenseFlatIndexer(D); flat.index_tensor(ids, x)
 es, el = flat.search_knn_tensors(q, K)
 t0 = time.perf_counter()
-ivf = DenseIVFFlatIndexer(D, nprobe=32); ivf.index_tensor(ids, x); torch.cuda.synchronize()
+ivf = DenseIVFFlatIndexer(D, nprobe=32, max_list_rows=CAP); ivf.index_tensor(ids, x); torch.cuda.synchronize()
 build = time.perf_counter() - t0
 inv = torch.as_tensor(ivf.index_id_to_db_id, device='cuda')          # sorted row -> original row
 
@@ -64,7 +77,7 @@ for nprobe in (1, 2, 4, 8, 16, 32, 64, 128, 256):
     orig = torch.where(l >= 0, inv[l.clamp_min(0)], l)
     recall = float(sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(orig, el)) / (512 * K))
     r1 = float((orig[:, 0] == el[:, 0]).float().mean())
-    print(json.dumps(dict(nprobe=nprobe, recall_at_10=recall, rank1_agreement=r1,
+    print(json.dumps(dict(nprobe=nprobe, recall_at_10=recall, rank1_agreement=r1, rows_scanned=round(rows_scanned(ivf, q, nprobe)),
                           ms_1q=lat(lambda: ivf.search_knn_tensors(q[:1], K, nprobe, exact_when_cheaper=False)),
                           ms_16q=lat(lambda: ivf.search_knn_tensors(q[:16], K, nprobe, exact_when_cheaper=False)),
                           ms_512q=lat(lambda: ivf.search_knn_tensors(q, K, nprobe, exact_when_cheaper=False), 20),
