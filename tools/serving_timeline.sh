@@ -23,8 +23,11 @@ for f in glob.glob("/tmp/stl/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:60]))
 ev.sort()
-starts = [i for i, e in enumerate(ev) if "convert_rows" in e[2]]
+# a search starts with the index scan (a few fp32 device queries are converted by the scan itself; larger batches by a conversion kernel first)
+starts = [i for i, e in enumerate(ev) if "score_narrow" in e[2]]
 i0 = starts[-1]
+if i0 > 0 and "convert_rows" in ev[i0 - 1][2] and ev[i0][0] - ev[i0 - 1][1] < 20000:
+    i0 -= 1
 t0 = ev[i0][0]; prev = t0
 for s, e, n in ev[i0:]:
     print("%9.1f us  +%7.1f gap  dur %8.1f  %s" % ((s - t0) / 1e3, (s - prev) / 1e3, (e - s) / 1e3, n))
