@@ -55,6 +55,10 @@ for it in range(cases):
         else:
             assert_topk_matches(q, x, s, l, k)
         st = ix.last_stats()
+        # the device-resident route (fp32 device queries, kernel-written device outputs: a few queries are not staged, the narrow scan
+        # converts them itself) must give the same bits as the host route — also when it overflows and recovers
+        sd, ld = ix.search_tensors(torch.from_numpy(q).cuda(), k)
+        assert np.array_equal(ld.cpu().numpy(), l) and np.array_equal(sd.cpu().numpy(), s), 'device route differs from the host route'
         print(f'ok   {desc} stats={st}', flush=True)
     except AssertionError as e:
         fails += 1
