@@ -671,14 +671,14 @@ static int fused_launch_and_select(ldot_index* ix, int64_t q0, int64_t nq, int64
     const uint16_t* q16 = (const uint16_t*)ix->w_q16b.p + q0 * ix->ld16();
     int32_t* over = (int32_t*)ix->w_over.p + q0;
     const int qg = fused_query_group(nq_pad);
-    const int64_t nslices = 256 / qg, nsubs = 4 * nslices;
+    const int64_t nslices = 256 / qg, nsubs = kPoolSubsPerSlice * nslices;
     int rc;
     prof_begin(ix, st, 2.0 * nq * len * ix->d, (double)len * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * kp * 8);
     rc = launch_score_filter(ix->x16b, ix->ld16(), r, len, q16, ix->ld16(), nq_pad, (int)ix->ld16(), tau, (uint4*)ix->w_pool.p,
                              (int32_t*)ix->w_pool_cnt.p, st);
     prof_end(ix, st);
     if (rc) return rc;
-    if (nq <= kFewSelectMaxQueries && nsubs >= 512 && kp + 512 + 32 <= 1024) {
+    if (nq <= kFewSelectMaxQueries && nsubs >= 1024 && kp + 512 + 32 <= 1024) {
         // few queries: G waves per query fold the sub-pools into partial lists, one merge joins them with the running list
         const int G = 16;
         if ((rc = ix->w_part_s.ensure((size_t)G * nq * kp * 4))) return rc;
@@ -698,7 +698,7 @@ static int fused_launch_and_select(ldot_index* ix, int64_t q0, int64_t nq, int64
 // candidate pools + counters for nq_pad queries (the counters are all-zero between searches)
 static int fused_pools(ldot_index* ix, int64_t nq_pad, hipStream_t st) {
     const int qg = fused_query_group(nq_pad);
-    const int64_t nsubs = 4 * (256 / qg);
+    const int64_t nsubs = kPoolSubsPerSlice * (256 / qg);
     int rc;
     if ((rc = ix->w_pool.ensure((size_t)nq_pad * nsubs * kPoolCap * kPoolRecBytes))) return rc;
     const size_t cnt_bytes = (size_t)nq_pad * nsubs * 4;
@@ -712,17 +712,18 @@ static int fused_pools(ldot_index* ix, int64_t nq_pad, hipStream_t st) {
 static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_pad, int kp, hipStream_t st) {
     int rc;   // (q0 is a multiple of 256: whole 16-row blocks of the query shadow)
     // Pool sizing rule: a launch over `len` rows after `r` scanned rows admits ~kp*len/r candidates per query,
-    // spread over nsubs lane-private sub-pools of kPoolCap records.  Keeping the expectation <= 8 per sub-pool
-    // (overflow probability ~1e-11 each) bounds len <= r * 8 * nsubs / kp (1024 r / kp at 128 sub-pools; 8x that for the
-    // 1024 sub-pools of a single query block, whose search is then ONE fused launch); the smallest launch is one tile
-    // per row slice, hence the warm-up covers at least bm * nslices * kp / (8 * nsubs) rows.
+    // spread over nsubs lane-private sub-pools of kPoolCap records.  Keeping the expectation <= kPoolCap / 4 per sub-pool
+    // (overflow probability ~1e-11 each) bounds len <= r * kFill * nsubs / kp (1024 r / kp at 256 sub-pools; 8x that for the
+    // 2048 sub-pools of a single query block, whose search is then ONE fused launch); the smallest launch is one tile
+    // per row slice, hence the warm-up covers at least bm * nslices * kp / (kFill * nsubs) rows.
+    constexpr int64_t kFill = kPoolCap / 4;
     const int64_t bm = fused_tile_rows();
     const int qg = fused_query_group(nq_pad);
-    const int64_t nslices = 256 / qg, nsubs = 4 * nslices;
-    int64_t warm = std::max<int64_t>(ix->warm_rows, round_up(bm * nslices * (int64_t)kp / (8 * nsubs), 256));
+    const int64_t nslices = 256 / qg, nsubs = kPoolSubsPerSlice * nslices;
+    int64_t warm = std::max<int64_t>(ix->warm_rows, round_up(bm * nslices * (int64_t)kp / (kFill * nsubs), 256));
     // few queries (serving): launches and selects cost more than dense rows -> warm up over just enough rows for ONE fused launch
-    // to cover the rest within the pool bound (len <= r * 8 * nsubs / kp)
-    if (nq <= 64) warm = std::max(warm, round_up(ix->ntotal * kp / (kp + 8 * nsubs) + 1, 256));
+    // to cover the rest within the pool bound (len <= r * kFill * nsubs / kp)
+    if (nq <= 64) warm = std::max(warm, round_up(ix->ntotal * kp / (kp + kFill * nsubs) + 1, 256));
     warm = std::min(ix->ntotal, warm);
     if ((rc = dense_scan_all(ix, nq, 0, warm, kp, (float*)ix->w_tau.p, nq <= 64, st, q0))) return rc;
     if (warm >= ix->ntotal) return LDOT_OK;
@@ -736,7 +737,7 @@ static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_p
     const int64_t growth = nq_pad <= kBM ? std::max<int64_t>(ix->growth_pct, few_growth) : ix->growth_pct;
     int64_t r = warm;
     while (r < ix->ntotal) {
-        int64_t len = std::min<int64_t>(r * growth / 100, r * 8 * nsubs / kp);
+        int64_t len = std::min<int64_t>(r * growth / 100, r * kFill * nsubs / kp);
         len = std::max<int64_t>(len, bm * nslices);
         // whole tiles for every row slice (a launch is as slow as its busiest slice); rounding DOWN keeps the pool bound
         len = len / (bm * nslices) * (bm * nslices);

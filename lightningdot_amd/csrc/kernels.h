@@ -11,17 +11,19 @@ constexpr int kMaxK = 2048;        // largest k of a search
 constexpr int kMaxKp = 3072;       // largest candidate-list length k' = k + margin: k' + 1024 keys fit a 32 KiB LDS buffer
 constexpr int kSelThreads = 256;
 
-// fused-filter candidate pools: per query, nsubs = 4 * (row slices) lane-private sub-pools of kPoolCap RECORDS.  A record is
-// what one lane holds when its 8-score test fires: the 8 scores of accumulator registers 8h..8h+7 of one 32x32 tile (rows
-// rb + {0,1,2,3,8,9,10,11}) and rb — three 16-byte planes {s0..s3}, {s4..s7}, {rb,-,-,-}, laid out entry-major and plane-major:
-// pool[((q * kPoolCap + e) * 3 + plane) * nsubs + sub].  The filter does not localise the hit (no per-score compares, no
-// nested branches on the matrix pipe's critical path: three stores straight from the accumulator registers); the pool select
+// fused-filter candidate pools: per query, nsubs = kPoolSubsPerSlice * (row slices) lane-private sub-pools of kPoolCap RECORDS.  A
+// record is what one lane holds when its 8-score test fires: the 4 + 4 scores of two vertically adjacent 16x16 MFMA tiles (rows
+// rb + {0,1,2,3} and rb + kPoolRecHiRow + {0,1,2,3}) and rb — three 16-byte planes {s0..s3}, {s4..s7}, {rb,-,-,-}, laid out entry-major
+// and plane-major: pool[((q * kPoolCap + e) * 3 + plane) * nsubs + sub].  The filter does not localise the hit (no per-score compares,
+// no nested branches on the matrix pipe's critical path: three stores straight from the accumulator registers); the pool select
 // applies the threshold to the 8 scores of every record.
-// sub-pool id = ((slice * 2 + wm) * 2 + (lane >> 5)); slices = 256 / (query blocks per XCD) = 32 .. 256
-constexpr int kPoolCap = 32;
+// sub-pool id = ((slice * 2 + wm) * 4 + (lane >> 4)); slices = 256 / (query blocks per XCD) = 32 .. 256
+constexpr int kPoolCap = 16;
 constexpr int kPoolPlanes = 3;
 constexpr int kPoolRecBytes = 16 * kPoolPlanes;
-constexpr int kPoolSubsMax = 1024;   // query-group width 1: 256 row slices x 4 lanes
+constexpr int kPoolSubsPerSlice = 8;   // 2 wave rows x 4 lane groups (the C/D layout of v_mfma_f32_16x16x32: lane l holds rows (l >> 4) * 4 .. + 4)
+constexpr int kPoolRecHiRow = 16;      // row offset of a record's second quad (the 16-row MFMA tile below)
+constexpr int kPoolSubsMax = 2048;     // query-group width 1: 256 row slices x 8
 
 // rows: convert n rows of `dtype` (row stride ld_src elements, d valid columns) into the padded fp32 master copy
 // and/or its bf16 shadow (row stride dpad, zero padded); optional L2 normalisation.  Rows [n, n_pad) are zero-filled.

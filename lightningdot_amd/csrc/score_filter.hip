@@ -2,15 +2,31 @@
 //
 // Replaces the sgemm + heap inside faiss IndexFlatIP.search (dvl/indexer/faiss_indexers.py:83) for large
 // indexes.  Orientation is "swapped": A = index rows (M side), B = queries (N side), so in the MFMA C/D layout
-// a lane owns ONE query column (col = lane & 31) and its accumulator registers hold that query's scores
-// against 96 different index rows.  The per-query admission threshold tau (the current k'-th best score, a
-// valid lower bound of the final one) therefore lives in a lane register and the filter is a v_max3 tree + one
-// v_cmp per 4 scores with an exec-masked, almost never taken, append.
+// a lane owns query COLUMNS and its accumulator registers hold those queries' scores against 48 different index rows each.
+// The per-query admission threshold tau (the current k'-th best score, a valid lower bound of the final one) therefore lives in
+// lane registers and the filter is a v_max3 tree + one v_cmp per 8 scores with an exec-masked, almost never taken, append.
 //
-// Appends go to lane-private sub-pools in HBM (cursor in a VGPR, no atomics, no LDS): for a query q each of the
-// 4 lanes x (row slices) that can produce candidates owns kPoolCap RECORDS.  A record is what a lane holds when its
-// max-of-8 test fires: the 8 scores of accumulator registers 8h..8h+7 (rows rb + {0,1,2,3,8,9,10,11}) and rb — three 16-byte
-// planes, stored entry-major and plane-major, pool[((q * kPoolCap + e) * 3 + plane) * nsubs + sub] in 16-byte units, so that the
+// Round 3 — the tile engine is built on v_mfma_f32_16x16x32_bf16 (16 x 16 tiles, K = 32 per instruction) instead of
+// v_mfma_f32_32x32x16_bf16.  Same flops per clock on paper; under the chip's power limit, with random operands, the 16x16x32 shape
+// sustains 2020 TFLOP/s MFMA-only against 1725 (it accumulates twice the K per accumulator read-modify-write), and this kernel's slab
+// loop (LDS fragment stream + direct-to-LDS slab loads) 1600-1615 against 1405-1455 (tools/mfma_ceiling.hip, lines "T16" / "W2").
+//   * workgroup = 512 threads = 8 waves (2 along M x 4 along N), wave tile 192 x 64 = 12 x 4 MFMA tiles, 192 accumulator VGPRs;
+//     workgroup tile 384 rows x 256 queries; 4-stage LDS ring of 32-deep K slabs (4 x 40 KiB = all 160 KiB), ONE k-step per slab;
+//   * a fragment (16 rows x 32 k) is one 1-KiB block of the ring image: lane l reads row l & 15, 16-byte chunk (l >> 4) ^ ((row >> 1) & 3)
+//     (the swizzle is applied on the per-lane SOURCE address of the direct-to-LDS loads, conflict-free ds_read_b128);
+//   * A fragments live in a ring of THREE register quads (row block i uses a[i % 3], refilled with block i + 3 right after its four
+//     MFMAs — 12 MFMAs = 192 cycles ahead); the four B fragments of the next slab are fetched during the last three row blocks;
+//   * slabs are issued 3 ahead and retired by a counted s_waitcnt vmcnt + one raw s_barrier per slab, placed before row block 9: by
+//     then every fragment of the current stage is in registers (the stage is free for the slab 4 ahead) and the next stage is about
+//     to be read.
+//
+// C/D layout of 16x16x32: lane l holds rows (l >> 4) * 4 .. + 4 of column l & 15.  A lane therefore owns FOUR query columns (column
+// block j = 0..3: query wn * 64 + j * 16 + (l & 15)) and, per column, 4 rows of each of the wave's 12 row blocks.
+//
+// Appends go to lane-private sub-pools in HBM (cursor in a VGPR byte, no atomics, no LDS): for a query q each of the
+// 8 (wave row, lane group) x (row slices) that can produce candidates owns kPoolCap RECORDS.  A record is what a lane holds when its
+// max-of-8 test fires: the 4 + 4 scores of two vertically adjacent tiles (rows rb + {0,1,2,3} and rb + 16 + {0,1,2,3}) and rb — three
+// 16-byte planes, stored entry-major and plane-major, pool[((q * kPoolCap + e) * 3 + plane) * nsubs + sub] in 16-byte units, so that the
 // select kernel, which folds the pools into the running top-k' list between launches and raises tau, reads one entry level of
 // all sub-pools as contiguous 16-byte words instead of one cache line per record.
 //
@@ -23,13 +39,12 @@
 // 8 Q panels (3 MiB) and streams each row panel once per query group.
 //
 // Operand layout: both bf16 shadows are read in the BLOCKED layout written by convert_rows_kernel (dst16b): 1 KiB blocks of
-// 16 rows x 32 k, block (g, s) of a 16-row group g and K slab s at ((g * nslab + s) KiB.  One wave-level direct-to-LDS load
-// instruction (64 lanes x 16 B = 16 rows x 64 B of one slab) then reads one contiguous KiB = eight full 128-B lines; with
-// row-major operands the same instruction touched 16 half lines, and the L2 request rate (one 64-B request per half line,
-// ~0.8 per clock and channel) bounded the L2->LDS stream: loads-only time 8.7 -> 5.9 ms, kernel -5.5 %.
+// 16 rows x 32 k, block (g, s) of a 16-row group g and K slab s at ((g * nslab + s) KiB — exactly one MFMA operand.  One wave-level
+// direct-to-LDS load instruction (64 lanes x 16 B = 16 rows x 64 B of one slab) reads one contiguous KiB = eight full 128-B lines.
 //
-// Earlier generations of this kernel (256x256 two-stage, commit da2a5a4; 256x256 on the LDS ring, commit 62cbd68) are in
-// the history; their measurements are in DESIGN.md section 5.2.
+// Earlier generations of this kernel (256x256 two-stage, commit da2a5a4; 256x256 on the LDS ring, commit 62cbd68; 384x256 on
+// v_mfma_f32_32x32x16_bf16 with its ablation variants, rounds 1-3 up to commit 0f2c) are in the history; their measurements are in
+// DESIGN.md section 5.2.
 #include <math.h>
 #include <stdlib.h>
 
@@ -40,17 +55,10 @@
 
 namespace ldot {
 
-// ---- third generation: (64*MR) x 256 tile on the ring, A fragments recycled in place (gemm_ring.h) -------------
-// max of four accumulator registers in two instructions.  fmaxf() would add a canonicalising v_max per MFMA
+// max of eight accumulator registers in four instructions.  fmaxf() would add a canonicalising v_max per MFMA
 // output (hipcc cannot prove MFMA results are quiet); scores are never signalling NaNs, so v_max3 is applied
-// directly.  The operands are MFMA results: the caller guarantees >= 18 wait states since the last MFMA issue
-// (the s_nop block at the top of the epilogue) because hipcc does not pad hazards for inline asm.
-__device__ __forceinline__ float max4_raw(float a0, float a1, float a2, float a3) {
-    float m;
-    asm volatile("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4" : "=&v"(m) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
-    return m;
-}
-
+// directly.  The operands are MFMA results: the caller guarantees the MFMA -> VALU read wait states (hipcc does not pad hazards for
+// inline asm).
 __device__ __forceinline__ float max8_raw(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
     float m;
     asm volatile(
@@ -60,56 +68,25 @@ __device__ __forceinline__ float max8_raw(float a0, float a1, float a2, float a3
     return m;
 }
 
-// MFMA -> VALU read hazard cover for the inline-asm accumulator reads of the epilogue (32x32x16 bf16: 8 passes, <= 18 wait
-// states since the last MFMA issue; hipcc does not pad hazards for inline asm)
+// two such maxima as two INTERLEAVED dependency chains (a dependent VALU instruction cannot issue back to back; 18 asm operands — the
+// limit is 30, so four chains do not fit one statement)
+__device__ __forceinline__ void max8x2_raw(const f32x4& a0, const f32x4& a1, const f32x4& b0, const f32x4& b1, float& ma, float& mb) {
+    asm volatile(
+        "v_max3_f32 %0, %2, %3, %4\n\tv_max3_f32 %1, %10, %11, %12\n\t"
+        "v_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %1, %1, %13, %14\n\t"
+        "v_max3_f32 %0, %0, %7, %8\n\tv_max3_f32 %1, %1, %15, %16\n\t"
+        "v_max_f32 %0, %0, %9\n\tv_max_f32 %1, %1, %17"
+        : "=&v"(ma), "=&v"(mb)
+        : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]),
+          "v"(b0[0]), "v"(b0[1]), "v"(b0[2]), "v"(b0[3]), "v"(b1[0]), "v"(b1[1]), "v"(b1[2]), "v"(b1[3]));
+}
+
+// MFMA -> VALU read hazard cover for the inline-asm accumulator reads of the stand-alone epilogue (the accumulators were written by
+// the MFMAs just issued; hipcc does not pad hazards for inline asm)
 __device__ __forceinline__ void filter_hazard_cover() {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-}
-
-// threshold filter of one 32-row block (mr) of the wave tile: both query columns of the lane, eight scores per test
-// (three v_max3 + v_max + compare + branch on the fast path).  A firing test does NOT localise the hit: the lane appends one
-// record = the 8 scores (two 16-byte stores straight from the accumulator registers) + their base row to its sub-pool (cursor
-// `cur`, clamped at kPoolCap; the true count is kept so that overflow is detectable) and the pool select thresholds them.
-// pbase = (q * kPoolCap * 3) * nsubs + sub in 16-byte units; entry e, plane p at pbase + (e * 3 + p) * nsubs.
-template <bool NOSTORE>
-__device__ __forceinline__ void filter_epilogue_mr(const f32x16& acc0, const f32x16& acc1, int mr, const float (&tau)[2],
-                                                   int (&cur)[2], uint32_t pbase0, uint32_t pstep, uint32_t nsubs,
-                                                   uint4* __restrict__ pool, int32_t row_wave0) {
-#pragma unroll
-    for (int nr = 0; nr < 2; ++nr) {
-        const f32x16& a = nr ? acc1 : acc0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float a0 = a[8 * h + 0], a1 = a[8 * h + 1], a2 = a[8 * h + 2], a3 = a[8 * h + 3];
-            const float a4 = a[8 * h + 4], a5 = a[8 * h + 5], a6 = a[8 * h + 6], a7 = a[8 * h + 7];
-            const float m = max8_raw(a0, a1, a2, a3, a4, a5, a6, a7);
-            if (m >= tau[nr]) {   // rare (a few per tile and wave)
-                // (rare path: the lane's row offset and the sub-pool base are derived here instead of living in registers)
-                // registers 8h..8h+3: rows +0..3, 8h+4..8h+7: rows +8..11
-                const int32_t rb = row_wave0 + 4 * (int32_t)((threadIdx.x & 63) >> 5) + mr * 32 + 16 * h;
-                const int p = cur[nr];
-                cur[nr] = p + 1;
-                if (p < kPoolCap && !NOSTORE) {
-                    uint4* rec = pool + (pbase0 + (uint32_t)nr * pstep + (uint32_t)p * (kPoolPlanes * nsubs));
-                    rec[0] = make_uint4(__float_as_uint(a0), __float_as_uint(a1), __float_as_uint(a2), __float_as_uint(a3));
-                    rec[nsubs] = make_uint4(__float_as_uint(a4), __float_as_uint(a5), __float_as_uint(a6), __float_as_uint(a7));
-                    rec[2 * nsubs] = make_uint4((uint32_t)rb, 0u, 0u, 0u);
-                }
-            }
-        }
-    }
-}
-
-template <int MR, bool NOSTORE>
-__device__ __forceinline__ void filter_epilogue_r(const f32x16 (&acc)[MR][2], const float (&tau)[2], int (&cur)[2],
-                                                  uint32_t pbase0, uint32_t pstep, uint32_t nsubs, uint4* __restrict__ pool,
-                                                  int32_t row_wave0) {
-    filter_hazard_cover();
-#pragma unroll
-    for (int mr = 0; mr < MR; ++mr)
-        filter_epilogue_mr<NOSTORE>(acc[mr][0], acc[mr][1], mr, tau, cur, pbase0, pstep, nsubs, pool, row_wave0);
 }
 
 template <int N>
@@ -117,31 +94,93 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// the lane id, produced by an instruction the compiler can neither hoist nor keep: the rare paths of the tile loop (an admitted record,
+// a change of query group) derive their per-lane addresses from it on the spot.  Left to itself the compiler hoists those loop-invariant
+// per-lane values out of the tile loop (nine registers at the last count), runs out of registers and spills inside the rare paths —
+// and a scratch RELOAD is an s_waitcnt vmcnt(0), which drains the LDS-DMA ring.
+__device__ __forceinline__ uint32_t lane_now() {
+    uint32_t l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+constexpr int kT16RowBlocks = 12;   // 16-row blocks of a wave tile (192 rows)
+constexpr int kT16ColBlocks = 4;    // 16-query blocks of a wave tile (64 queries)
+
+// threshold filter of one PAIR of row blocks (2p, 2p + 1) of the wave tile: the lane's four query columns, eight scores per test
+// (three v_max3 + v_max + compare + branch on the fast path).  A firing test does NOT localise the hit: the lane appends one
+// record = the 8 scores (two 16-byte stores straight from the accumulator registers) + their base row to its sub-pool (cursor
+// byte j of `curp`, clamped at kPoolCap; the true count — saturating at 255 — is kept so that overflow is detectable) and the pool
+// select thresholds them.  Record address in 16-byte units: (q * kPoolCap * 3) * nsubs + sub + (e * 3 + plane) * nsubs with
+// q = q_u + 16 j + (lane & 15) and sub = sub_u + (lane >> 4): pbase_u carries the wave-uniform part (a scalar), the lane's part is
+// derived in the rare path.
+// the compares, ONE wave-uniform branch, and the rare admissions of a pair whose maxima m are complete
+template <bool NOSTORE>
+__device__ __forceinline__ void filter_admit(const f32x4 (&lo)[kT16ColBlocks], const f32x4 (&hi)[kT16ColBlocks], int p,
+                                             const float (&m)[kT16ColBlocks], const float (&tau)[kT16ColBlocks], uint32_t& curp,
+                                             uint32_t pbase_u, uint32_t pstep, uint32_t nsubs, uint4* __restrict__ pool,
+                                             int32_t row_wave0) {
+    const bool any = (m[0] >= tau[0]) | (m[1] >= tau[1]) | (m[2] >= tau[2]) | (m[3] >= tau[3]);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(any) == 0, 1)) return;   // (rare otherwise: a few per tile and wave; laid out of line)
+#pragma unroll
+    for (int j = 0; j < kT16ColBlocks; ++j) {
+        const f32x4 a = lo[j], b = hi[j];
+        if (m[j] >= tau[j]) {
+            // (the lane's row offset and the record address are derived HERE from lane_now(): see there)
+            const uint32_t ln = lane_now();
+            const uint32_t e = (curp >> (8 * j)) & 255u;
+            if (e < 255u) curp += 1u << (8 * j);
+            if (e < (uint32_t)kPoolCap && !NOSTORE) {
+                // buffer stores: the wave-uniform base lives in the (scalar) resource, the plane and the column block in the scalar
+                // offset, so the lane's address is ONE register (a 64-bit flat address per plane did not fit: the rare path spilled, and
+                // a scratch reload waits for vmcnt(0) = for the whole LDS-DMA ring)
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void*)(pool + pbase_u), 0, (int)(pstep * 64u), 0x00020000);
+                const uint32_t g4 = (ln >> 4) & 3u;
+                const uint32_t vo = ((ln & 15u) * (pstep >> 4) + g4 + e * (kPoolPlanes * nsubs)) << 4;
+                const uint32_t so = (uint32_t)j * pstep * 16u;
+                const int32_t rb = row_wave0 + 4 * (int32_t)g4 + p * 32;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), pr, vo, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, b), pr, vo, so + nsubs * 16u, 0);
+                __builtin_amdgcn_raw_buffer_store_b32((uint32_t)rb, pr, vo, so + nsubs * 32u, 0);
+            }
+        }
+    }
+}
+
+// maxima (two statements of two interleaved chains) + admission of a pair in one block (first pair of the fused slab, stand-alone epilogue)
+template <bool NOSTORE>
+__device__ __forceinline__ void filter_pair(const f32x4 (&lo)[kT16ColBlocks], const f32x4 (&hi)[kT16ColBlocks], int p,
+                                            const float (&tau)[kT16ColBlocks], uint32_t& curp, uint32_t pbase_u, uint32_t pstep,
+                                            uint32_t nsubs, uint4* __restrict__ pool, int32_t row_wave0) {
+    float m[kT16ColBlocks];
+    max8x2_raw(lo[0], hi[0], lo[1], hi[1], m[0], m[1]);
+    max8x2_raw(lo[2], hi[2], lo[3], hi[3], m[2], m[3]);
+    filter_admit<NOSTORE>(lo, hi, p, m, tau, curp, pbase_u, pstep, nsubs, pool, row_wave0);
+}
+
+// VAR (ablation builds): 1 no epilogue at all, 8 no record stores, 16 tau = +inf (fast path only), 256 no deferral of the slab-load
+// burst around the filter.
 // qg_log2: log2 of the number of query blocks an XCD works on concurrently (8 for large batches; 1/2/4 for few
-// query blocks, so that all 256 workgroups stream index rows even for a single query block — the serving shape).
+// query blocks, so that all 256 workgroups stream index rows even for a single query block).
 template <int VAR>
-__global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
+__global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
     const char* __restrict__ X16, int64_t ldx_b, int64_t row0, int64_t nrows, const char* __restrict__ Q16,
     int64_t ldq_b, int nqb, int nk, const float* __restrict__ tau_g, uint4* __restrict__ pool,
     int32_t* __restrict__ pool_cnt, int qg_log2) {
-    constexpr int MR = 6;
-    using Geo = RingGeom<MR>;
+    using Geo = RingGeom<6>;   // 384-row A slab + 256-row B slab per stage, 5 direct-to-LDS pieces per wave and slab
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    RingCtx c;
-    ring_ctx_init(c);
-#ifdef LDOT_ABLATION
-    if ((VAR & 16384) && c.wave >= 4) __builtin_amdgcn_s_setprio(1);   // static priority for the later-dispatched half (guide: +0..1 %)
-    if ((VAR & 32768) && c.wave < 4) __builtin_amdgcn_s_setprio(1);
-#endif
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
     const int qg = 1 << qg_log2;                       // query blocks in flight per XCD
     const int nstream = 32 >> qg_log2;                 // row streams per XCD
     const int nslices = 8 * nstream;                   // row slices of the launch
-    const int nsubs = nslices * 4;                     // lane-private sub-pools per query
+    const int nsubs = nslices * kPoolSubsPerSlice;     // lane-private sub-pools per query
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int qsub = slot & (qg - 1), nsub = slot >> qg_log2;
     const int slice = xcd * nstream + nsub;
     const int ntiles = (int)((nrows + Geo::kBM - 1) / Geo::kBM);
-    const int sub = (slice * 2 + c.wm) * 2 + (c.lane >> 5);
     const int nq_iter = (nqb > qsub) ? (nqb - qsub + qg - 1) >> qg_log2 : 0;   // query groups in which this qsub is valid
     const int64_t nunits = (int64_t)nq_iter * ntiles;                            // (group, tile) units of this qsub
     const int ntile_total = (nunits > slice) ? (int)((nunits - slice + nslices - 1) / nslices) : 0;
@@ -149,33 +188,32 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     const int64_t S = (int64_t)ntile_total * nk;
     const int g0 = slice / ntiles, t0 = slice % ntiles;                          // first unit of this stream
 
-    // ---- load cursor (see the second-generation kernel) ---------------------------------------------------------
-    // one per-lane offset serves every staging instruction of both operands (their row strides are equal): the row-group
-    // step of instruction j (j * 8 groups of 16 rows) and the slab (KiB block) ride in the scalar offset
-    const int vo = c.wave * 16 * (int)ldx_b + (c.lane >> 2) * 64 + c.st_col;
+    // ---- load cursor -------------------------------------------------------------------------------------------------------
+    // staging instruction j of wave w fills LDS bytes [(j*8+w)*1024, +1024) = slab rows (j*8+w)*16 .. +16; lane i lands on row
+    // (i >> 2), physical chunk (i & 3) and therefore fetches logical chunk (i & 3) ^ ((row >> 1) & 3).  One per-lane offset serves
+    // every staging instruction of both operands (their row strides are equal): the row-group step of instruction j (j * 8 groups
+    // of 16 rows) and the slab (KiB block) ride in the scalar offset
+    const int st_col = ((lane & 3) ^ ((lane >> 3) & 3)) << 4;
+    const int vo = wave * 16 * (int)ldx_b + (lane >> 2) * 64 + st_col;
     const int jstep = 8 * 16 * (int)ldx_b;
     int l_q = g0, l_t = t0, l_k = 0;
     RingSrc sa, sb;
     sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)l_t * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
     sb.rsrc = ring_make_rsrc_n(Q16 + (int64_t)(qsub + l_q * qg) * kRBN * ldq_b, kRBN * ldq_b);
     int64_t issued = 0;
-    // one slab = kLoads pieces per wave (3 of the row panel, 2 of the query panel).  piece(j) issues one of them into the stage
-    // of slab `issued`; advance() moves the cursor to the next slab once all pieces are out.
-    auto piece = [&](const int j) {
+    // one slab = kLoads pieces per wave (3 of the row panel, 2 of the query panel); issue() sends them into the stage of slab
+    // `issued` as a burst and moves the cursor on
+    auto issue = [&]() {
         char* st = smem + (int)(issued & 3) * Geo::kStage;
         const int k0b = l_k * 1024;   // slab l_k of a 16-row group = its l_k-th KiB block
-        if ((VAR & 2) && issued >= 4) return;
-        // cache policy of the two streams (ablation): bit 1 of aux = nt (non-temporal: the line is the first to leave the L2), bit 0 =
-        // sc0.  VAR & 65536: row-panel loads nt (streamed once per query group: they should not evict the query panels, which every
-        // unit re-reads); VAR & 131072: query-panel loads nt (the opposite, as a control)
-        constexpr int kAuxA = (VAR & 65536) ? 2 : 0, kAuxB = (VAR & 131072) ? 2 : 0;
-        if (j < Geo::kALoads)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(sa.rsrc, (rg_lptr_t)(st + (j * 8 + c.wave) * 1024), 16, vo, k0b + j * jstep, 0, kAuxA);
-        else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(sb.rsrc, (rg_lptr_t)(st + Geo::kAOpBytes + ((j - Geo::kALoads) * 8 + c.wave) * 1024),
-                                                     16, vo, k0b + (j - Geo::kALoads) * jstep, 0, kAuxB);
-    };
-    auto advance = [&]() {
+#pragma unroll
+        for (int j = 0; j < Geo::kLoads; ++j) {
+            if (j < Geo::kALoads)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(sa.rsrc, (rg_lptr_t)(st + (j * 8 + wave) * 1024), 16, vo, k0b + j * jstep, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(sb.rsrc, (rg_lptr_t)(st + Geo::kAOpBytes + ((j - Geo::kALoads) * 8 + wave) * 1024),
+                                                         16, vo, k0b + (j - Geo::kALoads) * jstep, 0, 0);
+        }
         ++issued;
         if (issued < S) {
             if (++l_k == nk) {   // next unit of this stream
@@ -188,60 +226,8 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
                     } while (l_t >= ntiles);
                     sb.rsrc = ring_make_rsrc_n(Q16 + (int64_t)(qsub + l_q * qg) * kRBN * ldq_b, kRBN * ldq_b);
                 }
-                sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)((VAR & 512) ? (l_t & 28) : (VAR & 64) ? (l_t & 31) : l_t) * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
+                sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)l_t * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
             }
-        }
-    };
-    auto issue = [&]() {
-#pragma unroll
-        for (int j = 0; j < Geo::kLoads; ++j) piece(j);
-        advance();
-    };
-    // the pieces of a slab ride between the MFMAs of two k-steps: pieces 0..2 after row blocks 1, 3, 5 of the k-step that follows
-    // the barrier (the stage they overwrite was vacated there), pieces 3, 4 after row blocks 1, 3 of the next k-step (before the
-    // next barrier's counted vmcnt, which therefore still sees whole slabs)
-    bool defer_burst = false, defer_burst_b = false;
-    auto hook_post = [&](int mr) {
-        if (VAR & 8192) return;   // ablation: the burst BEFORE the barrier (end of the k-step that precedes it), see hook_pre
-        if (VAR & 2048) {     // ablation: the burst at the START of the k-step that follows the barrier
-            if (mr == 0 && !defer_burst) issue();
-            return;
-        }
-        if (VAR & 4096) {     // ablation: row-panel pieces after this k-step, query-panel pieces after the next one
-            if (mr == MR - 1 && !defer_burst) {
-#pragma unroll
-                for (int j = 0; j < Geo::kALoads; ++j) piece(j);
-            }
-            return;
-        }
-        if (!(VAR & 128)) {   // default: the whole slab as a burst after the k-step (VAR & 128: piece by piece, see below)
-            if (mr == MR - 1 && !defer_burst) issue();
-            return;
-        }
-        // (a deferred slab is issued whole by the MODE 2 slab, after its filter blocks — round 2 issued these three pieces as well
-        // AND the whole slab there: one slab too many per tile, which is what made this variant slower than the burst)
-        if (defer_burst) return;
-        if (mr & 1) piece(mr >> 1);
-    };
-    auto hook_pre = [&](int mr) {
-        if (VAR & 8192) {
-            if (mr == MR - 1) issue();
-            return;
-        }
-        if (VAR & 4096) {
-            if (mr == MR - 1 && !defer_burst_b) {
-                piece(Geo::kALoads);
-                piece(Geo::kALoads + 1);
-                advance();
-            }
-            return;
-        }
-        if (!(VAR & 128)) return;
-        if (defer_burst_b && !(VAR & 256)) return;   // MODE 2 with deferral: the whole slab follows the filter blocks
-        if (mr == 1) piece(3);
-        if (mr == 3) {
-            piece(4);
-            advance();
         }
     };
     issue();
@@ -251,135 +237,157 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
     wait_vmcnt<3 * Geo::kLoads>();
     __builtin_amdgcn_s_barrier();
 
-    // ---- compute side --------------------------------------------------------------------------------------
-    float tau[2];
-    int cur[2] = {0, 0};
-    uint32_t pbase0 = 0;                                             // sub-pool base of the lane's first query column
-    const uint32_t pstep = 32u * kPoolCap * kPoolPlanes * (uint32_t)nsubs;   // ... the second one is 32 queries further
-    f32x16 acc[MR][2];
-    FragsR<MR> f;
+    // ---- compute side --------------------------------------------------------------------------------------------------------
+    float tau[kT16ColBlocks];
+    uint32_t curp = 0;                                                // four 8-bit sub-pool cursors (one per column block)
+    uint32_t pbase_u = 0;                                             // (uniform) record base of query column 0 / lane group 0 of the wave
+    const uint32_t pstep = 16u * kPoolCap * kPoolPlanes * (uint32_t)nsubs;   // ... the next column block is 16 queries further
+    f32x4 acc[kT16RowBlocks][kT16ColBlocks];
+    bf16x8_t a[3], b[2][kT16ColBlocks];
+    const int frow = lane & 15;
+    const int foff = frow * 64 + (((lane >> 4) ^ ((frow >> 1) & 3)) << 4);   // lane's 16 bytes inside a 1-KiB fragment block
     {
-        const char* a_w = smem + c.wm * (32 * MR * 64) + c.frag_off0;
+        const char* a_w = smem + wm * (192 * 64) + foff;
+        const char* b_w = smem + Geo::kAOpBytes + wn * (64 * 64) + foff;
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) f.a[mr] = *(const bf16x8_t*)(a_w + mr * 2048);
-        ringr_read_b<MR>(c, smem, 0, f.b[0]);
-        f.b[1][0] = f.b[0][0];
-        f.b[1][1] = f.b[0][1];
+        for (int i = 0; i < 3; ++i) a[i] = *(const bf16x8_t*)(a_w + i * 1024);
+#pragma unroll
+        for (int j = 0; j < kT16ColBlocks; ++j) b[0][j] = *(const bf16x8_t*)(b_w + j * 1024);
     }
     int64_t s = 0;
-    // MODE 0: a slab inside a tile.  MODE 1: the first slab of the first tile (its first MFMAs take C = 0 instead of a
-    // cleared accumulator).  MODE 2: the first slab of a later tile, FUSED with the threshold filter of the tile just
-    // finished: block by block (mr), the filter reads the finished scores and the C = 0 MFMAs of the new tile overwrite
-    // them, so the matrix pipe works on block mr while the VALU filters block mr + 1 (the filter alone leaves the matrix
-    // pipe idle: all waves run it at the same time).  The LAST slab of a tile that a MODE 2 slab follows (defer_burst): its trailing
-    // burst of slab loads is deferred until after the filter, so that the filter's pool stores do not queue behind 40 LDS-DMA
-    // pieces in the CU's texture-address FIFO while the matrix pipe waits for the wave (VAR & 256: no deferral, ablation).
-    int32_t epi_row_wave0 = 0;   // (uniform) first row of the wave's block of the tile whose filter is pending
-    auto slab = [&](auto mode_tag) {
+    bool defer_burst = false;     // (uniform) the slab being multiplied is the last of a tile that a fused-filter slab follows
+    int32_t epi_row_wave0 = 0;    // (uniform) first row of the wave's block of the tile whose filter is pending
+    // MODE 0: a slab inside a tile.  MODE 1: the first slab of a tile (its MFMAs take C = 0 instead of a cleared accumulator).
+    // MODE 2 (ablation VAR & 4096, the default until the A/B of profiles/r03_t16_standalone.txt): the first slab of a later tile, FUSED
+    // with the threshold filter of the tile just finished: the filter reads a pair of row
+    // blocks and the C = 0 MFMAs of the new tile overwrite it, so the matrix pipe works while the VALU filters (the filter alone
+    // leaves the matrix pipe idle: all waves run it at the same time).  All six pairs are filtered before row block 9 (pairs 4 and 5
+    // together at row block 8: their accumulators are only overwritten at blocks 8..11), and the slab-load burst that the previous slab
+    // DEFERRED is issued right after them, before the slab barrier: the filter's pool stores do not queue behind 40 LDS-DMA pieces in
+    // the CU's texture-address FIFO while the matrix pipe waits for the wave, and the barrier's counted vmcnt still sees whole slabs.
+    auto slab = [&](auto mode_tag, auto cur_tag) {
         constexpr int MODE = decltype(mode_tag)::value;
-        char* st0 = smem + (int)(s & 3) * Geo::kStage;
-        // k-step 0 of slab s (operands: a, b[0]); a <- k-step 1 of slab s, b[1] <- k-step 1 of slab s
-        if (!(VAR & 4)) {
-            if (MODE == 0) {
-                ringr_step<MR, (VAR & 32) != 0>(c, f, 0, st0, 1, acc, hook_pre);
-            } else {
-                ringr_read_b<MR>(c, st0, 1, f.b[1]);
-                const char* a_w = st0 + c.wm * (32 * MR * 64) + (c.frag_off0 ^ 32);
-                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (MODE == 2 && !(VAR & 1)) filter_hazard_cover();
-                if (MODE == 2) defer_burst_b = true;    // (VAR & 4096 only: the explicit issue() below carries the whole slab)
+        constexpr int CUR = decltype(cur_tag)::value;
+        const char* st0 = smem + (int)(s & 3) * Geo::kStage;
+        const char* st1 = smem + (int)((s + 1) & 3) * Geo::kStage;
+        const char* a_cur = st0 + wm * (192 * 64) + foff;
+        const char* a_nxt = st1 + wm * (192 * 64) + foff;
+        const char* b_nxt = st1 + Geo::kAOpBytes + wn * (64 * 64) + foff;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int mr = 0; mr < MR; ++mr) {
-                    if (MODE == 2 && !(VAR & 1)) {
-                        filter_epilogue_mr<(VAR & 8) != 0>(acc[mr][0], acc[mr][1], mr, tau, cur, pbase0, pstep, (uint32_t)nsubs,
-                                                           pool, epi_row_wave0);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    acc[mr][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mr], f.b[0][0], z, 0, 0, 0);
-                    acc[mr][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mr], f.b[0][1], z, 0, 0, 0);
-                    f.a[mr] = *(const bf16x8_t*)(a_w + mr * 2048);
-                    if (MODE == 2) hook_pre(mr);   // (MODE 1 = the very first slab: no slab is half issued yet)
-                    if (MODE == 2 && !(VAR & 1)) __builtin_amdgcn_sched_barrier(0);
-                }
-                if (MODE == 2) defer_burst_b = false;
-                if (MODE == 2 && !(VAR & 256) && !(VAR & 8192)) issue();   // the burst the previous slab deferred
+        for (int i = 0; i < kT16RowBlocks; ++i) {
+            if (i == 9) {
+                // every fragment of stage s is in registers or consumed (its stage may be refilled), slab s + 1 must have landed
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of slab s are complete (WAR on its stage)
+                wait_vmcnt<2 * Geo::kLoads>();                       // slab s+1 has landed (this thread's part) ...
+                __builtin_amdgcn_s_barrier();                        // ... and everybody else's
             }
+            if (MODE == 2 && !(VAR & 1) && (!(VAR & 512) || wm == 0)) {   // (VAR & 512, ablation: only one wave of each SIMD filters)
+                if (i == 0 || (!(VAR & 32) && (i == 2 || i == 4 || i == 6))) {   // (VAR & 32, ablation: pair 0 only)
+                    filter_pair<(VAR & 8) != 0>(acc[i], acc[i + 1], i >> 1, tau, curp, pbase_u, pstep, (uint32_t)nsubs, pool, epi_row_wave0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (i == 8 && !(VAR & 32)) {
+                    filter_pair<(VAR & 8) != 0>(acc[8], acc[9], 4, tau, curp, pbase_u, pstep, (uint32_t)nsubs, pool, epi_row_wave0);
+                    filter_pair<(VAR & 8) != 0>(acc[10], acc[11], 5, tau, curp, pbase_u, pstep, (uint32_t)nsubs, pool, epi_row_wave0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kT16ColBlocks; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i % 3], b[CUR][j], MODE == 0 ? acc[i][j] : z, 0, 0, 0);
+            a[i % 3] = *(const bf16x8_t*)(i + 3 < kT16RowBlocks ? a_cur + (i + 3) * 1024 : a_nxt + (i + 3 - kT16RowBlocks) * 1024);
+            if (i >= 9) b[CUR ^ 1][i - 9] = *(const bf16x8_t*)(b_nxt + (i - 9) * 1024);
+            if (i == 11) b[CUR ^ 1][3] = *(const bf16x8_t*)(b_nxt + 3 * 1024);
+            if (MODE == 2 && i == 8 && !(VAR & 256) && (!(VAR & 1) || (VAR & 1024))) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue();   // the burst the previous slab deferred
+            }
+            if (!(VAR & 128)) __builtin_amdgcn_sched_barrier(0);   // program order pinned after every row block (VAR & 128: left to the scheduler, +0.35 ms)
         }
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of slab s are complete (WAR on its stage)
-        if (VAR & 2)
-            wait_vmcnt<0>();
-        else
-            wait_vmcnt<2 * Geo::kLoads>();                   // slab s+1 has landed (this thread's part) ...
-        __builtin_amdgcn_s_barrier();                        // ... and everybody else's
         ++s;
-        // k-step 1 of the old slab (operands: a, b[1]); a, b[0] <- k-step 0 of slab s (just opened)
-        // ... and the first three pieces of slab s+3 (or a dummy) -> the stage slab s-1 vacated at the barrier
-        if (!(VAR & 4)) ringr_step<MR, (VAR & 32) != 0>(c, f, 1, smem + (int)(s & 3) * Geo::kStage, 0, acc, hook_post);
+        // the stage slab s-1 vacated at its barrier takes slab s+3 — unless the fused filter of the next slab wants the FIFO first
+        if (!defer_burst) issue();
         __builtin_amdgcn_sched_barrier(0);
     };
     using M0 = std::integral_constant<int, 0>;
     using M1 = std::integral_constant<int, 1>;
     using M2 = std::integral_constant<int, 2>;
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    // (the B double buffer alternates with the slab parity.  A tile has an EVEN number of slabs — the row stride is a multiple of 64
+    // elements —, so the first slab of every tile has parity 0 and the parity of every call below is a compile-time constant: a
+    // run-time dispatch on (s & 1) doubled the slab body behind a branch and cost the register allocator 1500 spills)
 
-    // the counters' query index is recomputed at store time (two VGPR pairs less live across the tile loop)
+    // the counters' query index is recomputed at store time (registers are scarce across the tile loop)
     auto store_counts = [&](int g) {
 #pragma unroll
-        for (int nr = 0; nr < 2; ++nr) {
-            const int64_t qi = (int64_t)(qsub + g * qg) * kRBN + c.wn * 64 + nr * 32 + (c.lane & 31);
-            pool_cnt[qi * nsubs + sub] = cur[nr];
+        for (int j = 0; j < kT16ColBlocks; ++j) {
+            const uint32_t ln = lane_now();
+            const int64_t qi = (int64_t)(qsub + g * qg) * kRBN + wn * 64 + j * 16 + (int)(ln & 15u);
+            pool_cnt[qi * nsubs + (slice * 2 + wm) * 4 + (int)(ln >> 4)] = (int32_t)((curp >> (8 * j)) & 255u);
         }
     };
     auto setup_group = [&](int g) {
 #pragma unroll
-        for (int nr = 0; nr < 2; ++nr) {
-            const int64_t qi = (int64_t)(qsub + g * qg) * kRBN + c.wn * 64 + nr * 32 + (c.lane & 31);
-            tau[nr] = (VAR & 16) ? INFINITY : ring_launder(tau_g[qi]);
-            if (nr == 0) pbase0 = (uint32_t)(qi * kPoolCap * kPoolPlanes * nsubs + sub);
-            cur[nr] = 0;
+        for (int j = 0; j < kT16ColBlocks; ++j) {
+            const int64_t qi = (int64_t)(qsub + g * qg) * kRBN + wn * 64 + j * 16 + (int)(lane_now() & 15u);
+            tau[j] = (VAR & 16) ? INFINITY : ring_launder(tau_g[qi]);
         }
+        pbase_u = (uint32_t)(((int64_t)(qsub + g * qg) * kRBN + wn * 64) * kPoolCap * kPoolPlanes * nsubs + (slice * 2 + wm) * 4);
+        curp = 0;
     };
     int c_q = g0, c_t = t0, cur_q = g0;
     setup_group(c_q);
-    if (VAR & 4) {
-#pragma unroll
-        for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-            for (int nr = 0; nr < 2; ++nr)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.f;
-    }
-    slab(M1{});
+    slab(M1{}, C0{});
 #pragma unroll 1
-    for (int j = 0; j < ntile_total; ++j) {
+    for (int jt = 0; jt < ntile_total; ++jt) {
 #pragma unroll 1
-        for (int kk = 1; kk < nk; ++kk) {
-            defer_burst = !(VAR & 256) && !(VAR & 8192) && kk == nk - 1 && j + 1 < ntile_total;   // (uniform) see MODE 2
-            slab(M0{});
+        for (int kk = 1; kk + 1 < nk; kk += 2) {
+            slab(M0{}, C1{});
+            slab(M0{}, C0{});
         }
+        constexpr bool kFused = (VAR & 4096) != 0;   // ablation: the filter fused into the next tile's first slab (MODE 2), see above
+        defer_burst = kFused && !(VAR & 256) && (!(VAR & 1) || (VAR & 1024)) && jt + 1 < ntile_total;   // (uniform) see MODE 2
+        slab(M0{}, C1{});
         defer_burst = false;
-        // tile j is complete in acc
+        // tile jt is complete in acc
         const int64_t trow = row0 + (int64_t)c_t * Geo::kBM;
-        epi_row_wave0 = (int32_t)trow + c.wm * (32 * MR);
+        epi_row_wave0 = (int32_t)trow + wm * 192;
         c_t += nslices;
         while (c_t >= ntiles) {
             c_t -= ntiles;
             ++c_q;
         }
-        if (j + 1 < ntile_total) {
-            slab(M2{});                 // filter of tile j fused with the first slab of tile j + 1
-            if (c_q != cur_q) {         // (uniform) the stream moves on to the next query group
+        const bool more = jt + 1 < ntile_total;
+        if (!(VAR & 1) && !(kFused && more)) {
+            // the filter of the finished tile, on its own: all eight waves run it at the same time and the matrix pipe idles for ~1.7 us per
+            // tile — and that is CHEAPER than hiding it (fused into the next tile's first slab it cost 1.1 ms per pass instead of 0.7: with
+            // 48 short MFMAs per slab the wave's instruction stream has no slack, and every VALU block a wave inserts lengthens the slab
+            // for all eight waves at its barrier; profiles/r03_t16_*.txt)
+            filter_hazard_cover();
+#pragma unroll
+            for (int p = 0; p < kT16RowBlocks / 2; ++p)
+                filter_pair<(VAR & 8) != 0>(acc[2 * p], acc[2 * p + 1], p, tau, curp, pbase_u, pstep, (uint32_t)nsubs, pool, epi_row_wave0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else if ((VAR & 1) && !more) {
+#pragma unroll
+            for (int i = 0; i < kT16RowBlocks; ++i)
+#pragma unroll
+                for (int j = 0; j < kT16ColBlocks; ++j) asm volatile("" ::"v"(acc[i][j]));
+        }
+        if (more) {
+            if (kFused)
+                slab(M2{}, C0{});           // filter of tile jt fused with the first slab of tile jt + 1
+            else
+                slab(M1{}, C0{});
+            if (c_q != cur_q) {             // (uniform) the stream moves on to the next query group
                 store_counts(cur_q);
                 cur_q = c_q;
                 setup_group(c_q);
             }
-        } else if (!(VAR & 1)) {
-            filter_epilogue_r<MR, (VAR & 8) != 0>(acc, tau, cur, pbase0, pstep, (uint32_t)nsubs, pool, epi_row_wave0);
-        } else {
-#pragma unroll
-            for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-                for (int nr = 0; nr < 2; ++nr) asm volatile("" ::"v"(acc[mr][nr]));
         }
     }
     store_counts(cur_q);
@@ -390,7 +398,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_r6_kernel(
 int fused_tile_rows() { return RingGeom<6>::kBM; }
 
 // query blocks an XCD works on concurrently for a batch of nqb query blocks (power of two <= 8); the fused launch then
-// has 256 / qg row slices and 1024 / qg sub-pools per query
+// has 256 / qg row slices and kPoolSubsPerSlice * 256 / qg sub-pools per query
 int fused_query_group(int64_t nq_pad) {
     const int64_t nqb = nq_pad / kRBN;
 #ifdef LDOT_ABLATION
@@ -409,44 +417,27 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
                         hipStream_t st) {
     if (nrows <= 0 || nq_pad <= 0) return LDOT_OK;
     LDOT_REQUIRE(ldx_elems == ldq_elems, LDOT_EINVAL, "index and query shadows must have the same row stride");
-    auto rk = score_filter_r6_kernel<0>;
+    auto rk = score_filter_t16_kernel<0>;
 #ifdef LDOT_ABLATION
-    // Ablation builds only (python -m lightningdot_amd.build --ablation; tools/ablate.sh): LDOT_DEBUG_VARIANT selects a profiling
-    // variant of the kernel.  Results are meaningless under most of them, so the product library does not contain this hook.
-    //   16 tau = +inf (epilogue fast path only), 18 = 16 + no global loads after the prologue, 17 no epilogue at all,
-    //   64 every row tile aliased onto the first 32 (A panel always L2-resident), 128 slab loads piece by piece between the MFMAs,
-    //   256 no deferral of the slab-load burst around the filter
+    // Ablation builds only (python -m lightningdot_amd.build --ablation -> libldot_ablation.so; tools/ab.sh): LDOT_DEBUG_VARIANT selects
+    // a profiling variant of the kernel.  Results are meaningless under most of them, so the product library does not contain this hook.
+    //   16 tau = +inf (filter fast path only), 17 no filter at all, 8 no record stores, 4096 the filter fused into the next tile's first slab
     static int variant = -1;
     if (variant < 0) {
         const char* e = getenv("LDOT_DEBUG_VARIANT");
         variant = e ? atoi(e) : 0;
     }
-    if (variant == 16) rk = score_filter_r6_kernel<16>;
-    if (variant == 18) rk = score_filter_r6_kernel<18>;
-    if (variant == 17) rk = score_filter_r6_kernel<17>;
-    if (variant == 48) rk = score_filter_r6_kernel<48>;
-    if (variant == 64) rk = score_filter_r6_kernel<64>;
-    if (variant == 80) rk = score_filter_r6_kernel<80>;
-    if (variant == 128) rk = score_filter_r6_kernel<128>;
-    if (variant == 144) rk = score_filter_r6_kernel<144>;
-    if (variant == 256) rk = score_filter_r6_kernel<256>;
-    if (variant == 65536) rk = score_filter_r6_kernel<65536>;     // row-panel loads non-temporal
-    if (variant == 65552) rk = score_filter_r6_kernel<65552>;     // ... with tau = +inf
-    if (variant == 131072) rk = score_filter_r6_kernel<131072>;   // query-panel loads non-temporal (control)
-    if (variant == 131088) rk = score_filter_r6_kernel<131088>;
-    if (variant == 384) rk = score_filter_r6_kernel<384>;   // spread loads, no deferral
-    if (variant == 400) rk = score_filter_r6_kernel<400>;
-    if (variant == 528) rk = score_filter_r6_kernel<528>;
-    if (variant == 4096) rk = score_filter_r6_kernel<4096>;
-    if (variant == 4112) rk = score_filter_r6_kernel<4112>;
-    if (variant == 16384) rk = score_filter_r6_kernel<16384>;
-    if (variant == 32768) rk = score_filter_r6_kernel<32768>;
-    if (variant == 8192) rk = score_filter_r6_kernel<8192>;
-    if (variant == 8208) rk = score_filter_r6_kernel<8208>;
-    if (variant == 2048) rk = score_filter_r6_kernel<2048>;
-    if (variant == 2064) rk = score_filter_r6_kernel<2064>;   // 16 + 512: the 4 row streams of an XCD share ONE tile (everything L2-resident)
-#endif
-#ifdef LDOT_ABLATION
+    if (variant == 16) rk = score_filter_t16_kernel<16>;
+    if (variant == 17) rk = score_filter_t16_kernel<17>;
+    if (variant == 8) rk = score_filter_t16_kernel<8>;
+    if (variant == 128) rk = score_filter_t16_kernel<128>;    // row blocks NOT pinned in program order (the scheduler sinks the fragment loads)
+    // the filter fused into the next tile's first slab (the default until the stand-alone filter measured 0.4 ms faster):
+    if (variant == 4096) rk = score_filter_t16_kernel<4096>;
+    if (variant == 4112) rk = score_filter_t16_kernel<4112>;  // ... with tau = +inf
+    if (variant == 4352) rk = score_filter_t16_kernel<4352>;  // ... without the deferral of the slab-load burst
+    if (variant == 4624) rk = score_filter_t16_kernel<4624>;  // ... tau = +inf, only the wm = 0 waves filter
+    if (variant == 4144) rk = score_filter_t16_kernel<4144>;  // ... tau = +inf, only pair 0 filtered
+    if (variant == 1041 + 4096) rk = score_filter_t16_kernel<1041 + 4096>;  // no epilogue, but the slab-load burst deferred as if there were a fused one
     LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<6>::kLds));
 #else
     static bool attr_set[kAttrDevices];

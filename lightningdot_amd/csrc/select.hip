@@ -705,8 +705,8 @@ __global__ __launch_bounds__(256) void parts_to_lists_kernel(const float* __rest
 constexpr int kPoolSelThreads = 64;
 // A step (one entry level of 64 sub-pools = 64 records of 8 scores) appends at most 512 candidates on top of a full list,
 // which sizes the LDS key buffer (cap >= kp + 512) and with it the workgroups per CU.  (LV: unused, kept for the launch sites.)
-// rows of the 8 scores of a record relative to its base row (accumulator registers 8h..8h+3 / 8h+4..8h+7 of a 32x32 MFMA tile)
-__device__ __forceinline__ int pool_rec_row(int j) { return j < 4 ? j : j + 4; }
+// rows of the 8 scores of a record relative to its base row (the lane's 4 rows of a 16x16 MFMA tile and of the tile below it)
+__device__ __forceinline__ int pool_rec_row(int j) { return j < 4 ? j : j - 4 + kPoolRecHiRow; }
 
 // Walk the records of 64 sub-pools (lane l holds the clamped count c of sub-pool sidx = s0 + l).  The counts are small and uneven
 // (1.5 on average, 6-10 at the fullest sub-pool), so walking LEVEL by level (entry e of every sub-pool per round) costs as many
@@ -759,10 +759,10 @@ __device__ __forceinline__ void walk_subpools(WaveSelector& sel, const uint4* __
             sel.push(make_key(__uint_as_float(p0.y), (uint32_t)(r + 1)), r + 1 < row_end);
             sel.push(make_key(__uint_as_float(p0.z), (uint32_t)(r + 2)), r + 2 < row_end);
             sel.push(make_key(__uint_as_float(p0.w), (uint32_t)(r + 3)), r + 3 < row_end);
-            sel.push(make_key(__uint_as_float(p1.x), (uint32_t)(r + 8)), r + 8 < row_end);
-            sel.push(make_key(__uint_as_float(p1.y), (uint32_t)(r + 9)), r + 9 < row_end);
-            sel.push(make_key(__uint_as_float(p1.z), (uint32_t)(r + 10)), r + 10 < row_end);
-            sel.push(make_key(__uint_as_float(p1.w), (uint32_t)(r + 11)), r + 11 < row_end);
+            sel.push(make_key(__uint_as_float(p1.x), (uint32_t)(r + kPoolRecHiRow + 0)), r + kPoolRecHiRow + 0 < row_end);
+            sel.push(make_key(__uint_as_float(p1.y), (uint32_t)(r + kPoolRecHiRow + 1)), r + kPoolRecHiRow + 1 < row_end);
+            sel.push(make_key(__uint_as_float(p1.z), (uint32_t)(r + kPoolRecHiRow + 2)), r + kPoolRecHiRow + 2 < row_end);
+            sel.push(make_key(__uint_as_float(p1.w), (uint32_t)(r + kPoolRecHiRow + 3)), r + kPoolRecHiRow + 3 < row_end);
         }
     }
 }
