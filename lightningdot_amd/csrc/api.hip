@@ -678,7 +678,7 @@ static int fused_launch_and_select(ldot_index* ix, int64_t q0, int64_t nq, int64
                              (int32_t*)ix->w_pool_cnt.p, st);
     prof_end(ix, st);
     if (rc) return rc;
-    if (nq <= kFewSelectMaxQueries && nsubs >= 1024 && kp + 512 + 32 <= 1024) {
+    if (nq <= kFewSelectMaxQueries && nsubs >= 128 * kPoolSubsPerSlice && kp + 512 + 32 <= 1024) {
         // few queries: G waves per query fold the sub-pools into partial lists, one merge joins them with the running list
         const int G = 16;
         if ((rc = ix->w_part_s.ensure((size_t)G * nq * kp * 4))) return rc;
@@ -713,8 +713,8 @@ static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_p
     int rc;   // (q0 is a multiple of 256: whole 16-row blocks of the query shadow)
     // Pool sizing rule: a launch over `len` rows after `r` scanned rows admits ~kp*len/r candidates per query,
     // spread over nsubs lane-private sub-pools of kPoolCap records.  Keeping the expectation <= kPoolCap / 4 per sub-pool
-    // (overflow probability ~1e-11 each) bounds len <= r * kFill * nsubs / kp (1024 r / kp at 256 sub-pools; 8x that for the
-    // 2048 sub-pools of a single query block, whose search is then ONE fused launch); the smallest launch is one tile
+    // (overflow probability ~1e-11 each) bounds len <= r * kFill * nsubs / kp (1024 r / kp at 128 sub-pools; 8x that for the
+    // 1024 sub-pools of a single query block, whose search is then ONE fused launch); the smallest launch is one tile
     // per row slice, hence the warm-up covers at least bm * nslices * kp / (kFill * nsubs) rows.
     constexpr int64_t kFill = kPoolCap / 4;
     const int64_t bm = fused_tile_rows();

@@ -23,7 +23,9 @@
 // C/D layout of 16x16x32: lane l holds rows (l >> 4) * 4 .. + 4 of column l & 15.  A lane therefore owns FOUR query columns (column
 // block j = 0..3: query wn * 64 + j * 16 + (l & 15)) and, per column, 4 rows of each of the wave's 12 row blocks.
 //
-// Appends go to lane-private sub-pools in HBM (cursor in a VGPR byte, no atomics, no LDS): for a query q each of the
+// Appends go to lane-private sub-pools in HBM (cursor in a VGPR byte, no atomics, no LDS; letting lanes l and l ^ 32 SHARE a sub-pool —
+// identical cursor copies, both run the rare path when either fires — halves the sub-pools the select walks but costs the kernel what it
+// saves the select: 12.84 vs 12.82 ms per pass, profiles/r03_subpool_sharing_ab.txt): for a query q each of the
 // 8 (wave row, lane group) x (row slices) that can produce candidates owns kPoolCap RECORDS.  A record is what a lane holds when its
 // max-of-8 test fires: the 4 + 4 scores of two vertically adjacent tiles (rows rb + {0,1,2,3} and rb + 16 + {0,1,2,3}) and rb — three
 // 16-byte planes, stored entry-major and plane-major, pool[((q * kPoolCap + e) * 3 + plane) * nsubs + sub] in 16-byte units, so that the
@@ -363,10 +365,10 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
         }
         const bool more = jt + 1 < ntile_total;
         if (!(VAR & 1) && !(kFused && more)) {
-            // the filter of the finished tile, on its own: all eight waves run it at the same time and the matrix pipe idles for ~1.7 us per
-            // tile — and that is CHEAPER than hiding it (fused into the next tile's first slab it cost 1.1 ms per pass instead of 0.7: with
-            // 48 short MFMAs per slab the wave's instruction stream has no slack, and every VALU block a wave inserts lengthens the slab
-            // for all eight waves at its barrier; profiles/r03_t16_*.txt)
+            // the filter of the finished tile, on its own: all eight waves run it at the same time and the matrix pipe idles meanwhile
+            // (~0.6 us per tile without admissions, 0.24 ms per pass).  Hiding it in the next tile's first slab (MODE 2, variant 4096) is
+            // not faster: 10.93-10.97 vs 10.97-10.99 ms per pass in this build, and 0.4 ms SLOWER in the build before the tile loop was
+            // restructured (profiles/r03_t16_standalone.txt, r03_final_variants.txt) — the simple form is the default.
             filter_hazard_cover();
 #pragma unroll
             for (int p = 0; p < kT16RowBlocks / 2; ++p)
