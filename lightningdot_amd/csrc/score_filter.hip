@@ -45,7 +45,7 @@
 // direct-to-LDS load instruction (64 lanes x 16 B = 16 rows x 64 B of one slab) reads one contiguous KiB = eight full 128-B lines.
 //
 // Earlier generations of this kernel (256x256 two-stage, commit da2a5a4; 256x256 on the LDS ring, commit 62cbd68; 384x256 on
-// v_mfma_f32_32x32x16_bf16 with its ablation variants, rounds 1-3 up to commit 0f2c) are in the history; their measurements are in
+// v_mfma_f32_32x32x16_bf16 with the filter fused into the next tile's first slab, rounds 1-3 up to commit 34b001c) are in the history; their measurements are in
 // DESIGN.md section 5.2.
 #include <math.h>
 #include <stdlib.h>
@@ -57,21 +57,12 @@
 
 namespace ldot {
 
-// max of eight accumulator registers in four instructions.  fmaxf() would add a canonicalising v_max per MFMA
+// max of eight accumulator registers in four instructions (max8x2_raw: two such maxima at a time).  fmaxf() would add a canonicalising v_max per MFMA
 // output (hipcc cannot prove MFMA results are quiet); scores are never signalling NaNs, so v_max3 is applied
 // directly.  The operands are MFMA results: the caller guarantees the MFMA -> VALU read wait states (hipcc does not pad hazards for
 // inline asm).
-__device__ __forceinline__ float max8_raw(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
-    float m;
-    asm volatile(
-        "v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max_f32 %0, %0, %8"
-        : "=&v"(m)
-        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));
-    return m;
-}
-
-// two such maxima as two INTERLEAVED dependency chains (a dependent VALU instruction cannot issue back to back; 18 asm operands — the
-// limit is 30, so four chains do not fit one statement)
+// Two INTERLEAVED dependency chains per statement, so that no instruction waits for the result of the one before it (18 asm operands — the
+// limit is 30, so four chains do not fit one statement).
 __device__ __forceinline__ void max8x2_raw(const f32x4& a0, const f32x4& a1, const f32x4& b0, const f32x4& b1, float& ma, float& mb) {
     asm volatile(
         "v_max3_f32 %0, %2, %3, %4\n\tv_max3_f32 %1, %10, %11, %12\n\t"
