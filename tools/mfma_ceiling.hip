@@ -333,7 +333,8 @@ static void run_shape(const char* name, const char* src, float* sink, uint64_t* 
 // The slab loop of score_filter_r6 re-tiled for v_mfma_f32_16x16x32_bf16: wave tile 192 x 64 = 12 x 4 tiles of 16 x 16, ONE k-step per
 // 32-deep slab (48 MFMAs), A fragments in a ring of 6 registers-quads (reloaded in place 24 MFMAs ahead), the 4 B fragments of the next
 // slab fetched during the current one.  Fragment (16 rows x 32 k): lane l reads row l & 15, 16-byte chunk (l >> 4) ^ ((row >> 1) & 3).
-// FEED as above: 1 ds_read stream only, 2 + direct-to-LDS burst, 5 + the loads spread between the MFMAs.
+// FEED as above: 1 ds_read stream only, 2 + direct-to-LDS burst, 5 + the loads spread between the MFMAs.  Upper bounds of taking the query
+// operand out of the LDS: 7 = 2 without the B fragment reads (B stays in registers), 8 = 7 without the B pieces of the slab loads.
 template <int FEED>
 __global__ __launch_bounds__(512, 2) void ceiling16_kernel(const char* __restrict__ src, int64_t src_region, int nslab,
                                                            float* __restrict__ sink, uint64_t* __restrict__ ticks) {
@@ -348,7 +349,8 @@ __global__ __launch_bounds__(512, 2) void ceiling16_kernel(const char* __restric
     const int so_end = (int)src_region - kStage;
     auto issue_piece = [&](const int j) {
         char* st = smem + (issued & 3) * kStage;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (rg_lptr_t)(st + (j * 8 + wave) * 1024), 16, vo, so + (j * 8 + wave) * 1024, 0, 0);
+        if (FEED != 8 || j < 3)   // (8: the row-panel pieces only)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (rg_lptr_t)(st + (j * 8 + wave) * 1024), 16, vo, so + (j * 8 + wave) * 1024, 0, 0);
         if (j == 4) {
             ++issued;
             so += kStage;
@@ -357,7 +359,8 @@ __global__ __launch_bounds__(512, 2) void ceiling16_kernel(const char* __restric
     };
     auto issue = [&]() {
 #pragma unroll
-        for (int j = 0; j < 5; ++j) issue_piece(j);
+        for (int j = 0; j < 5; ++j)
+            issue_piece(j);
     };
     issue();
     issue();
@@ -392,16 +395,16 @@ __global__ __launch_bounds__(512, 2) void ceiling16_kernel(const char* __restric
         for (int i = 0; i < 12; ++i) {
             if (i == 9) {   // blocks 0..11 of this slab are in registers or consumed: the stage is free, the next one must have landed
                 __builtin_amdgcn_sched_barrier(0);
-                if (FEED == 2 || FEED == 5) {
+                if (FEED == 2 || FEED == 5 || FEED == 7 || FEED == 8) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(10) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FEED == 8 ? 6 : 10) : "memory");
                     __builtin_amdgcn_s_barrier();
                 }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i % 3], b[cur][j], acc[i][j], 0, 0, 0);
             a[i % 3] = *(const bf16x8_t*)((i + 3 < 12 ? a_cur + (i + 3) * 1024 : a_nxt + (i + 3 - 12) * 1024));
-            if (i >= 9) {
+            if (i >= 9 && FEED != 7 && FEED != 8) {
                 b[cur ^ 1][i - 9] = *(const bf16x8_t*)(b_nxt + (i - 9) * 1024);
                 if (i == 11) b[cur ^ 1][3] = *(const bf16x8_t*)(b_nxt + 3 * 1024);
             }
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(512, 2) void ceiling16_kernel(const char* __restric
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (FEED == 2) issue();
+        if (FEED == 2 || FEED == 7 || FEED == 8) issue();
     };
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
@@ -490,6 +493,8 @@ int main(int argc, char** argv) {
         run16<1>("T16 mfma+ds_read           random", src, region, sink, ticks, target_ms);
         run16<2>("T16 mfma+ds_read+lds-dma   random", src, region, sink, ticks, target_ms);
         run16<5>("T16 full, dma interleaved  random", src, region, sink, ticks, target_ms);
+        run16<7>("T16 no B fragment reads    random", src, region, sink, ticks, target_ms);
+        run16<8>("T16 no B reads, no B dma   random", src, region, sink, ticks, target_ms);
         run16<2>("T16 mfma+ds_read+lds-dma   zeros", zsrc, region, sink, ticks, target_ms);
         run_shape<32>("shape 32x32x16 mfma-only   random", src, sink, ticks, target_ms);
         run_shape<16>("shape 16x16x32 mfma-only   random", src, sink, ticks, target_ms);
