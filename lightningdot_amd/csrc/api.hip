@@ -655,7 +655,7 @@ static int dense_scan_all(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, in
 
 // fused scan: dense warm-up of the first rows (gives every query a full list and a threshold), then
 // geometrically growing fused-filter launches, each followed by the pool select that raises the thresholds.
-// Queries are processed in chunks of kFusedQueryChunk (bounds the candidate pools: 196 KiB per query at 128 sub-pools).
+// Queries are processed in chunks of kFusedQueryChunk (bounds the candidate pools: 196 KiB per query at 256 sub-pools of 16 records).
 constexpr int64_t kFusedQueryChunk = 16384;
 constexpr int64_t kFewSelectMaxQueries = 256;   // one query block: sub-pools folded by 16 waves per query + one merge
 constexpr int64_t kFewBlockGrowthPct = 1600;   // launch growth with ONE query block (65 .. 256 queries): 2-3 % faster than growing
@@ -713,8 +713,8 @@ static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_p
     int rc;   // (q0 is a multiple of 256: whole 16-row blocks of the query shadow)
     // Pool sizing rule: a launch over `len` rows after `r` scanned rows admits ~kp*len/r candidates per query,
     // spread over nsubs lane-private sub-pools of kPoolCap records.  Keeping the expectation <= kPoolCap / 4 per sub-pool
-    // (overflow probability ~1e-11 each) bounds len <= r * kFill * nsubs / kp (1024 r / kp at 128 sub-pools; 8x that for the
-    // 1024 sub-pools of a single query block, whose search is then ONE fused launch); the smallest launch is one tile
+    // (overflow probability ~1e-11 each) bounds len <= r * kFill * nsubs / kp (1024 r / kp at 256 sub-pools; 8x that for the
+    // 2048 sub-pools of a single query block, whose search is then ONE fused launch); the smallest launch is one tile
     // per row slice, hence the warm-up covers at least bm * nslices * kp / (kFill * nsubs) rows.
     constexpr int64_t kFill = kPoolCap / 4;
     const int64_t bm = fused_tile_rows();

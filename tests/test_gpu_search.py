@@ -142,8 +142,8 @@ def test_fused_adversarial_order_falls_back(L):
     """Rows sorted so that every later row beats all earlier ones for every query: the lane-private pools
     overflow, the library detects it and redoes the search densely — results stay exact."""
     rng = np.random.default_rng(11)
-    # 8 query blocks -> 32 row slices; a sub-pool holds 32 records of 8 rows each, so it takes a launch with 3 tiles per slice
-    # (the third geometric launch, rows 26 624 .. 63 488) to overflow one: 288 winning rows per sub-pool = 36 records
+    # 8 query blocks -> 32 row slices; a sub-pool (one lane group of one wave row: 48 rows of a 384-row tile) holds 16 records of 8 rows
+    # each, so a launch with 3 tiles per slice (the third geometric launch, rows 26 624 .. 63 488) overflows it: 144 winning rows = 18 records
     n, d, nq = 70000, 64, 2048
     base = rng.standard_normal(d).astype(np.float32)
     base /= np.linalg.norm(base)
@@ -161,11 +161,11 @@ def test_overflow_recovery_redoes_only_the_flagged_queries(L):
     lane-private pools of the few queries that match it.  Only those queries are searched again — one fused launch with their
     (valid) thresholds, no dense pass at all — and the results equal the dense path's bit for bit."""
     rng = np.random.default_rng(33)
-    n, d, nq, nb = 200000, 64, 2048, 24      # (8 query blocks -> 32 row slices, 128 sub-pools per query)
+    n, d, nq, nb = 200000, 64, 2048, 24      # (8 query blocks -> 32 row slices, 256 sub-pools per query)
     x = rng.standard_normal((n, d)).astype(np.float32)
     v = rng.standard_normal(d).astype(np.float32)
     v *= 4.0 / np.linalg.norm(v)
-    x[110000:190000] += v                                   # the block: 208 tiles of 384 rows = 6.5 per row slice (> 32 records per sub-pool)
+    x[110000:190000] += v                                   # the block: 208 tiles of 384 rows = 6.5 per row slice (6 records per tile: > 16 records per sub-pool)
     q, g = planted_queries(x[:100000], nq)                  # (planted outside the block)
     q[:nb] = v + 0.7 * rng.standard_normal((nb, d)).astype(np.float32)     # queries that match every row of the block
     ix = _index(x, mode=L.MODE_FUSED, warm_rows=4096)
