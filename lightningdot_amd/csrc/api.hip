@@ -713,7 +713,9 @@ static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_p
     int rc;   // (q0 is a multiple of 256: whole 16-row blocks of the query shadow)
     // Pool sizing rule: a launch over `len` rows after `r` scanned rows admits ~kp*len/r candidates per query,
     // spread over nsubs lane-private sub-pools of kPoolCap records.  Keeping the expectation <= kPoolCap / 4 per sub-pool
-    // (overflow probability ~1e-11 each) bounds len <= r * kFill * nsubs / kp (1024 r / kp at 256 sub-pools; 8x that for the
+    // (16 records, expectation 4: overflow probability ~1e-6 per sub-pool and launch WHERE THIS BOUND IS THE ACTIVE ONE, i.e. for k' in the
+    // thousands; at the default growth of 150 % and k' = 128 the expectation is 0.75 and the probability ~1e-17; an overflow costs the
+    // flagged queries one more fused launch, redo_flagged) bounds len <= r * kFill * nsubs / kp (1024 r / kp at 256 sub-pools; 8x that for the
     // 2048 sub-pools of a single query block, whose search is then ONE fused launch); the smallest launch is one tile
     // per row slice, hence the warm-up covers at least bm * nslices * kp / (kFill * nsubs) rows.
     constexpr int64_t kFill = kPoolCap / 4;
