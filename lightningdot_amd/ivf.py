@@ -78,7 +78,7 @@ def _split_long_lists(x, cent, assign, cap: int, seed: int, max_rounds: int = 8)
             n1 = int((part == 1).sum())
             if n1 == 0 or n1 == xs.shape[0]:      # (identical rows: cannot be split by distance — cut the list in the middle)
                 part = (torch.arange(xs.shape[0], device=x.device) >= xs.shape[0] // 2).long()
-                c2 = torch.stack([xs[part == 0].mean(0), xs[part == 1].mean(0)])
+            c2 = torch.stack([xs[part == 0].mean(0), xs[part == 1].mean(0)])   # the halves' centroids = the means of their final members
             cent[li] = c2[0]
             assign[idx[part == 1]] = cent.shape[0] + len(new_cent)
             new_cent.append(c2[1])
