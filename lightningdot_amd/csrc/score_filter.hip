@@ -111,31 +111,30 @@ constexpr int kT16ColBlocks = 4;    // 16-query blocks of a wave tile (64 querie
 template <bool NOSTORE>
 __device__ __forceinline__ void filter_admit(const f32x4 (&lo)[kT16ColBlocks], const f32x4 (&hi)[kT16ColBlocks], int p,
                                              const float (&m)[kT16ColBlocks], const float (&tau)[kT16ColBlocks], uint32_t& curp,
-                                             uint32_t pbase_u, uint32_t pstep, uint32_t nsubs, uint4* __restrict__ pool,
-                                             int32_t row_wave0) {
+                                             uint32_t pbase_u, uint32_t pstep, uint32_t nsubs, uint4* __restrict__ pool, uint32_t vo0,
+                                             int32_t rb0) {
     const bool any = (m[0] >= tau[0]) | (m[1] >= tau[1]) | (m[2] >= tau[2]) | (m[3] >= tau[3]);
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(any) == 0, 1)) return;   // (rare otherwise: a few per tile and wave; laid out of line)
+    // The rare path's cost follows its INSTRUCTION count (one wave issuing dependent instructions: ~8 cycles each, 11.7 M admissions per
+    // pass), not its store count (records of 4 scores and two stores were measured: slower).  Everything per lane that does not depend on
+    // the hit — byte offset of the lane's sub-pool entry 0 (vo0), first row of the lane's rows in the tile (rb0) — is computed once per
+    // tile by the caller, from lane_now() (values that live across the slab loop would be spilled, see there).
 #pragma unroll
     for (int j = 0; j < kT16ColBlocks; ++j) {
         const f32x4 a = lo[j], b = hi[j];
         if (m[j] >= tau[j]) {
-            // (the lane's row offset and the record address are derived HERE from lane_now(): see there)
-            const uint32_t ln = lane_now();
             const uint32_t e = (curp >> (8 * j)) & 255u;
             if (e < 255u) curp += 1u << (8 * j);
             if (e < (uint32_t)kPoolCap && !NOSTORE) {
                 // buffer stores: the wave-uniform base lives in the (scalar) resource, the plane and the column block in the scalar
-                // offset, so the lane's address is ONE register (a 64-bit flat address per plane did not fit: the rare path spilled, and
-                // a scratch reload waits for vmcnt(0) = for the whole LDS-DMA ring)
+                // offset, so the lane's address is ONE register
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void*)(pool + pbase_u), 0, (int)(pstep * 64u), 0x00020000);
-                const uint32_t g4 = (ln >> 4) & 3u;
-                const uint32_t vo = ((ln & 15u) * (pstep >> 4) + g4 + e * (kPoolPlanes * nsubs)) << 4;
+                const uint32_t vo = vo0 + e * (kPoolPlanes * nsubs * 16u);
                 const uint32_t so = (uint32_t)j * pstep * 16u;
-                const int32_t rb = row_wave0 + 4 * (int32_t)g4 + p * 32;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), pr, vo, so, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, b), pr, vo, so + nsubs * 16u, 0);
-                __builtin_amdgcn_raw_buffer_store_b32((uint32_t)rb, pr, vo, so + nsubs * 32u, 0);
+                __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(rb0 + p * 32), pr, vo, so + nsubs * 32u, 0);
             }
         }
     }
@@ -145,15 +144,14 @@ __device__ __forceinline__ void filter_admit(const f32x4 (&lo)[kT16ColBlocks], c
 template <bool NOSTORE>
 __device__ __forceinline__ void filter_pair(const f32x4 (&lo)[kT16ColBlocks], const f32x4 (&hi)[kT16ColBlocks], int p,
                                             const float (&tau)[kT16ColBlocks], uint32_t& curp, uint32_t pbase_u, uint32_t pstep,
-                                            uint32_t nsubs, uint4* __restrict__ pool, int32_t row_wave0) {
+                                            uint32_t nsubs, uint4* __restrict__ pool, uint32_t vo0, int32_t rb0) {
     float m[kT16ColBlocks];
     max8x2_raw(lo[0], hi[0], lo[1], hi[1], m[0], m[1]);
     max8x2_raw(lo[2], hi[2], lo[3], hi[3], m[2], m[3]);
-    filter_admit<NOSTORE>(lo, hi, p, m, tau, curp, pbase_u, pstep, nsubs, pool, row_wave0);
+    filter_admit<NOSTORE>(lo, hi, p, m, tau, curp, pbase_u, pstep, nsubs, pool, vo0, rb0);
 }
 
-// VAR (ablation builds): 1 no epilogue at all, 8 no record stores, 16 tau = +inf (fast path only), 256 no deferral of the slab-load
-// burst around the filter.
+// VAR (ablation builds): 1 no filter at all, 8 no record stores, 16 tau = +inf (fast path only), 128 program order not pinned.
 // qg_log2: log2 of the number of query blocks an XCD works on concurrently (8 for large batches; 1/2/4 for few
 // query blocks, so that all 256 workgroups stream index rows even for a single query block).
 template <int VAR>
@@ -248,16 +246,10 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
         for (int j = 0; j < kT16ColBlocks; ++j) b[0][j] = *(const bf16x8_t*)(b_w + j * 1024);
     }
     int64_t s = 0;
-    bool defer_burst = false;     // (uniform) the slab being multiplied is the last of a tile that a fused-filter slab follows
     int32_t epi_row_wave0 = 0;    // (uniform) first row of the wave's block of the tile whose filter is pending
     // MODE 0: a slab inside a tile.  MODE 1: the first slab of a tile (its MFMAs take C = 0 instead of a cleared accumulator).
-    // MODE 2 (ablation VAR & 4096, the default until the A/B of profiles/r03_t16_standalone.txt): the first slab of a later tile, FUSED
-    // with the threshold filter of the tile just finished: the filter reads a pair of row
-    // blocks and the C = 0 MFMAs of the new tile overwrite it, so the matrix pipe works while the VALU filters (the filter alone
-    // leaves the matrix pipe idle: all waves run it at the same time).  All six pairs are filtered before row block 9 (pairs 4 and 5
-    // together at row block 8: their accumulators are only overwritten at blocks 8..11), and the slab-load burst that the previous slab
-    // DEFERRED is issued right after them, before the slab barrier: the filter's pool stores do not queue behind 40 LDS-DMA pieces in
-    // the CU's texture-address FIFO while the matrix pipe waits for the wave, and the barrier's counted vmcnt still sees whole slabs.
+    // (Until the A/B of profiles/r03_t16_standalone.txt the filter of a finished tile was FUSED into the first slab of the next one —
+    // MODE 2, with the slab-load burst deferred around it; that code is in the history, commit 7a1f30d.)
     auto slab = [&](auto mode_tag, auto cur_tag) {
         constexpr int MODE = decltype(mode_tag)::value;
         constexpr int CUR = decltype(cur_tag)::value;
@@ -276,38 +268,21 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
                 wait_vmcnt<2 * Geo::kLoads>();                       // slab s+1 has landed (this thread's part) ...
                 __builtin_amdgcn_s_barrier();                        // ... and everybody else's
             }
-            if (MODE == 2 && !(VAR & 1) && (!(VAR & 512) || wm == 0)) {   // (VAR & 512, ablation: only one wave of each SIMD filters)
-                if (i == 0 || (!(VAR & 32) && (i == 2 || i == 4 || i == 6))) {   // (VAR & 32, ablation: pair 0 only)
-                    filter_pair<(VAR & 8) != 0>(acc[i], acc[i + 1], i >> 1, tau, curp, pbase_u, pstep, (uint32_t)nsubs, pool, epi_row_wave0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (i == 8 && !(VAR & 32)) {
-                    filter_pair<(VAR & 8) != 0>(acc[8], acc[9], 4, tau, curp, pbase_u, pstep, (uint32_t)nsubs, pool, epi_row_wave0);
-                    filter_pair<(VAR & 8) != 0>(acc[10], acc[11], 5, tau, curp, pbase_u, pstep, (uint32_t)nsubs, pool, epi_row_wave0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
 #pragma unroll
             for (int j = 0; j < kT16ColBlocks; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i % 3], b[CUR][j], MODE == 0 ? acc[i][j] : z, 0, 0, 0);
             a[i % 3] = *(const bf16x8_t*)(i + 3 < kT16RowBlocks ? a_cur + (i + 3) * 1024 : a_nxt + (i + 3 - kT16RowBlocks) * 1024);
             if (i >= 9) b[CUR ^ 1][i - 9] = *(const bf16x8_t*)(b_nxt + (i - 9) * 1024);
             if (i == 11) b[CUR ^ 1][3] = *(const bf16x8_t*)(b_nxt + 3 * 1024);
-            if (MODE == 2 && i == 8 && !(VAR & 256) && (!(VAR & 1) || (VAR & 1024))) {
-                __builtin_amdgcn_sched_barrier(0);
-                issue();   // the burst the previous slab deferred
-            }
             if (!(VAR & 128)) __builtin_amdgcn_sched_barrier(0);   // program order pinned after every row block (VAR & 128: left to the scheduler, +0.35 ms)
         }
         __builtin_amdgcn_sched_barrier(0);
         ++s;
-        // the stage slab s-1 vacated at its barrier takes slab s+3 — unless the fused filter of the next slab wants the FIFO first
-        if (!defer_burst) issue();
+        issue();   // the stage this slab vacated at its barrier takes the slab four ahead
         __builtin_amdgcn_sched_barrier(0);
     };
     using M0 = std::integral_constant<int, 0>;
     using M1 = std::integral_constant<int, 1>;
-    using M2 = std::integral_constant<int, 2>;
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
     // (the B double buffer alternates with the slab parity.  A tile has an EVEN number of slabs — the row stride is a multiple of 64
@@ -342,10 +317,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
             slab(M0{}, C1{});
             slab(M0{}, C0{});
         }
-        constexpr bool kFused = (VAR & 4096) != 0;   // ablation: the filter fused into the next tile's first slab (MODE 2), see above
-        defer_burst = kFused && !(VAR & 256) && (!(VAR & 1) || (VAR & 1024)) && jt + 1 < ntile_total;   // (uniform) see MODE 2
         slab(M0{}, C1{});
-        defer_burst = false;
         // tile jt is complete in acc
         const int64_t trow = row0 + (int64_t)c_t * Geo::kBM;
         epi_row_wave0 = (int32_t)trow + wm * 192;
@@ -355,27 +327,27 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
             ++c_q;
         }
         const bool more = jt + 1 < ntile_total;
-        if (!(VAR & 1) && !(kFused && more)) {
+        if (!(VAR & 1)) {
             // the filter of the finished tile, on its own: all eight waves run it at the same time and the matrix pipe idles meanwhile
-            // (~0.6 us per tile without admissions, 0.24 ms per pass).  Hiding it in the next tile's first slab (MODE 2, variant 4096) is
-            // not faster: 10.93-10.97 vs 10.97-10.99 ms per pass in this build, and 0.4 ms SLOWER in the build before the tile loop was
-            // restructured (profiles/r03_t16_standalone.txt, r03_final_variants.txt) — the simple form is the default.
+            // (~0.6 us per tile without admissions, 0.24 ms per pass).  Hiding it in the next tile's first slab was not faster in the
+            // final build and 0.4 ms SLOWER in the one before (profiles/r03_t16_standalone.txt, r03_final_variants.txt).
             filter_hazard_cover();
+            const uint32_t ln = lane_now();
+            const uint32_t g4 = (ln >> 4) & 3u;
+            const uint32_t vo0 = ((ln & 15u) * (pstep >> 4) + g4) << 4;      // byte offset of entry 0 of the lane's sub-pool (column block 0)
+            const int32_t rb0 = epi_row_wave0 + 4 * (int32_t)g4;             // first of the lane's rows in row block 0 of the tile
 #pragma unroll
             for (int p = 0; p < kT16RowBlocks / 2; ++p)
-                filter_pair<(VAR & 8) != 0>(acc[2 * p], acc[2 * p + 1], p, tau, curp, pbase_u, pstep, (uint32_t)nsubs, pool, epi_row_wave0);
+                filter_pair<(VAR & 8) != 0>(acc[2 * p], acc[2 * p + 1], p, tau, curp, pbase_u, pstep, (uint32_t)nsubs, pool, vo0, rb0);
             __builtin_amdgcn_sched_barrier(0);
-        } else if ((VAR & 1) && !more) {
+        } else if (!more) {
 #pragma unroll
             for (int i = 0; i < kT16RowBlocks; ++i)
 #pragma unroll
                 for (int j = 0; j < kT16ColBlocks; ++j) asm volatile("" ::"v"(acc[i][j]));
         }
         if (more) {
-            if (kFused)
-                slab(M2{}, C0{});           // filter of tile jt fused with the first slab of tile jt + 1
-            else
-                slab(M1{}, C0{});
+            slab(M1{}, C0{});
             if (c_q != cur_q) {             // (uniform) the stream moves on to the next query group
                 store_counts(cur_q);
                 cur_q = c_q;
@@ -414,7 +386,7 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
 #ifdef LDOT_ABLATION
     // Ablation builds only (python -m lightningdot_amd.build --ablation -> libldot_ablation.so; tools/ab.sh): LDOT_DEBUG_VARIANT selects
     // a profiling variant of the kernel.  Results are meaningless under most of them, so the product library does not contain this hook.
-    //   16 tau = +inf (filter fast path only), 17 no filter at all, 8 no record stores, 4096 the filter fused into the next tile's first slab
+    //   16 tau = +inf (filter fast path only), 17 no filter at all, 8 no record stores, 128 program order not pinned
     static int variant = -1;
     if (variant < 0) {
         const char* e = getenv("LDOT_DEBUG_VARIANT");
@@ -424,13 +396,6 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     if (variant == 17) rk = score_filter_t16_kernel<17>;
     if (variant == 8) rk = score_filter_t16_kernel<8>;
     if (variant == 128) rk = score_filter_t16_kernel<128>;    // row blocks NOT pinned in program order (the scheduler sinks the fragment loads)
-    // the filter fused into the next tile's first slab (the default until the stand-alone filter measured 0.4 ms faster):
-    if (variant == 4096) rk = score_filter_t16_kernel<4096>;
-    if (variant == 4112) rk = score_filter_t16_kernel<4112>;  // ... with tau = +inf
-    if (variant == 4352) rk = score_filter_t16_kernel<4352>;  // ... without the deferral of the slab-load burst
-    if (variant == 4624) rk = score_filter_t16_kernel<4624>;  // ... tau = +inf, only the wm = 0 waves filter
-    if (variant == 4144) rk = score_filter_t16_kernel<4144>;  // ... tau = +inf, only pair 0 filtered
-    if (variant == 1041 + 4096) rk = score_filter_t16_kernel<1041 + 4096>;  // no epilogue, but the slab-load burst deferred as if there were a fused one
     LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<6>::kLds));
 #else
     static bool attr_set[kAttrDevices];
