@@ -566,11 +566,11 @@ struct DirectOut {
     int64_t ldqf = 0;   // ... their row stride = the number of columns the kernels read (d, or dpad for zero-padded rows)
 };
 
-// <= 16 queries over one scan chunk: everything after the scan is ONE launch (narrow_finish_kernel)
+// <= 64 queries over one scan chunk: everything after the scan is ONE launch (narrow_finish_kernel, one workgroup per query)
 static bool narrow_one_launch(const ldot_index* ix, int64_t nq, int kp) {
     int sh, nruns;
     narrow_plan(ix->ntotal, kp, &sh, &nruns);
-    return nq <= 16 && ix->ntotal <= ((int64_t)1 << 22) && nruns <= 2048 && kp <= 512;
+    return nq <= kNarrowMaxQueries && ix->ntotal <= ((int64_t)1 << 22) && nruns <= 2048 && kp <= 512;
 }
 
 static int narrow_search(ldot_index* ix, int64_t nq, int kp, hipStream_t st, const DirectOut* direct = nullptr) {
@@ -580,21 +580,23 @@ static int narrow_search(ldot_index* ix, int64_t nq, int kp, hipStream_t st, con
     if ((rc = narrow_buffers(ix, kNarrowMaxQueries, kNarrowMaxRuns, st))) return rc;
     uint32_t* M = (uint32_t*)ix->w_nmax.p;
     uint32_t* tk = (uint32_t*)ix->w_ntau.p;
-    // <= 16 queries over one scan chunk: everything after the scan is ONE launch (narrow_finish_kernel: threshold, collect, top-k', exact
-    // re-score, final order, output) instead of threshold + collect + final + re-score kernels — 38 -> ~12 us on the GPU for one query
+    // <= 64 queries over one scan chunk: everything after the scan is ONE launch (narrow_finish_kernel, a workgroup per query: threshold,
+    // collect, top-k', exact re-score, final order, output) instead of threshold + collect + final + re-score kernels — 38 -> ~12 us on the
+    // GPU for one query
     {
         int sh, nruns;
         narrow_plan(ix->ntotal, kp, &sh, &nruns);
         if (narrow_one_launch(ix, nq, kp)) {
             const int64_t nrows = ix->ntotal, nrows_pad = round_up(nrows, 16);
             const float* qf = direct ? direct->qf32 : nullptr;   // (not staged: see DirectOut)
-            if ((rc = ix->w_S.ensure((size_t)16 * nrows_pad * sizeof(float)))) return rc;
+            const int qgroups = nq <= 16 ? 1 : nq <= 32 ? 2 : 4;   // S in 1-KiB tiles of 16 queries x 16 rows
+            if ((rc = ix->w_S.ensure((size_t)qgroups * 16 * nrows_pad * sizeof(float)))) return rc;
             prof_begin(ix, st, 2.0 * nq * nrows * ix->d, (double)nrows * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * nrows * 4);
             rc = launch_score_narrow(ix->w_q16b.p, ix->x16b, ix->ld16(), 0, nrows, (float*)ix->w_S.p, nrows_pad, (int)nq, M,
                                      kNarrowMaxRuns, sh, 1, st, qf, qf ? direct->ldqf : 0, qf ? (int)direct->ldqf : 0);
             prof_end(ix, st);
             if (rc) return rc;
-            if ((rc = launch_narrow_finish((const float*)ix->w_S.p, 1, nrows_pad, M, kNarrowMaxRuns, nruns, 16 << sh, nrows, (int)nq,
+            if ((rc = launch_narrow_finish((const float*)ix->w_S.p, qgroups, nrows_pad, M, kNarrowMaxRuns, nruns, 16 << sh, nrows, (int)nq,
                                            qf ? qf : (const float*)ix->w_q32.p, qf ? direct->ldqf : ix->dpad, ix->x32, ix->dpad, ix->dpad, kp,
                                            direct ? direct->k : std::min(kp, 1), ix->rescore, (float*)ix->w_ls.p, (int32_t*)ix->w_li.p,
                                            (float*)ix->w_tau.p, direct ? direct->scores : nullptr, direct ? direct->labels : nullptr,
@@ -936,7 +938,7 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
     // converts them itself (the recovery of an overflowed search stages them then, stage_unstaged_queries).
     DirectOut direct_q;
     ix->unstaged_q = nullptr;
-    if (narrow && direct && narrow_one_launch(ix, nq, kp) && dtype == LDOT_F32 && mem == LDOT_DEVICE && !normalize && !ix->precision &&
+    if (narrow && direct && nq <= 16 && narrow_one_launch(ix, nq, kp) && dtype == LDOT_F32 && mem == LDOT_DEVICE && !normalize && !ix->precision &&
         (ix->d == ix->dpad || ix->q_prepadded) && ((uintptr_t)queries & 15) == 0) {
         direct_q = *direct;
         direct_q.qf32 = (const float*)queries;

@@ -494,12 +494,12 @@ def test_search_begin_finish_with_floor(L):
 
 
 def test_few_query_search_all_output_routes_agree(L):
-    """<= 16 queries end in ONE kernel after the index scan (narrow_finish_kernel).  Its three uses — results written directly
+    """<= 64 queries end in ONE kernel after the index scan (narrow_finish_kernel; <= 16 fp32 device queries are not even staged).  Its three uses — results written directly
     (device outputs / pinned host outputs), list + threshold only followed by the ordinary re-score (pageable host outputs, the
     begin / finish halves of a sharded search) — and the streaming-selector path (MODE_DENSE) give identical results; 70 000 rows
     = runs of 64 rows, 300 000 rows = runs of 256 rows."""
     import torch
-    for n, nq, k in ((70000, 1, 100), (70000, 16, 10), (300000, 5, 100)):
+    for n, nq, k in ((70000, 1, 100), (70000, 16, 10), (300000, 5, 100), (70000, 17, 100), (150000, 64, 20), (70000, 33, 100)):
         rng = np.random.default_rng(n + nq)
         x = rng.standard_normal((n, 64)).astype(np.float32)
         q, g = planted_queries(x, nq)
