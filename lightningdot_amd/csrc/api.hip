@@ -1214,12 +1214,12 @@ static int lists_search_impl(ldot_index* ix, const void* queries, int64_t nq, in
             // for 16 queries, but 0.115 vs 0.106 ms for ONE query — its scan is a handful of microseconds either way and the bf16 route
             // pays a query conversion and a row gather on top
             const int kpb = candidate_len(ix, k);
-            const bool few = n <= 16 && nruns <= 2048 && (int64_t)run * kpb <= 4096 && kpb <= 512;
-            bool scan16 = few && n >= 8 && ix->precision == 0 && ix->rescore &&
+            const bool few = n <= kNarrowMaxQueries && nruns <= 2048 && (int64_t)run * kpb <= 4096 && kpb <= 512;
+            bool scan16 = few && n >= 8 && n <= 16 && ix->precision == 0 && ix->rescore &&
                           (size_t)ix->dpad / 32 * 1024 + (size_t)(nprobe + 1) * 12 + 8 <= 64 * 1024;
 #ifdef LDOT_ABLATION
             if (getenv("LDOT_DEBUG_IVF_FP32")) scan16 = false;   // (A/B: the exact fp32 list scan under the same finish kernel)
-            if (getenv("LDOT_DEBUG_IVF_BF16")) scan16 = few && ix->precision == 0 && ix->rescore;
+            if (getenv("LDOT_DEBUG_IVF_BF16")) scan16 = few && n <= 16 && ix->precision == 0 && ix->rescore;
 #endif
             if (scan16) {
                 if ((rc = ix->w_q16b.ensure((size_t)round_up(n, 16) * ix->ld16() * 2))) return rc;
