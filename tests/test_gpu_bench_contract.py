@@ -1,0 +1,43 @@
+"""The measurement contract of bench.py (one JSON line on stdout with `roofline` and `cpu_baseline`), exercised at a small size."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *args], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]          # ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_headline_line_has_the_contract_fields():
+    d = _run('--rows', '131072', '--queries', '1024', '--steps', '3', '--warmup', '1', '--cpu-sample-queries', '16')
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+                'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in d, key
+    assert d['metric'] == 'queries/sec' and d['unit'] == 'queries/s' and d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 1
+    assert d['higher_is_better'] is True and d['vs_baseline'] is None and d['dtype'] == 'bf16' and 'synthetic' in d['data']
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    assert abs(d['value'] - 1024 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6      # whole-job throughput of the timed steps
+    r = d['roofline']
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 2500.0
+    assert 0.0 < r['frac'] < 1.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    assert r['kernel_ms_per_step'] <= d['ms_per_step']                                   # the dominant kernels ran inside the timed region
+    c = d['cpu_baseline']
+    assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == 'queries/s' and c['sample']
+    assert d['recall@1'] == 1.0 and d['overflowed_queries'] == 0
+
+
+def test_serving_line_reports_an_hbm_roofline():
+    d = _run('--workload', 'serving', '--rows', '200000', '--steps', '10', '--warmup', '2', '--no-cpu-baseline')
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and 0.0 < r['frac'] < 1.0
+    assert d['config']['workload'] and d['ms_per_step'] > 0
