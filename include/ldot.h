@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDOT_ABI_VERSION 2
+#define LDOT_ABI_VERSION 3
 
 /* status codes */
 #define LDOT_OK 0
@@ -122,6 +122,20 @@ int ldot_index_search_begin(ldot_index_t* ix, const void* queries, int64_t nq, i
                             float* tau_out, void* stream);
 int ldot_index_search_finish(ldot_index_t* ix, const float* floor, float* out_scores, int64_t* out_labels, int out_mem,
                              void* stream);
+/* _begin in two steps, so that the shards of a row-sharded index agree on thresholds BEFORE their candidate pass instead of after it
+ * (each shard then admits ~1/parts of the candidates, and its pass is one or two kernel launches instead of four; the single
+ * index.search of dvl/indexer/faiss_indexers.py:82-87 / its callers dvl/trainer.py:167,170 are what is being sharded):
+ *   _warmup  ingests the queries, scores them against the first few thousand rows of THIS shard and writes two numbers per query to
+ *            stat_out [2*nq] (device): stat_out[q] = the k'-th best warm-up score (-inf if there was no warm-up: small shards and
+ *            small batches take one-pass paths), stat_out[nq+q] = MINUS the ceil(k'/parts)-th best (+inf if not available).
+ *   the caller all-reduces stat_out with MAX over the `parts` shards.  max(stat[q], -stat[nq+q]) is then a lower bound of the GLOBAL
+ *            k'-th best score: some shard has k' rows at or above the first term, every shard has ceil(k'/parts) rows at or above
+ *            the second.
+ *   _scan    (stat_in = the reduced array, or NULL = no exchange) runs the candidate pass from that threshold and fills tau_out like
+ *            _begin does; _finish follows as before.  _begin = _warmup(parts = 1) + _scan(NULL). */
+int ldot_index_search_warmup(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k, int parts,
+                             float* stat_out, void* stream);
+int ldot_index_search_scan(ldot_index_t* ix, const float* stat_in, float* tau_out, void* stream);
 /* Approximate search — stands where the reference selects faiss.IndexHNSWFlat (dvl/indexer/faiss_indexers.py:90-154, `--hnsw_index`).
  * The index rows are stored sorted by inverted list (the caller clusters them and adds them in list order): list l = rows
  * [list_offsets[l], list_offsets[l+1]).  Every query is scored EXACTLY (fp32) against the rows of its nprobe lists probes[q][0..nprobe)

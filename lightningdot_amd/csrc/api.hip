@@ -127,6 +127,10 @@ struct ldot_index {
     // a search in two halves (ldot_index_search_begin / _finish): what _finish needs to know
     int64_t pend_nq = 0;
     int pend_k = 0, pend_kp = 0;
+    // ... or in three (ldot_index_search_warmup / _scan / _finish, the sharded search): what _scan needs to know.  split_path: 0 none
+    // pending, 1 narrow search, 2 dense scan, 3 fused scan whose warm-up has run
+    int split_path = 0, split_parts = 1;
+    int cur_parts = 1;   // shards of the search in progress (1 = plain search): sizes the warm-up of a fused scan, fused_warm_rows
 };
 
 static int index_reserve(ldot_index* ix, int64_t rows, hipStream_t st) {
@@ -711,8 +715,17 @@ static int fused_pools(ldot_index* ix, int64_t nq_pad, hipStream_t st) {
     return LDOT_OK;
 }
 
-static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_pad, int kp, hipStream_t st) {
-    int rc;   // (q0 is a multiple of 256: whole 16-row blocks of the query shadow)
+// Thresholds the shards of a sharded search agree on after their warm-ups (max over the shards of the k'-th best, min of the
+// ceil(k'/parts)-th best: ldot.h) are worth fewer scanned rows than parts x warm: the minimum over `parts` noisy order statistics sits
+// ~1.4 sigma low (measured: 640 admitted records per query where k' x 120904 / 32768 = 472 were expected, tools/shard_floor.py).  The
+// pool bound of a launch on agreed thresholds counts them at 70 % and allows an expectation of 3 records per sub-pool instead of 4 (the
+// bound IS the active limit there: P(Poisson(3) > 16) ~ 1e-8 per sub-pool against 4e-7 at 4, times 2.6 M sub-pools per search; an
+// overflow costs the flagged queries one more launch).  Measured at 8 x 125 000 rows: 2.5 records per sub-pool, one launch per shard.
+constexpr int64_t kAgreedWorthPct = 70, kAgreedFill = 3;
+constexpr int64_t kWarmSelectFastCols = 5120;   // the warm-up's select keeps a row in registers up to here (select_dense_runs_kernel)
+
+// rows of the dense warm-up of a fused scan
+static int64_t fused_warm_rows(const ldot_index* ix, int64_t nq, int64_t nq_pad, int kp) {
     // Pool sizing rule: a launch over `len` rows after `r` scanned rows admits ~kp*len/r candidates per query,
     // spread over nsubs lane-private sub-pools of kPoolCap records.  Keeping the expectation <= kPoolCap / 4 per sub-pool
     // (16 records, expectation 4: overflow probability ~1e-6 per sub-pool and launch WHERE THIS BOUND IS THE ACTIVE ONE, i.e. for k' in the
@@ -728,8 +741,33 @@ static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_p
     // few queries (serving): launches and selects cost more than dense rows -> warm up over just enough rows for ONE fused launch
     // to cover the rest within the pool bound (len <= r * kFill * nsubs / kp)
     if (nq <= 64) warm = std::max(warm, round_up(ix->ntotal * kp / (kp + kFill * nsubs) + 1, 256));
-    warm = std::min(ix->ntotal, warm);
-    if ((rc = dense_scan_all(ix, nq, 0, warm, kp, (float*)ix->w_tau.p, nq <= 64, st, q0))) return rc;
+    // sharded search: thresholds agreed after the warm-ups of `parts` shards are worth ~kAgreedWorthPct of parts x warm scanned rows
+    // (fused_rest_chunk); a warm-up long enough for ONE launch to cover the rest of the shard within the pool bound saves a launch and
+    // a pool select — as long as the warm-up's select stays on its fast path (dense rows cost ~10x fused ones, and the streaming select
+    // of a longer warm-up 3x the register one: 211 vs 71 us at 10 000 queries, profiles/r04_shard_timeline_*.txt)
+    if (ix->cur_parts > 1 && nq > 64) {
+        const int64_t per_row = kAgreedWorthPct * ix->cur_parts * kAgreedFill * nsubs / (100 * kp);   // rows one launch may cover per warm-up row
+        warm = std::max(warm, std::min<int64_t>(std::max(warm, kWarmSelectFastCols), round_up(ix->ntotal / (per_row + 1) + 1, 256)));
+    }
+    return std::min(ix->ntotal, warm);
+}
+
+static int fused_warm_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_pad, int kp, hipStream_t st) {
+    // (q0 is a multiple of 256: whole 16-row blocks of the query shadow)
+    const int64_t warm = fused_warm_rows(ix, nq, nq_pad, kp);
+    return dense_scan_all(ix, nq, 0, warm, kp, (float*)ix->w_tau.p, nq <= 64, st, q0);
+}
+
+// the fused launches after the warm-up.  parts > 1 (sharded search): the thresholds were raised to a bound the `parts` ranks agreed on
+// after their warm-ups (ldot_index_search_scan) — it is worth about parts x warm scanned rows, so the pool bound allows that much longer
+// launches, and one long launch on it beats two that each pay a pool select.
+static int fused_rest_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_pad, int kp, int parts, hipStream_t st) {
+    int rc;
+    constexpr int64_t kFill = kPoolCap / 4;
+    const int64_t bm = fused_tile_rows();
+    const int qg = fused_query_group(nq_pad);
+    const int64_t nslices = 256 / qg, nsubs = kPoolSubsPerSlice * nslices;
+    const int64_t warm = fused_warm_rows(ix, nq, nq_pad, kp);
     if (warm >= ix->ntotal) return LDOT_OK;
     if ((rc = fused_pools(ix, nq_pad, st))) return rc;
     // (the pad queries' thresholds are +inf since init_lists: they never produce candidates)
@@ -738,10 +776,14 @@ static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_p
 #ifdef LDOT_ABLATION
     if (const char* e = getenv("LDOT_DEBUG_FEWGROWTH")) few_growth = atoll(e);
 #endif
-    const int64_t growth = nq_pad <= kBM ? std::max<int64_t>(ix->growth_pct, few_growth) : ix->growth_pct;
+    int64_t growth = nq_pad <= kBM ? std::max<int64_t>(ix->growth_pct, few_growth) : ix->growth_pct;
+    if (parts > 1) growth = std::max<int64_t>(growth, kFewBlockGrowthPct);
+    const int64_t r_agreed = parts > 1 ? warm * parts * kAgreedWorthPct / 100 : 0;   // what the agreed thresholds are worth, in scanned rows
     int64_t r = warm;
     while (r < ix->ntotal) {
-        int64_t len = std::min<int64_t>(r * growth / 100, r * kFill * nsubs / kp);
+        const bool agreed = r_agreed > r;
+        const int64_t r_eff = agreed ? r_agreed : r;
+        int64_t len = std::min<int64_t>(r_eff * growth / 100, r_eff * (agreed ? kAgreedFill : kFill) * nsubs / kp);
         len = std::max<int64_t>(len, bm * nslices);
         // whole tiles for every row slice (a launch is as slow as its busiest slice); rounding DOWN keeps the pool bound
         len = len / (bm * nslices) * (bm * nslices);
@@ -764,23 +806,34 @@ static int fused_scan_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_p
 
 // Enqueues the whole fused scan WITHOUT synchronising: whether a lane-private pool overflowed (adversarial row orders) is
 // summarised in w_over_sum; fused_overflow_check() fetches it (4 bytes into pinned memory) when the caller has to wait anyway.
-static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStream_t st) {
+// phase 0: the whole scan; 1: set-up + the dense warm-ups only; 2: the fused launches of a scan whose phase 1 has run (sharded search:
+// the ranks exchange thresholds in between, ldot_index_search_warmup / _scan)
+static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStream_t st, int phase = 0, int parts = 1) {
     int rc;
-    const size_t over_bytes = (size_t)nq_pad * 4;
-    const bool fresh_flags = over_bytes > ix->w_over.bytes;
-    if ((rc = ix->w_over.ensure(over_bytes))) return rc;
-    if ((rc = ix->w_over_sum.ensure(16))) return rc;
-    if ((rc = ix->w_qcnt.ensure((size_t)nq_pad * 4))) return rc;
-    LDOT_HIP_CHECK(hipMemsetAsync(ix->w_qcnt.p, 0, (size_t)nq_pad * 4, st));
-    ix->qcnt_n = nq;
-    if (!ix->h_over_sum) LDOT_HIP_CHECK(hipHostMalloc((void**)&ix->h_over_sum, 16));
-    if (fresh_flags || !ix->flags_clean) LDOT_HIP_CHECK(hipMemsetAsync(ix->w_over.p, 0, ix->w_over.bytes, st));
-    LDOT_HIP_CHECK(hipMemsetAsync(ix->w_over_sum.p, 0, 16, st));
-    ix->flags_clean = false;
+    if (phase != 2) {
+        const size_t over_bytes = (size_t)nq_pad * 4;
+        const bool fresh_flags = over_bytes > ix->w_over.bytes;
+        if ((rc = ix->w_over.ensure(over_bytes))) return rc;
+        if ((rc = ix->w_over_sum.ensure(16))) return rc;
+        if ((rc = ix->w_qcnt.ensure((size_t)nq_pad * 4))) return rc;
+        LDOT_HIP_CHECK(hipMemsetAsync(ix->w_qcnt.p, 0, (size_t)nq_pad * 4, st));
+        ix->qcnt_n = nq;
+        if (!ix->h_over_sum) LDOT_HIP_CHECK(hipHostMalloc((void**)&ix->h_over_sum, 16));
+        if (fresh_flags || !ix->flags_clean) LDOT_HIP_CHECK(hipMemsetAsync(ix->w_over.p, 0, ix->w_over.bytes, st));
+        LDOT_HIP_CHECK(hipMemsetAsync(ix->w_over_sum.p, 0, 16, st));
+        ix->flags_clean = false;
+    }
     for (int64_t q0 = 0; q0 < nq; q0 += kFusedQueryChunk) {
         const int64_t nqc = std::min(kFusedQueryChunk, nq - q0);
-        if ((rc = fused_scan_chunk(ix, q0, nqc, round_up(nqc, kBM), kp, st))) return rc;
+        if (phase != 2 && (rc = fused_warm_chunk(ix, q0, nqc, round_up(nqc, kBM), kp, st))) return rc;
+        if (phase == 0 && (rc = fused_rest_chunk(ix, q0, nqc, round_up(nqc, kBM), kp, 1, st))) return rc;
     }
+    if (phase == 1) return LDOT_OK;
+    if (phase == 2)
+        for (int64_t q0 = 0; q0 < nq; q0 += kFusedQueryChunk) {
+            const int64_t nqc = std::min(kFusedQueryChunk, nq - q0);
+            if ((rc = fused_rest_chunk(ix, q0, nqc, round_up(nqc, kBM), kp, parts, st))) return rc;
+        }
     LDOT_HIP_CHECK(hipMemcpyAsync(ix->h_over_sum, ix->w_over_sum.p, 4, hipMemcpyDeviceToHost, st));
     ix->overflow_pending = true;
     return LDOT_OK;
@@ -851,7 +904,9 @@ static int redo_flagged(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipS
                                   (uint16_t*)c.q16b.p, 0, st)))
         return rc;
     if ((rc = launch_init_lists((float*)c.ls.p, (int32_t*)c.li.p, nf_pad * kp, (float*)c.tau.p, nf, nf_pad, st))) return rc;
-    if (level == 0 && (rc = launch_gather_tau((const float*)ix->w_tau.p, didx, nf, (float*)c.tau.p, st))) return rc;
+    if (level == 0 && (rc = launch_gather_tau((const float*)ix->w_tau.p, didx, nf, (const float*)ix->w_q32.p, ix->dpad, ix->d,
+                                              (const float*)ix->w_norm.p, (float*)c.tau.p, st)))
+        return rc;
     // the compact batch stands where the search's operands and lists are, for the duration of its own scan
     auto swap_in = [&]() {
         std::swap(ix->w_q32, c.q32);
@@ -892,8 +947,11 @@ static int stage_unstaged_queries(ldot_index* ix, int64_t nq, hipStream_t st) {
 }
 
 // defer_check: enqueue a fused scan speculatively and leave the overflow check to the caller's own synchronisation point
+// warm_only (ldot_index_search_warmup): stop after the local warm-up of a fused scan, leave the statistics the ranks exchange in
+// stat_out (2 * nq floats) and remember the path in split_path; ldot_index_search_scan continues from there
 static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k,
-                             float* tau_out, bool defer_check, hipStream_t st, const DirectOut* direct = nullptr) {
+                             float* tau_out, bool defer_check, hipStream_t st, const DirectOut* direct = nullptr,
+                             bool warm_only = false, int parts = 1, float* stat_out = nullptr) {
     LDOT_REQUIRE(ix != nullptr, LDOT_EINVAL, "index is NULL");
     LDOT_REQUIRE(nq >= 0, LDOT_EINVAL, "negative query count");
     LDOT_REQUIRE(k >= 1 && k <= kMaxK, LDOT_EINVAL, "k must be in [1, %d] (got %d)", kMaxK, k);
@@ -905,6 +963,8 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
     ix->overflow_narrow = 0;
     ix->qcnt_n = 0;
     ix->unproven_n = 0;
+    ix->split_path = 0;
+    ix->cur_parts = warm_only ? parts : 1;
     if (nq == 0) return LDOT_OK;
     LDOT_REQUIRE(queries != nullptr, LDOT_EINVAL, "NULL buffer");
     DeviceGuard guard(ix->device);
@@ -952,6 +1012,27 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
     }
     if (!narrow && (rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, tau, nq, nq_pad, st))) return rc;
 
+    if (warm_only) {
+        const bool fused = !narrow && ix->ntotal > 0 &&
+                           (ix->mode == LDOT_MODE_FUSED ||
+                            (ix->mode == LDOT_MODE_AUTO && !(nq <= 16 && narrow_ok(ix, nq)) &&
+                             (ix->ntotal >= 32768 || (ix->ntotal >= 16384 && nq >= 16384))));
+        if (fused) {
+            if ((rc = fused_scan(ix, nq, nq_pad, kp, st, 1))) return rc;
+            // m = ceil(k' / parts): every rank has m rows at or above its own m-th best warm-up score
+            if ((rc = launch_list_stats((const float*)ix->w_ls.p, (const int32_t*)ix->w_li.p, kp, nq, (kp + parts - 1) / parts, tau, stat_out, st)))
+                return rc;
+        } else if ((rc = launch_neutral_stats(nq, stat_out, st))) {
+            return rc;
+        }
+        if (mem == LDOT_HOST) LDOT_HIP_CHECK(hipStreamSynchronize(st));   // the staging buffer is reused by the next call
+        ix->split_path = narrow ? 1 : fused ? 3 : 2;
+        ix->split_parts = parts;
+        ix->pend_nq = nq;
+        ix->pend_k = k;
+        ix->pend_kp = kp;
+        return LDOT_OK;
+    }
     if (narrow) {
         if ((rc = narrow_search(ix, nq, kp, st, direct))) return rc;
         if (!defer_check) {
@@ -991,6 +1072,43 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
 int ldot_index_search_begin(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k,
                             float* tau_out, void* stream) {
     return search_begin_impl(ix, queries, nq, dtype, mem, normalize, k, tau_out, false, (hipStream_t)stream);
+}
+
+// A sharded search in three steps (lightningdot_amd/sharded.py): every rank warms up on its own shard and publishes two numbers per
+// query; one all-reduce(MAX) later every rank continues with the threshold all of them can vouch for.
+int ldot_index_search_warmup(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k, int parts,
+                             float* stat_out, void* stream) {
+    LDOT_REQUIRE(parts >= 1 && parts <= 65536, LDOT_EINVAL, "bad number of parts %d", parts);
+    if (nq > 0) LDOT_REQUIRE(stat_out != nullptr, LDOT_EINVAL, "NULL buffer");
+    return search_begin_impl(ix, queries, nq, dtype, mem, normalize, k, nullptr, false, (hipStream_t)stream, nullptr, true, parts, stat_out);
+}
+
+int ldot_index_search_scan(ldot_index_t* ix, const float* stat_in, float* tau_out, void* stream) {
+    LDOT_REQUIRE(ix != nullptr, LDOT_EINVAL, "index is NULL");
+    const int64_t nq = ix->pend_nq;
+    if (nq == 0) return LDOT_OK;
+    LDOT_REQUIRE(ix->split_path != 0, LDOT_EINVAL, "ldot_index_search_scan without a pending ldot_index_search_warmup");
+    const int path = ix->split_path, kp = ix->pend_kp;
+    ix->split_path = 0;
+    DeviceGuard guard(ix->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nq_pad = round_up(nq, kBM);
+    float* tau = (float*)ix->w_tau.p;
+    int rc;
+    if (path == 1) {   // (the small-batch and small-index paths do not use the agreed thresholds: their scan is one pass anyway)
+        if ((rc = narrow_search(ix, nq, kp, st, nullptr))) return rc;
+        LDOT_HIP_CHECK(hipStreamSynchronize(st));
+        if (fused_overflow_check(ix) && (rc = redo_flagged(ix, nq, nq_pad, kp, st))) return rc;
+    } else if (path == 2) {
+        if (ix->ntotal > 0 && (rc = dense_scan_all(ix, nq, 0, ix->ntotal, kp, tau, true, st))) return rc;
+    } else {
+        if (stat_in && (rc = launch_apply_stats(nq, stat_in, tau, st))) return rc;
+        if ((rc = fused_scan(ix, nq, nq_pad, kp, st, 2, stat_in ? ix->split_parts : 1))) return rc;
+        LDOT_HIP_CHECK(hipStreamSynchronize(st));
+        if (fused_overflow_check(ix) && (rc = redo_flagged(ix, nq, nq_pad, kp, st))) return rc;
+    }
+    if (tau_out) LDOT_HIP_CHECK(hipMemcpyAsync(tau_out, tau, (size_t)nq * 4, hipMemcpyDeviceToDevice, st));
+    return LDOT_OK;
 }
 
 // re-score + output
@@ -1321,6 +1439,16 @@ int ldot_ivf_search(ldot_index_t* ix, ldot_index_t* coarse, const void* queries,
     // The coarse search of a few queries ends in a kernel that writes the probes itself; its synchronisation + buffer-full check is
     // DEFERRED to the synchronisation of the list stage (one host round trip per search instead of two).  A full coarse buffer
     // (thousands of centroids with equal scores) is then found after the fact and the search repeated the plain way.
+    // (the chain state lives in the coarse index for the duration of this call; the guard clears it on EVERY way out, so that an error
+    // return can not leave a later plain search of the coarse handle reading its queries with the padded stride)
+    struct ChainGuard {
+        ldot_index_t* c;
+        ~ChainGuard() {
+            c->q_prepadded = false;
+            c->chain_defer_sync = false;
+            c->pend_nq = 0;
+        }
+    } chain_guard{coarse};
     coarse->q_prepadded = true;
     coarse->chain_defer_sync = true;
     rc = ldot_index_search(coarse, ix->w_laug.p, nq, LDOT_F32, LDOT_DEVICE, 0, nprobe, (float*)ix->w_lprobe_s.p,
@@ -1341,8 +1469,6 @@ int ldot_ivf_search(ldot_index_t* ix, ldot_index_t* coarse, const void* queries,
                                        nprobe, k, out_scores, out_labels, out_mem, st);
         }
     }
-    coarse->pend_nq = 0;
-    coarse->q_prepadded = false;
     return rc;
 }
 

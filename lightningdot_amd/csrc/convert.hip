@@ -191,13 +191,23 @@ __global__ __launch_bounds__(256) void gather_rows_f32_kernel(const float* __res
 }
 
 // thresholds of the flagged queries, lowered by a hair: the threshold is the k'-th best score the FIRST pass saw, partly computed by
-// another kernel (the dense warm-up) whose fp32 summation order may differ in the last bits from the filter kernel's
+// another kernel (the dense warm-up) whose fp32 summation order may differ in the last bits from the filter kernel's.  That difference
+// scales with sum |q_i x_i| <= |q| max|x|, not with the threshold itself (which may be near 0 for centred data), so the slack is
+// 1e-5 |q| max|x| (max|x| = the index's running row-norm maximum), and never less than 1e-5 |t|.
 __global__ __launch_bounds__(256) void gather_tau_kernel(const float* __restrict__ tau, const int32_t* __restrict__ idx, int64_t n,
-                                                         float* __restrict__ dst) {
+                                                         const float* __restrict__ q32, int64_t ldq, int d,
+                                                         const float* __restrict__ xnorm_max, float* __restrict__ dst) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float t = tau[idx[i]];
-    dst[i] = t - fabsf(t) * 1e-5f - 1e-30f;
+    float slack = fabsf(t) * 1e-5f;
+    if (q32 && xnorm_max) {
+        const float* q = q32 + (int64_t)idx[i] * ldq;
+        float s = 0.f;
+        for (int c = 0; c < d; ++c) s = fmaf(q[c], q[c], s);
+        slack = fmaxf(slack, 1e-5f * sqrtf(s) * xnorm_max[0]);
+    }
+    dst[i] = t - slack - 1e-30f;
 }
 
 __global__ __launch_bounds__(256) void scatter_lists_kernel(const float* __restrict__ cs, const int32_t* __restrict__ ci,
@@ -221,9 +231,10 @@ int launch_gather_rows_f32(const float* src, int64_t ld, const int32_t* idx, int
     return LDOT_OK;
 }
 
-int launch_gather_tau(const float* tau, const int32_t* idx, int64_t n, float* dst, hipStream_t st) {
+int launch_gather_tau(const float* tau, const int32_t* idx, int64_t n, const float* q32, int64_t ldq, int d, const float* xnorm_max,
+                      float* dst, hipStream_t st) {
     if (n <= 0) return LDOT_OK;
-    hipLaunchKernelGGL(gather_tau_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tau, idx, n, dst);
+    hipLaunchKernelGGL(gather_tau_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tau, idx, n, q32, ldq, d, xnorm_max, dst);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

@@ -37,7 +37,8 @@ int launch_convert_rows(const void* src, int dtype, int64_t ld_src, int64_t n, i
 // recovery of overflowed queries: dst row i = src row idx[i] (rows [n, n_pad) zero); their thresholds (lowered by a hair); and the
 // way back for finished lists: list / threshold of compact query i -> query idx[i]
 int launch_gather_rows_f32(const float* src, int64_t ld, const int32_t* idx, int64_t n, int64_t n_pad, float* dst, hipStream_t st);
-int launch_gather_tau(const float* tau, const int32_t* idx, int64_t n, float* dst, hipStream_t st);
+int launch_gather_tau(const float* tau, const int32_t* idx, int64_t n, const float* q32, int64_t ldq, int d, const float* xnorm_max,
+                      float* dst, hipStream_t st);
 int launch_scatter_lists(const float* cs, const int32_t* ci, const float* ctau, const int32_t* idx, int64_t n, int kp, float* ls,
                          int32_t* li, float* tau, hipStream_t st);
 
@@ -120,6 +121,10 @@ int launch_select_pools_parts(const uint4* pool, const int32_t* pool_cnt, int ns
                               const float* tau, float* part_s, int64_t* part_l, int32_t* overflow_flags, int32_t* over_sum,
                               int32_t* qcnt, hipStream_t st);
 // parts [nparts][nq][kp] + the running list -> the new running list (+ tau), in place
+// sharded search: warm-up statistics (stat[q] = threshold, stat[nq + q] = -(m-th best)), their neutral element, and the agreed floor
+int launch_list_stats(const float* list_s, const int32_t* list_i, int kp, int64_t nq, int m, const float* tau, float* stat, hipStream_t st);
+int launch_neutral_stats(int64_t nq, float* stat, hipStream_t st);
+int launch_apply_stats(int64_t nq, const float* stat, float* tau, hipStream_t st);
 int launch_merge_parts_into_lists(const float* part_s, const int64_t* part_l, int nparts, int64_t nq, int kp, float* list_s,
                                   int32_t* list_i, float* tau, hipStream_t st);
 // generic merge of explicit candidate lists: cand_[sl] is [nq][ncand] (labels int64, -1 = empty) -> [nq][k_out]

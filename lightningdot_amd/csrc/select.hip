@@ -100,7 +100,7 @@ struct Selector {
         sel_sync();
         if (n >= kp) compact();   // sorts the kp keys (cheap) and sets tau = the kp-th best
     }
-    __device__ inline void finish(float* ls, int32_t* li, float* tau_out) {
+    __device__ inline void finish(float* ls, int32_t* li, float* tau_out, bool keep_max = false) {
         compact();
         const int n = *count;
         for (int e = threadIdx.x; e < kp; e += blockDim.x) {
@@ -113,8 +113,10 @@ struct Selector {
                 li[e] = -1;
             }
         }
-        if (tau_out && threadIdx.x == 0)
-            *tau_out = (n >= kp) ? desc_key_to_float((uint32_t)(keys[kp - 1] >> 32)) : -INFINITY;
+        if (tau_out && threadIdx.x == 0) {
+            const float t = (n >= kp) ? desc_key_to_float((uint32_t)(keys[kp - 1] >> 32)) : -INFINITY;
+            *tau_out = keep_max ? fmaxf(*tau_out, t) : t;
+        }
     }
 };
 
@@ -256,7 +258,9 @@ struct WaveSelector {
         wave_sync();
         tau = (n >= kp) ? worst : kEmptyKey;
     }
-    __device__ inline void finish(float* ls, int32_t* li, float* tau_out) {
+    // keep_max: the query's threshold never goes DOWN (the pool selects of a sharded search start from a threshold the ranks agreed on,
+    // which may exceed this shard's own k'-th best score: ldot_index_search_scan)
+    __device__ inline void finish(float* ls, int32_t* li, float* tau_out, bool keep_max = false) {
         compact();
         for (int e = (threadIdx.x & 63); e < kp; e += 64) {
             if (e < n) {
@@ -268,7 +272,10 @@ struct WaveSelector {
                 li[e] = -1;
             }
         }
-        if (tau_out && (threadIdx.x & 63) == 0) *tau_out = (n >= kp) ? desc_key_to_float((uint32_t)(tau >> 32)) : -INFINITY;
+        if (tau_out && (threadIdx.x & 63) == 0) {
+            const float t = (n >= kp) ? desc_key_to_float((uint32_t)(tau >> 32)) : -INFINITY;
+            *tau_out = keep_max ? fmaxf(*tau_out, t) : t;
+        }
     }
 };
 
@@ -794,6 +801,13 @@ __global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(con
     // counters of the first 64 sub-pools are requested before the list so that both round trips overlap
     int cn = lane < nsubs ? cnt[lane] : 0;
     if (!(dbg & 4)) sel.load_list(ls, li);
+    if (tau) {   // a threshold above the list's own worst key (sharded search: agreed between the ranks) filters the pushes
+        const float t0 = tau[q];
+        if (t0 > -INFINITY) {
+            const uint64_t fk = make_key(t0, 0xfffffffeu);
+            if (fk < sel.tau) sel.tau = fk;
+        }
+    }
     bool over = false;
     int nrec = 0;   // records of this query in this launch (statistics)
     // entry-major, plane-major pools: plane p of level e of all sub-pools is one contiguous run of 16-byte words -> coalesced
@@ -812,7 +826,7 @@ __global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(con
     }
     const bool any_over = __any(over);
     if (dbg & 2) return;
-    sel.finish(ls, li, tau ? tau + q : nullptr);
+    sel.finish(ls, li, tau ? tau + q : nullptr, true);
     if (qcnt) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) nrec += __shfl_xor(nrec, o);
@@ -953,7 +967,7 @@ __global__ __launch_bounds__(kSelThreads) void select_pools_block_kernel(const u
                 }
         }
     }
-    sel.finish(ls, li, tau ? tau + q : nullptr);
+    sel.finish(ls, li, tau ? tau + q : nullptr, true);
     if (qcnt) {
         __shared__ int nrec_sh;
         if (threadIdx.x == 0) nrec_sh = 0;
@@ -1033,7 +1047,7 @@ __global__ __launch_bounds__(kSelThreads) void merge_parts_into_lists_kernel(con
         }
         sel.push(key, valid);
     }
-    sel.finish(ls, li, tau ? tau + q : nullptr);
+    sel.finish(ls, li, tau ? tau + q : nullptr, true);   // (thresholds are initialised by init_lists and never go down)
 }
 
 // The same merge for at most 4096 keys in all ((nparts + 1) * kp): every key lives in a register (16 per thread), the k'-th best
@@ -1121,7 +1135,7 @@ __global__ __launch_bounds__(kSelThreads) void merge_parts_regs_kernel(const flo
             li[e] = -1;
         }
     }
-    if (tau && tid == 0) tau[q] = n >= kp ? desc_key_to_float(t) : -INFINITY;
+    if (tau && tid == 0) tau[q] = fmaxf(tau[q], n >= kp ? desc_key_to_float(t) : -INFINITY);   // (never down: see WaveSelector::finish)
 }
 
 int launch_merge_parts_into_lists(const float* part_s, const int64_t* part_l, int nparts, int64_t nq, int kp, float* list_s,
@@ -1260,6 +1274,88 @@ int launch_select_pools_parts(const uint4* pool, const int32_t* pool_cnt, int ns
     LDOT_REQUIRE(cap <= WaveSelector::kRegKeys * 64 && nsubs % G == 0, LDOT_EINVAL, "select_pools_parts: unsupported shape");
     hipLaunchKernelGGL(select_pools_parts_kernel, dim3((unsigned)nq, (unsigned)G), dim3(kPoolSelThreads), (size_t)cap * 8, st, pool,
                        (int32_t*)pool_cnt, nsubs, nq, G, row_end, kp, cap, tau, part_s, part_l, overflow_flags, over_sum, qcnt);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+// ---- sharded search: what the ranks exchange after the local warm-up (ldot_index_search_warmup / _scan) ---------------------------
+// stat[q] = the query's threshold (its k'-th best warm-up score), stat[nq + q] = MINUS its m-th best warm-up score, m = ceil(k'/parts)
+// (+inf when the list holds fewer than m rows).  After an all-reduce(MAX) over the ranks, max(stat[q], -stat[nq + q]) is a lower bound
+// of the GLOBAL k'-th best score: some rank has k' rows at or above the first term, and EVERY rank has m rows at or above the
+// second (parts * m >= k').  One wave per query; the list is a set of <= 64 * R keys held in registers, the m-th best by bit search.
+template <int R>
+__global__ __launch_bounds__(256) void list_stats_kernel(const float* __restrict__ ls, const int32_t* __restrict__ li, int kp, int64_t nq,
+                                                         int m, const float* __restrict__ tau, float* __restrict__ stat) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    uint32_t key[R];
+    int nvalid = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int e = r * 64 + lane;
+        const bool valid = e < kp && li[q * kp + e] >= 0;
+        key[r] = valid ? desc_key(ls[q * kp + e]) : 0xffffffffu;
+        nvalid += __popcll(__ballot(valid));
+    }
+    float tm = -INFINITY;
+    if (nvalid >= m) {
+        uint32_t T = 0;   // smallest key with #(keys <= T) >= m  (descending keys: the m-th best score)
+        for (int b = 31; b >= 0; --b) {
+            const uint32_t trial = T | ((1u << b) - 1u);
+            int c = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) c += __popcll(__ballot(key[r] <= trial && key[r] != 0xffffffffu));
+            if (c < m) T |= 1u << b;
+        }
+        tm = desc_key_to_float(T);
+    }
+    if (lane == 0) {
+        stat[q] = tau[q];
+        stat[nq + q] = -tm;
+    }
+}
+
+int launch_list_stats(const float* list_s, const int32_t* list_i, int kp, int64_t nq, int m, const float* tau, float* stat, hipStream_t st) {
+    if (nq <= 0) return LDOT_OK;
+    const dim3 grid((unsigned)((nq + 3) / 4)), block(256);
+    if (kp <= 128)
+        hipLaunchKernelGGL(list_stats_kernel<2>, grid, block, 0, st, list_s, list_i, kp, nq, m, tau, stat);
+    else if (kp <= 256)
+        hipLaunchKernelGGL(list_stats_kernel<4>, grid, block, 0, st, list_s, list_i, kp, nq, m, tau, stat);
+    else if (kp <= 1024)
+        hipLaunchKernelGGL(list_stats_kernel<16>, grid, block, 0, st, list_s, list_i, kp, nq, m, tau, stat);
+    else
+        hipLaunchKernelGGL(list_stats_kernel<48>, grid, block, 0, st, list_s, list_i, kp, nq, m, tau, stat);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+// "no warm-up on this rank": neutral elements of the exchange (a rank without a statistic must not raise anybody's threshold)
+__global__ __launch_bounds__(256) void neutral_stats_kernel(int64_t nq, float* __restrict__ stat) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    stat[q] = -INFINITY;
+    stat[nq + q] = INFINITY;
+}
+
+int launch_neutral_stats(int64_t nq, float* stat, hipStream_t st) {
+    if (nq <= 0) return LDOT_OK;
+    hipLaunchKernelGGL(neutral_stats_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, nq, stat);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+// tau[q] = max(tau[q], stat[q], -stat[nq + q]): the agreed threshold becomes the floor of this shard's candidate pass
+__global__ __launch_bounds__(256) void apply_stats_kernel(int64_t nq, const float* __restrict__ stat, float* __restrict__ tau) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    tau[q] = fmaxf(tau[q], fmaxf(stat[q], -stat[nq + q]));
+}
+
+int launch_apply_stats(int64_t nq, const float* stat, float* tau, hipStream_t st) {
+    if (nq <= 0) return LDOT_OK;
+    hipLaunchKernelGGL(apply_stats_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, nq, stat, tau);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

@@ -212,6 +212,36 @@ class FlatIPIndex:
         self._pending = (nq, int(k), keep.device)
         return tau
 
+    def search_warmup(self, queries, k: int, parts: int):
+        """First step of a sharded search over ``parts`` shards (CUDA tensors): ingests the queries, warms up on this shard and returns
+        the statistics the shards exchange — a float32 CUDA tensor [2, nq] to be all-reduced with MAX (ldot.h: row 0 = the k'-th best
+        warm-up score, row 1 = minus the ceil(k'/parts)-th best; neutral values when this shard takes a one-pass path)."""
+        import torch
+        keep, ptr, nq, dt, mem = _describe(queries, self.d, self.device)
+        if mem != L.DEVICE:
+            raise ValueError('search_warmup expects a CUDA tensor')
+        stat = torch.empty((2, nq), dtype=torch.float32, device=keep.device)
+        L.check(self._lib.ldot_index_search_warmup(self._h, ptr, nq, dt, mem, int(self.normalize), int(k), int(parts),
+                                                   ctypes.c_void_p(stat.data_ptr()), _stream_ptr(self.device)))
+        self._pending = (nq, int(k), keep.device)
+        return stat
+
+    def search_scan(self, stat=None):
+        """Second step: the candidate pass, from the thresholds the shards agreed on (``stat`` = the all-reduced tensor of
+        search_warmup; None = this shard's own).  Returns the thresholds like search_begin does."""
+        import torch
+        if self._pending is None:
+            raise L.LdotError(-5, 'search_scan without a pending search_warmup')
+        nq, _, dev = self._pending
+        tau = torch.empty((nq,), dtype=torch.float32, device=dev)
+        sptr = ctypes.c_void_p(0)
+        if stat is not None:
+            stat = stat.to(device=dev, dtype=torch.float32).contiguous()
+            assert stat.shape == (2, nq)
+            sptr = ctypes.c_void_p(stat.data_ptr())
+        L.check(self._lib.ldot_index_search_scan(self._h, sptr, ctypes.c_void_p(tau.data_ptr()), _stream_ptr(self.device)))
+        return tau
+
     def search_finish(self, floor=None):
         """Second half: re-scores the candidates at or above ``floor`` ([nq] float32 CUDA tensor, e.g. the all-reduce MAX of
         the shards' thresholds; None = all) and returns this shard's partial top-k (scores, labels) as CUDA tensors."""

@@ -53,7 +53,8 @@ def _hip_merge(scores: torch.Tensor, labels: torch.Tensor, k: int, out=None):
 
 class ShardedFlatIndexer:
     def __init__(self, vector_sz: int, group=None, local_search: Optional[Callable] = None,
-                 merge: Optional[Callable] = None, normalize: bool = False, exchange: str = 'all_to_all'):
+                 merge: Optional[Callable] = None, normalize: bool = False, exchange: str = 'all_to_all',
+                 exchange_warmup: bool = True):
         if exchange not in ('all_to_all', 'all_gather'):
             raise ValueError("exchange must be 'all_to_all' or 'all_gather'")
         self.group = group
@@ -61,6 +62,7 @@ class ShardedFlatIndexer:
         self.world = dist.get_world_size(group)
         self.d = vector_sz
         self.exchange = exchange
+        self.exchange_warmup = exchange_warmup   # thresholds agreed after the warm-up (False: only after the candidate pass, as in round 3)
         self._custom = local_search is not None
         self.local = None if self._custom else DenseFlatIndexer(vector_sz, normalize=normalize)
         self._local_search = local_search
@@ -193,6 +195,16 @@ class ShardedFlatIndexer:
         dist.all_gather(bufs, pad.contiguous(), group=self.group)
         return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0), counts
 
+    def _all_reduce_max(self, t: torch.Tensor) -> None:
+        """in-place MAX over the ranks.  RCCL reduces device tensors over xGMI; a backend without device collectives (gloo, the
+        one-GPU test rig) reduces a host copy."""
+        if t.is_cuda and dist.get_backend(self.group) != 'nccl':
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+
     def _all_to_all(self, send: torch.Tensor) -> torch.Tensor:
         """send[r] goes to rank r; returns recv with recv[r] = what rank r sent here.  RCCL moves device tensors over xGMI; a
         backend without device all-to-all (gloo, the one-GPU test rig) exchanges host copies."""
@@ -216,10 +228,19 @@ class ShardedFlatIndexer:
             # candidates on this shard, then ONE small all-reduce (MAX) of the per-query candidate thresholds: at least k'
             # candidates score >= that maximum globally, so every shard re-scores only its candidates at or above it
             # (~k'/G per shard instead of k'): the re-score gather is the largest per-query cost of a shard
-            tau = self.local.index.search_begin(q_all, k)
+            # Round 4: the shards agree on thresholds BEFORE the candidate pass as well — every shard warms up on its first few thousand
+            # rows, one all-reduce(MAX) of two numbers per query turns the warm-ups into a bound worth world x as many rows, and the
+            # candidate pass admits ~1/world of the records (one fused launch + one pool select instead of four of each).
+            ix = self.local.index
+            if self.world > 1 and self.exchange_warmup:
+                stat = ix.search_warmup(q_all, k, self.world)
+                self._all_reduce_max(stat)
+                tau = ix.search_scan(stat)
+            else:
+                tau = ix.search_begin(q_all, k)
             if self.world > 1:
-                dist.all_reduce(tau, op=dist.ReduceOp.MAX, group=self.group)
-            s, l = self.local.index.search_finish(tau)
+                self._all_reduce_max(tau)
+            s, l = ix.search_finish(tau)
         l = torch.where(l >= 0, l + self.offsets[self.rank], l)          # local row -> global row, padding stays -1
         starts = [0]
         for c in counts:

@@ -61,3 +61,98 @@ def test_sharded_search_two_ranks_one_gpu(tmp_path):
     for r in range(world):
         a = np.load(os.path.join(str(tmp_path), f'r{r}.npz'))
         assert_topk_matches(q[qb[r]:qb[r + 1]], x, a['s'], a['l'], k)
+
+
+# ---- round 4: four ranks on one GPU through the FUSED path at the BASELINE shard shapes ------------------------------------------
+# case A: the COCO-5k index of BASELINE configs[2] (25 000 x 768 rows) in 4 UNEQUAL shards (every shard below the fused threshold: the
+#         one-pass paths, neutral warm-up statistics);  case B: 125 000 rows per rank, the shard size of configs[3], where the fused
+#         filter runs and the ranks agree on thresholds after their warm-ups.  Unequal query counts, one rank without a query.
+_CASES = {
+    'coco': dict(bounds=[0, 4000, 11000, 19000, 25000], counts=[300, 0, 500, 224], d=768, k=10),
+    'shard125k': dict(bounds=[0, 125000, 250000, 375000, 500000], counts=[0, 700, 804, 800], d=768, k=100),
+}
+
+
+def _gen_rows(lo, hi, d, seed):
+    """rows [lo, hi) of a clustered synthetic index, generated on the GPU in blocks of 25 000 rows so that any shard layout sees the
+    same data"""
+    import torch
+    out, blk = [], 25000
+    for b in range(lo // blk, (hi + blk - 1) // blk):
+        g = torch.Generator(device='cuda').manual_seed(seed * 1000 + b)
+        rows = torch.randn(blk, d, device='cuda', generator=g)
+        out.append(rows[max(lo, b * blk) - b * blk:min(hi, (b + 1) * blk) - b * blk])
+    return torch.cat(out, 0)
+
+
+def _gen_queries(n, d, seed, rows_total):
+    import torch
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    return torch.randn(n, d, device='cuda', generator=g)
+
+
+def _worker4(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from lightningdot_amd.sharded import ShardedFlatIndexer
+    for ci, (name, c) in enumerate(_CASES.items()):
+        lo, hi = c['bounds'][rank], c['bounds'][rank + 1]
+        qs = np.cumsum([0] + c['counts'])
+        sh = ShardedFlatIndexer(c['d'])
+        sh.index_local_shard(list(range(lo, hi)), _gen_rows(lo, hi, c['d'], 11 + ci))
+        q = _gen_queries(int(qs[-1]), c['d'], 500 + ci, c['bounds'][-1])[qs[rank]:qs[rank + 1]].contiguous()
+        sh.exchange_warmup = False            # round 3's exchange (thresholds agreed only after the candidate pass), for comparison
+        s0, l0 = sh.search(q, c['k'])
+        st0 = sh.local.index.last_stats()
+        sh.exchange_warmup = True
+        s, l = sh.search(q, c['k'])
+        st = sh.local.index.last_stats()
+        assert torch.equal(s, s0) and torch.equal(l, l0)
+        np.savez(os.path.join(out_dir, f'{name}_r{rank}.npz'), s=s.cpu().numpy(), l=l.cpu().numpy(),
+                 fused_pairs=st['fused_pairs'], fused_candidates=st['fused_candidates'], overflowed=st['overflowed_queries'],
+                 fused_candidates_local=st0['fused_candidates'])
+        del sh
+        torch.cuda.empty_cache()
+        dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_search_four_ranks_fused_path_baseline_shapes(tmp_path):
+    import torch
+    import torch.multiprocessing as mp
+    from lightningdot_amd import _lib
+    from lightningdot_amd.indexer import FlatIPIndex
+    _lib.require_gpu()
+    world, port = 4, _free_port()
+    mp.spawn(_worker4, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for ci, (name, c) in enumerate(_CASES.items()):
+        n = c['bounds'][-1]
+        ix = FlatIPIndex(c['d'])
+        ix.add(_gen_rows(0, n, c['d'], 11 + ci))
+        qs = np.cumsum([0] + c['counts'])
+        q = _gen_queries(int(qs[-1]), c['d'], 500 + ci, n)
+        es, el = ix.search_tensors(q, c['k'])
+        es, el = es.cpu().numpy(), el.cpu().numpy()
+        cand = []
+        for r in range(world):
+            a = np.load(os.path.join(str(tmp_path), f'{name}_r{r}.npz'))
+            assert a['s'].shape == (c['counts'][r], c['k'])
+            # the same rows in the same order with bit-identical fp32 scores as the unsharded search of the whole index
+            np.testing.assert_array_equal(a['l'], el[qs[r]:qs[r + 1]])
+            np.testing.assert_array_equal(a['s'], es[qs[r]:qs[r + 1]])
+            assert int(a['overflowed']) == 0
+            if name == 'shard125k':   # every rank scanned its shard with the fused filter (all queries x its rows beyond the warm-up)
+                assert int(a['fused_pairs']) > 0.9 * int(qs[-1]) * 125000
+                cand.append((int(a['fused_candidates']), int(a['fused_candidates_local'])))
+            else:
+                assert int(a['fused_pairs']) == 0
+        if name == 'shard125k':
+            # thresholds agreed after the warm-ups: a shard admits clearly fewer records than on its own warm-up thresholds
+            assert all(a < 0.8 * b for a, b in cand), cand
+        del ix
+        torch.cuda.empty_cache()

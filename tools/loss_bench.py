@@ -14,7 +14,8 @@ def timeit(fn, n=50):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
 
 torch.manual_seed(99)
-for n1, n2, d in ((512, 512, 768), (512, 1536, 768), (64, 512, 768), (4096, 4096, 768)):
+ONCE = '--once' in sys.argv     # (under rocprofv3: few repetitions, and a per-call kernel timeline of the last one)
+for n1, n2, d in ((512, 512, 768), (512, 1536, 768)) if ONCE else ((512, 512, 768), (512, 1536, 768), (64, 512, 768), (4096, 4096, 768)):
     q = torch.randn(n1, d, device='cuda', requires_grad=True)
     c = torch.randn(n2, d, device='cuda', requires_grad=True)
     pos = list(range(n1))

@@ -472,6 +472,322 @@ static void run16(const char* name, const char* src, int64_t region, float* sink
     fflush(stdout);
 }
 
+
+// ---- round 4: one wave per SIMD on v_mfma_f32_16x16x32_bf16 -------------------------------------------------------------------------
+// 96 accumulator tiles of 16 x 16 per wave (384 registers): tiles 0..63 accumulate in AGPRs, 64..95 in VGPRs (inline asm, as in W1 above).
+template <bool AGPR>
+__device__ __forceinline__ void mfma16_asm(f32x4& acc, const bf16x8_t& a, const bf16x8_t& b) {
+    if (AGPR)
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    else
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
+// T16W1: 256 threads = 4 waves (2 x 2), wave tile 192 x 128 = 12 x 8 tiles, both operands through the LDS ring (the 40 KiB stage of the
+// product kernel).  LDS fragment bytes per MFMA: (12 + 8) KiB / 96 = 213 B against 341 B for the 192 x 64 wave tile at two waves per SIMD.
+// FEED 1 ds_read stream only, 2 + direct-to-LDS burst (10 pieces per wave and slab), 5 the pieces spread between the row blocks.
+template <int FEED>
+__global__ __launch_bounds__(256, 1) void ceiling16w1_kernel(const char* __restrict__ src, int64_t src_region, int nslab,
+                                                             float* __restrict__ sink, uint64_t* __restrict__ ticks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int xcd = blockIdx.x & 7;
+    const char* base = src + (int64_t)xcd * src_region;
+    __amdgpu_buffer_rsrc_t rs = ring_make_rsrc_n(base, src_region);
+    const int vo = lane * 16;
+    int issued = 0, so = 0;
+    const int so_end = (int)src_region - kStage;
+    auto issue_piece = [&](const int j) {
+        char* st = smem + (issued & 3) * kStage;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (rg_lptr_t)(st + (j * 4 + wave) * 1024), 16, vo, so + (j * 4 + wave) * 1024, 0, 0);
+        if (j == 9) {
+            ++issued;
+            so += kStage;
+            if (so >= so_end) so = 0;
+        }
+    };
+    auto issue = [&]() {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) issue_piece(j);
+    };
+    issue();
+    issue();
+    issue();
+    issue();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int row = lane & 15;
+    const int foff = row * 64 + (((lane >> 4) ^ ((row >> 1) & 3)) << 4);
+    f32x4 acc[12][8];
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8_t a[3], b[2][8];
+    const char* a_w0 = smem + wm * (192 * 64) + foff;
+    const char* b_w0 = smem + kAOp + wn * (128 * 64) + foff;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a[i] = *(const bf16x8_t*)(a_w0 + i * 1024);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[0][j] = b[1][j] = *(const bf16x8_t*)(b_w0 + j * 1024);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" ::: "memory");
+    const uint64_t t0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+    auto slab = [&](auto cur_tag, const char* st0, const char* st1) {
+        constexpr int cur = decltype(cur_tag)::value;
+        const char* a_cur = st0 + wm * (192 * 64) + foff;
+        const char* a_nxt = st1 + wm * (192 * 64) + foff;
+        const char* b_nxt = st1 + kAOp + wn * (128 * 64) + foff;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            if (i == 9) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (FEED == 2 || FEED == 5) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (i * 8 + j < 64)
+                    mfma16_asm<true>(acc[i][j], a[i % 3], b[cur][j]);
+                else
+                    mfma16_asm<false>(acc[i][j], a[i % 3], b[cur][j]);
+            }
+            a[i % 3] = *(const bf16x8_t*)((i + 3 < 12 ? a_cur + (i + 3) * 1024 : a_nxt + (i + 3 - 12) * 1024));
+            if (i >= 9) {   // the 8 B fragments of the next slab during the last three row blocks
+                b[cur ^ 1][(i - 9) * 3] = *(const bf16x8_t*)(b_nxt + ((i - 9) * 3) * 1024);
+                b[cur ^ 1][(i - 9) * 3 + 1] = *(const bf16x8_t*)(b_nxt + ((i - 9) * 3 + 1) * 1024);
+                if (i < 11) b[cur ^ 1][(i - 9) * 3 + 2] = *(const bf16x8_t*)(b_nxt + ((i - 9) * 3 + 2) * 1024);
+            }
+            if (FEED == 5) {   // 10 pieces: after row blocks 9, 10, 11 and 0..6 of the next slab
+                if (i >= 9) issue_piece(i - 9);
+                if (i <= 6) issue_piece(3 + i);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (FEED == 2) issue();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+#pragma unroll 1
+    for (int s = 0; s + 1 < nslab; s += 2) {
+        slab(C0{}, smem + (s & 3) * kStage, smem + ((s + 1) & 3) * kStage);
+        slab(C1{}, smem + ((s + 1) & 3) * kStage, smem + ((s + 2) & 3) * kStage);
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    const uint64_t t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f32x4 v = acc[i][j];
+            if (i * 8 + j < 64) asm volatile("" : "+a"(v));
+            sum += v[0] + v[1] + v[2] + v[3];
+        }
+    if (sum == 12345.678f) sink[blockIdx.x * blockDim.x + threadIdx.x] = sum;
+    if (threadIdx.x == 0) {
+        ticks[blockIdx.x * 2] = t1 - t0;
+        ticks[blockIdx.x * 2 + 1] = r1 - r0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// AG: 256 threads = 4 waves stacked along the index rows, wave tile 96 rows x 256 queries = 6 x 16 tiles.  Only the QUERY slab (16 KiB)
+// goes through the LDS (ring of 4 x 16 KiB, 4 direct-to-LDS pieces per wave and slab) and every wave reads all 16 of its fragments; the
+// wave's own 6 row fragments come from L2 straight into VGPRs (a 1-KiB block of the blocked layout IS one MFMA operand), PD slabs ahead.
+// Per slab and CU: 64 KiB of LDS fragment reads (128 in the product kernel), 16 KiB of LDS-DMA (40), 24 KiB of global -> VGPR loads (0).
+// FEED 1: query fragment stream only (row fragments stay in registers), 2: + query LDS-DMA, 3: + row fragments from global memory (all).
+template <int FEED, int PD>
+__global__ __launch_bounds__(256, 1) void ceilingAG_kernel(const char* __restrict__ src, int64_t src_region, int nslab,
+                                                           float* __restrict__ sink, uint64_t* __restrict__ ticks) {
+    constexpr int kBStage = 16 * 1024;
+    constexpr int NB = PD + 1;          // row-fragment buffers: the current slab + PD in flight
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xcd = blockIdx.x & 7;
+    const char* base = src + (int64_t)xcd * src_region;
+    __amdgpu_buffer_rsrc_t rs = ring_make_rsrc_n(base, src_region);
+    const int vo = lane * 16;
+    const int so_end = (int)src_region - kStage;
+    int b_issued = 0, so_b = 0, so_a = 0;
+    auto issue_b = [&]() {   // the 16 KiB query slab: bytes [24 KiB, 40 KiB) of the source slab
+        char* st = smem + (b_issued & 3) * kBStage;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (rg_lptr_t)(st + (p * 4 + wave) * 1024), 16, vo, so_b + kAOp + (p * 4 + wave) * 1024, 0, 0);
+        ++b_issued;
+        so_b += kStage;
+        if (so_b >= so_end) so_b = 0;
+    };
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    auto load_a = [&](bf16x8_t (&dst)[6]) {   // the wave's 6 row fragments: bytes [wave * 6 KiB, + 6 KiB) of the source slab
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            dst[i] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so_a + (wave * 6 + i) * 1024, 0));
+        so_a += kStage;
+        if (so_a >= so_end) so_a = 0;
+    };
+    // FEED 4: the same loads spread over the slab, one VMEM instruction at a time: row fragment i after query block i (i < 6), the
+    // fourth piece of the query slab in flight after block 6, the first three pieces of the next one after blocks 13, 14, 15
+    auto issue_b_piece = [&](const int p) {
+        char* st = smem + (b_issued & 3) * kBStage;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (rg_lptr_t)(st + (p * 4 + wave) * 1024), 16, vo, so_b + kAOp + (p * 4 + wave) * 1024, 0, 0);
+        if (p == 3) {
+            ++b_issued;
+            so_b += kStage;
+            if (so_b >= so_end) so_b = 0;
+        }
+    };
+    auto load_a_one = [&](bf16x8_t (&dst)[6], const int i) {
+        dst[i] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so_a + (wave * 6 + i) * 1024, 0));
+        if (i == 5) {
+            so_a += kStage;
+            if (so_a >= so_end) so_a = 0;
+        }
+    };
+    bf16x8_t a[NB][6], bq[4];
+    if (FEED >= 2) {
+        issue_b();
+        issue_b();
+        issue_b();
+        if (FEED == 4) {
+            issue_b_piece(0);
+            issue_b_piece(1);
+            issue_b_piece(2);
+        } else {
+            issue_b();
+        }
+    } else {
+        for (int i = threadIdx.x; i < 4 * kBStage / 16; i += 256) ((uint4*)smem)[i] = ((const uint4*)base)[i];
+    }
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        if (FEED >= 3 ? n < PD : true) load_a(a[n]);   // (FEED 3: slabs 0 .. PD-1 are in flight when the loop starts; slab s + PD is issued in slab s)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int row = lane & 15;
+    const int foff = row * 64 + (((lane >> 4) ^ ((row >> 1) & 3)) << 4);
+    f32x4 acc[16][6];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bq[j] = *(const bf16x8_t*)(smem + foff + j * 1024);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" ::: "memory");
+    const uint64_t t0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+    // one slab: query fragment j (ring of four register quads, refilled four fragments = 24 MFMAs ahead) against the wave's six row fragments
+    auto slab = [&](auto n_tag, const char* st0, const char* st1) {
+        constexpr int n = decltype(n_tag)::value;
+        if (FEED == 3) load_a(a[(n + PD) % NB]);     // = the buffer of the slab that just finished
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j == 13) {   // fragments 0..15 of this stage are in registers or consumed; fragment reads of the next stage start below
+                __builtin_amdgcn_sched_barrier(0);
+                if (FEED >= 2) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // query slab s + 1 must have landed: issued after it were (slab s - 1:) 6 row loads + 4 pieces, (slab s:) 6 row loads
+                    // (+ slab s - 2: 6 row loads + 4 pieces) = 26 younger loads may stay in flight
+                    if (FEED == 3)
+                        asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+                    else if (FEED == 4)   // younger than the last piece of query slab s + 1: 3 + (6 + 1 + 3) + (6 + 1) loads
+                        asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                    else
+                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    if (FEED != 4) issue_b();   // the stage everybody has left takes the slab four ahead
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                if (j * 6 + i < 64)
+                    mfma16_asm<true>(acc[j][i], a[n][i], bq[j & 3]);
+                else
+                    mfma16_asm<false>(acc[j][i], a[n][i], bq[j & 3]);
+            }
+            bq[j & 3] = *(const bf16x8_t*)((j + 4 < 16 ? st0 + (j + 4) * 1024 : st1 + (j + 4 - 16) * 1024) + foff);
+            if (FEED == 4) {
+                if (j < 6) load_a_one(a[(n + PD) % NB], j);
+                if (j == 6) issue_b_piece(3);
+                if (j >= 13) issue_b_piece(j - 13);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    static_assert(NB == 3, "PD = 2: three slabs ahead needs 96 + 128 + 16 VGPRs and spills");
+#pragma unroll 1
+    for (int s = 0; s + 12 <= nslab; s += 12) {   // 12 slabs per trip: a multiple of both NB and the 4 ring stages
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const char* st0 = smem + (u & 3) * kBStage;
+            const char* st1 = smem + ((u + 1) & 3) * kBStage;
+            if (u % NB == 0) slab(std::integral_constant<int, 0>{}, st0, st1);
+            if (u % NB == 1) slab(std::integral_constant<int, 1>{}, st0, st1);
+            if (u % NB == 2) slab(std::integral_constant<int, 2>{}, st0, st1);
+            if (NB == 4 && u % NB == 3) slab(std::integral_constant<int, 3 % NB>{}, st0, st1);
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    const uint64_t t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            f32x4 v = acc[j][i];
+            if (j * 6 + i < 64) asm volatile("" : "+a"(v));
+            sum += v[0] + v[1] + v[2] + v[3];
+        }
+    if (sum == 12345.678f) sink[blockIdx.x * blockDim.x + threadIdx.x] = sum;
+    if (threadIdx.x == 0) {
+        ticks[blockIdx.x * 2] = t1 - t0;
+        ticks[blockIdx.x * 2 + 1] = r1 - r0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// common driver of the one-wave-per-SIMD 16x16x32 kernels (256 threads, the same 384 x 256 x 32 slab per CU)
+template <typename K>
+static void run_w1(K k, int lds_bytes, int slab_multiple, const char* name, const char* src, int64_t region, float* sink, uint64_t* ticks,
+                   double target_ms) {
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const double flop_per_slab = 2.0 * 384 * 256 * 32 * 256;
+    int nslab = 1200;
+    float ms = 0.f;
+    for (int it = 0; it < 4; ++it) {
+        nslab = nslab / slab_multiple * slab_multiple;
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k, dim3(256), dim3(256), lds_bytes, 0, src, region, nslab, sink, ticks);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (it == 0) nslab = (int)(nslab * target_ms / ms);
+        if (it >= 2) {
+            std::vector<uint64_t> h(512);
+            CK(hipMemcpy(h.data(), ticks, 512 * 8, hipMemcpyDeviceToHost));
+            double cyc = 0, real = 0;
+            for (int i = 0; i < 256; ++i) {
+                cyc += (double)h[2 * i];
+                real += (double)h[2 * i + 1];
+            }
+            const double tf = flop_per_slab * nslab / (ms * 1e-3) / 1e12;
+            // 96 MFMAs of 16 cycles per slab and wave, 1 wave per SIMD
+            printf("%-34s %8.3f ms  %8.1f TFLOP/s  %5.1f %% of 2500  clock %.3f GHz  pipe-issue %.1f %%\n", name, ms, tf, tf / 25.0,
+                   cyc / real * 0.1, 96.0 * nslab * 16.0 / (cyc / 256) * 100);
+        }
+    }
+    fflush(stdout);
+}
+
 int main(int argc, char** argv) {
     const double target_ms = argc > 1 ? atof(argv[1]) : 12.0;
     const int64_t region = 16ll << 20;   // per XCD window of the slab source (8 x 16 MiB: Infinity-Cache resident)
@@ -490,6 +806,15 @@ int main(int argc, char** argv) {
     CK(hipMemset(zsrc, 0, region * 8));
     for (int rep = 0; rep < 1; ++rep) {
         printf("---- repetition %d (target %.1f ms per launch) ----\n", rep, target_ms);
+        run_w1(ceiling16w1_kernel<1>, 4 * kStage, 2, "T16W1 mfma+ds_read         random", src, region, sink, ticks, target_ms);
+        run_w1(ceiling16w1_kernel<2>, 4 * kStage, 2, "T16W1 mfma+ds_read+lds-dma random", src, region, sink, ticks, target_ms);
+        run_w1(ceiling16w1_kernel<5>, 4 * kStage, 2, "T16W1 full, dma interleaved random", src, region, sink, ticks, target_ms);
+        run_w1(ceilingAG_kernel<1, 2>, 65536, 12, "AG q ds_read only          random", src, region, sink, ticks, target_ms);
+        run_w1(ceilingAG_kernel<2, 2>, 65536, 12, "AG q ds_read + q lds-dma   random", src, region, sink, ticks, target_ms);
+        run_w1(ceilingAG_kernel<3, 2>, 65536, 12, "AG full, rows 2 slabs ahead random", src, region, sink, ticks, target_ms);
+        run_w1(ceilingAG_kernel<4, 2>, 65536, 12, "AG full, loads spread      random", src, region, sink, ticks, target_ms);
+        run_w1(ceilingAG_kernel<4, 2>, 65536, 12, "AG full, loads spread      zeros", zsrc, region, sink, ticks, target_ms);
+        run_w1(ceilingAG_kernel<3, 2>, 65536, 12, "AG full, rows 2 slabs ahead zeros", zsrc, region, sink, ticks, target_ms);
         run16<1>("T16 mfma+ds_read           random", src, region, sink, ticks, target_ms);
         run16<2>("T16 mfma+ds_read+lds-dma   random", src, region, sink, ticks, target_ms);
         run16<5>("T16 full, dma interleaved  random", src, region, sink, ticks, target_ms);

@@ -1,21 +1,49 @@
 #!/usr/bin/env python3
-"""Per-rank cost of the 8-GPU case on one GPU: 125 000-row shard, 10 000 queries, top-100; re-score with and without
-the global-threshold floor (emulated: a floor that keeps ~k'/8 candidates per query, what the all-reduce(MAX) gives on average)."""
+"""Per-rank cost of the 8-GPU case on one GPU: 125 000-row shard, 10 000 queries, top-100.
+  (a) round 3: candidate pass on the shard's own thresholds, then the re-score above an emulated global floor;
+  (b) round 4: thresholds agreed after the warm-up (ldot_index_search_warmup / _scan).  The other seven ranks are played by seven
+      small indexes that hold only the rows a warm-up touches; their statistics are reduced with MAX exactly like the all-reduce would.
+Results of (b) are compared with a plain search of the shard (labels and scores of the rows at or above the floor)."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lightningdot_amd import _lib as L
 from lightningdot_amd.indexer import FlatIPIndex
 torch.manual_seed(0)
+G, K = 8, 100
 x = torch.randn(125000, 768, device='cuda'); q = torch.randn(10000, 768, device='cuda')
 ix = FlatIPIndex(768); ix.add(x)
-s, l = ix.search_tensors(q, 100)
+others = []
+for r in range(G - 1):
+    o = FlatIPIndex(768); o.set_option(L.OPT_MODE, L.MODE_FUSED); o.add(torch.randn(8192, 768, device='cuda')); others.append(o)
+s, l = ix.search_tensors(q, K)
 floor = s[:, 15].contiguous() - 0.05          # ~16 candidates survive
 def t(fn, n=10):
     fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 def both(fl):
-    ix.search_begin(q, 100); return ix.search_finish(fl)
-print('begin+finish, no floor: %.3f ms' % t(lambda: both(None)))
-print('begin+finish, floor keeping ~16: %.3f ms' % t(lambda: both(floor)))
-s2, l2 = both(floor)
-print('survivors per query: %.1f' % float((l2 >= 0).sum(1).float().mean()))
+    ix.search_begin(q, K); return ix.search_finish(fl)
+print('round 3: begin+finish, no floor: %.3f ms' % t(lambda: both(None)))
+print('round 3: begin+finish, floor keeping ~16: %.3f ms' % t(lambda: both(floor)))
+print('   admitted records per query: %.0f' % (ix.last_stats()['fused_candidates'] / q.shape[0]))
+# the other ranks' warm-up statistics (not timed: they run on their own GPUs)
+stat_o = torch.stack([o.search_warmup(q, K, G) for o in others], 0).amax(0)
+def agreed():
+    stat = ix.search_warmup(q, K, G)
+    stat = torch.maximum(stat, stat_o)          # = all-reduce(MAX)
+    tau = ix.search_scan(stat)
+    return ix.search_finish(torch.maximum(tau, floor))
+print('round 4: warm-up + agreed thresholds + scan + finish (floor keeping ~16): %.3f ms' % t(agreed))
+print('   admitted records per query: %.0f' % (ix.last_stats()['fused_candidates'] / q.shape[0]))
+s2, l2 = agreed()
+print('   survivors per query: %.1f' % float((l2 >= 0).sum(1).float().mean()))
+s3, l3 = both(floor)
+# (b) re-scores above max(its own final threshold, floor): its survivors are a subset of (a)'s, with the same fp32 scores
+m = (l2[:, :, None] == l3[:, None, :]) & (l2[:, :, None] >= 0)
+pos = m.float().argmax(2)
+found = m.any(2)
+same = torch.gather(s3, 1, pos) == s2
+ok = bool((found | (l2 < 0)).all()) and bool((same | (l2 < 0)).all())
+print('   every survivor is one of the round-3 results, with the same fp32 score:', ok)
+top = min(10, int((l2 >= 0).sum(1).min()))
+print('   first %d of every query identical to the plain search:' % top, bool((l2[:, :top] == l[:, :top]).all()) and bool((s2[:, :top] == s[:, :top]).all()))

@@ -1,10 +1,29 @@
+"""One rank of an 8-way sharded search on one GPU, for a kernel timeline (tools/shard_timeline.sh): 125 000-row shard, 10 000 queries.
+argv[1] = rows, argv[2] = 'local' (thresholds exchanged only after the candidate pass) | 'agreed' (after the warm-up too; the other
+seven ranks' warm-up statistics come from seven small indexes, reduced with MAX like the all-reduce would)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lightningdot_amd import _lib as L
 from lightningdot_amd.indexer import FlatIPIndex
 torch.manual_seed(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 125000
+mode = sys.argv[2] if len(sys.argv) > 2 else 'local'
+G, K = 8, 100
 x = torch.randn(n, 768, device='cuda'); q = torch.randn(10000, 768, device='cuda')
 ix = FlatIPIndex(768); ix.add(x)
+s, _ = ix.search_tensors(q, K)
+floor = s[:, 15].contiguous() - 0.05
+if mode == 'agreed':
+    others = []
+    for r in range(G - 1):
+        o = FlatIPIndex(768); o.set_option(L.OPT_MODE, L.MODE_FUSED); o.add(torch.randn(8192, 768, device='cuda')); others.append(o)
+    stat_o = torch.stack([o.search_warmup(q, K, G) for o in others], 0).amax(0)
+torch.cuda.synchronize()
 for _ in range(6):
-    ix.search_begin(q, 100); ix.search_finish(None)
+    if mode == 'agreed':
+        stat = torch.maximum(ix.search_warmup(q, K, G), stat_o)
+        tau = ix.search_scan(stat)
+        ix.search_finish(torch.maximum(tau, floor))
+    else:
+        ix.search_begin(q, K); ix.search_finish(floor)
 torch.cuda.synchronize()
