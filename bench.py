@@ -155,7 +155,7 @@ def main():
             return flat.search_into(q_mine, K, host_s, host_l)
     else:
         from lightningdot_amd.sharded import ShardedFlatIndexer
-        sh = ShardedFlatIndexer(D)
+        sh = ShardedFlatIndexer(D, equal_query_counts=(Q % world == 0))   # equal slices: no per-search exchange of the query counts
         sh.local.index.set_option(L.OPT_MODE, mode)
         sh.local.index.set_option(L.OPT_PROFILE, 1)
         if args.split_bf16:

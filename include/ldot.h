@@ -136,6 +136,17 @@ int ldot_index_search_finish(ldot_index_t* ix, const float* floor, float* out_sc
 int ldot_index_search_warmup(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k, int parts,
                              float* stat_out, void* stream);
 int ldot_index_search_scan(ldot_index_t* ix, const float* stat_in, float* tau_out, void* stream);
+/* _finish writing the shard's partial lists straight into the send buffer of the all-to-all that follows (device memory, 16-byte
+ * aligned): block b — one per destination rank, block_bytes apart — holds the lists of the queries [b*block_rows, (b+1)*block_rows):
+ * scores float [block_rows][k] at byte 0, labels int64 [block_rows][k] at byte LDOT_BLOCK_LABELS_OFFSET(block_rows, k); labels are
+ * local rows + label_base (the shard's first global row), LDOT_PAD_LABEL stays.  ldot_merge_topk_blocked merges nparts such blocks
+ * (what the all-to-all delivers: one block per source rank) for the first nq <= block_rows queries; outputs are device pointers
+ * (device memory, or pinned host memory through its device mapping).  No torch op touches the lists between the two kernels. */
+#define LDOT_BLOCK_LABELS_OFFSET(block_rows, k) ((((int64_t)(block_rows) * (k) * 4) + 15) / 16 * 16)
+int ldot_index_search_finish_blocked(ldot_index_t* ix, const float* floor, void* out_blocks, int64_t block_rows, int64_t block_bytes,
+                                     int64_t label_base, void* stream);
+int ldot_merge_topk_blocked(const void* blocks, int nparts, int64_t block_rows, int64_t block_bytes, int64_t nq, int k_in, int k_out,
+                            float* out_scores, int64_t* out_labels, void* stream);
 /* Approximate search — stands where the reference selects faiss.IndexHNSWFlat (dvl/indexer/faiss_indexers.py:90-154, `--hnsw_index`).
  * The index rows are stored sorted by inverted list (the caller clusters them and adds them in list order): list l = rows
  * [list_offsets[l], list_offsets[l+1]).  Every query is scored EXACTLY (fp32) against the rows of its nprobe lists probes[q][0..nprobe)

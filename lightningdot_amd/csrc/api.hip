@@ -1176,6 +1176,30 @@ int ldot_index_search_finish(ldot_index_t* ix, const float* floor, float* out_sc
     return search_finish_impl(ix, floor, out_scores, out_labels, out_mem, false, (hipStream_t)stream);
 }
 
+// _finish of a sharded search, straight into the send buffer of the all-to-all that follows: block b (one per destination rank)
+// receives the partial lists of the queries [b * block_rows, (b + 1) * block_rows), labels already global (+ label_base)
+int ldot_index_search_finish_blocked(ldot_index_t* ix, const float* floor, void* out_blocks, int64_t block_rows, int64_t block_bytes,
+                                     int64_t label_base, void* stream) {
+    LDOT_REQUIRE(ix != nullptr, LDOT_EINVAL, "index is NULL");
+    const int64_t nq = ix->pend_nq;
+    if (nq == 0) return LDOT_OK;
+    const int k = ix->pend_k, kp = ix->pend_kp;
+    LDOT_REQUIRE(out_blocks != nullptr, LDOT_EINVAL, "NULL buffer");
+    const int64_t lab_off = LDOT_BLOCK_LABELS_OFFSET(block_rows, k);
+    LDOT_REQUIRE(block_rows >= 1 && block_bytes % 16 == 0 && block_bytes >= lab_off + block_rows * k * 8 && ((uintptr_t)out_blocks & 15) == 0,
+                 LDOT_EINVAL, "bad block geometry (rows %lld, bytes %lld, k %d)", (long long)block_rows, (long long)block_bytes, k);
+    ix->pend_nq = 0;
+    DeviceGuard guard(ix->device);
+    hipStream_t st = (hipStream_t)stream;
+    const RescoreOut lay{block_rows, block_bytes / 4, block_bytes / 8, label_base};
+    int rc = launch_rescore((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, nq, (const float*)ix->w_ls.p,
+                            (const int32_t*)ix->w_li.p, kp, k, ix->rescore, floor, (float*)out_blocks,
+                            (int64_t*)((char*)out_blocks + lab_off), st, &lay);
+    if (rc) return rc;
+    prof_collect(ix, st);
+    return LDOT_OK;
+}
+
 int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k,
                       float* out_scores, int64_t* out_labels, int out_mem, void* stream) {
     LDOT_REQUIRE(out_mem == LDOT_HOST || out_mem == LDOT_DEVICE, LDOT_EINVAL, "bad memory space");
@@ -1555,6 +1579,20 @@ int ldot_index_load(const char* path, ldot_index_t** out) {
     return LDOT_OK;
 }
 
+// the merge of a sharded search, reading the all-to-all's receive buffer in place: nparts blocks in the layout of
+// ldot_index_search_finish_blocked (one per source rank), of which the first nq (<= block_rows) queries are merged
+int ldot_merge_topk_blocked(const void* blocks, int nparts, int64_t block_rows, int64_t block_bytes, int64_t nq, int k_in, int k_out,
+                            float* out_scores, int64_t* out_labels, void* stream) {
+    LDOT_REQUIRE(blocks && out_scores && out_labels, LDOT_EINVAL, "NULL buffer");
+    LDOT_REQUIRE(nparts >= 1 && k_in >= 1 && k_out >= 1 && k_out <= kMaxKp && nq >= 0 && nq <= block_rows, LDOT_EINVAL, "bad sizes");
+    const int64_t lab_off = LDOT_BLOCK_LABELS_OFFSET(block_rows, k_in);
+    LDOT_REQUIRE(block_bytes % 16 == 0 && block_bytes >= lab_off + block_rows * k_in * 8 && ((uintptr_t)blocks & 15) == 0, LDOT_EINVAL,
+                 "bad block geometry");
+    if (nq == 0) return LDOT_OK;
+    return launch_select_lists((const float*)blocks, (const int64_t*)((const char*)blocks + lab_off), block_bytes / 4, block_bytes / 8, nparts,
+                               k_in, nq, k_out, out_scores, out_labels, (hipStream_t)stream);
+}
+
 int ldot_merge_topk(const float* scores, const int64_t* labels, int nparts, int64_t nq, int k_in, int k_out,
                     float* out_scores, int64_t* out_labels, int mem, void* stream) {
     LDOT_REQUIRE(scores && labels && out_scores && out_labels, LDOT_EINVAL, "NULL buffer");
@@ -1562,7 +1600,7 @@ int ldot_merge_topk(const float* scores, const int64_t* labels, int nparts, int6
     if (nq == 0) return LDOT_OK;
     hipStream_t st = (hipStream_t)stream;
     if (mem == LDOT_DEVICE)
-        return launch_select_lists(scores, labels, nq * k_in, nparts, k_in, nq, k_out, out_scores, out_labels, st);
+        return launch_select_lists(scores, labels, nq * k_in, nq * k_in, nparts, k_in, nq, k_out, out_scores, out_labels, st);
     LDOT_REQUIRE(mem == LDOT_HOST, LDOT_EINVAL, "bad mem");
     const size_t n_in = (size_t)nparts * nq * k_in, n_out = (size_t)nq * k_out;
     // host-side callers: a grow-only per-thread device workspace (released when the thread exits), no hipMalloc/hipFree per call.
@@ -1597,7 +1635,7 @@ int ldot_merge_topk(const float* scores, const int64_t* labels, int nparts, int6
         rc = LDOT_EDEVICE;
     }
     if (!rc)
-        rc = launch_select_lists((const float*)ds, (const int64_t*)dl, nq * k_in, nparts, k_in, nq, k_out, (float*)os,
+        rc = launch_select_lists((const float*)ds, (const int64_t*)dl, nq * k_in, nq * k_in, nparts, k_in, nq, k_out, (float*)os,
                                  (int64_t*)ol, st);
     if (!rc && (hipMemcpyAsync(out_scores, os, n_out * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipMemcpyAsync(out_labels, ol, n_out * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||

@@ -128,13 +128,19 @@ int launch_apply_stats(int64_t nq, const float* stat, float* tau, hipStream_t st
 int launch_merge_parts_into_lists(const float* part_s, const int64_t* part_l, int nparts, int64_t nq, int kp, float* list_s,
                                   int32_t* list_i, float* tau, hipStream_t st);
 // generic merge of explicit candidate lists: cand_[sl] is [nq][ncand] (labels int64, -1 = empty) -> [nq][k_out]
-int launch_select_lists(const float* cand_s, const int64_t* cand_l, int64_t part_stride, int nparts, int k_in,
+int launch_select_lists(const float* cand_s, const int64_t* cand_l, int64_t part_stride, int64_t part_stride_l, int nparts, int k_in,
                         int64_t nq, int k_out, float* out_s, int64_t* out_l, hipStream_t st);
 
 // exact fp32 re-score of the kp candidates of every query, final ordering, top-k output.
+// where the re-score kernel puts a query's final list: dense [nq][k] arrays (block_rows = 0), or blocks of block_rows queries
+// stride_s floats / stride_l int64 apart (the per-destination blocks of a sharded search's send buffer); label_base is added to every valid label
+struct RescoreOut {
+    int64_t block_rows, stride_s, stride_l, label_base;
+};
 int launch_rescore(const float* q32, int64_t ldq, const float* x32, int64_t ldx, int dpad, int64_t nq,
                    const float* list_s, const int32_t* list_i, int kp, int k, int do_rescore, const float* floor,
-                   float* out_s, int64_t* out_l, hipStream_t st);
+                   float* out_s, int64_t* out_l, hipStream_t st,
+                   const RescoreOut* layout = nullptr);
 
 // running maximum of the L2 norms of the rows of a padded fp32 matrix (atomicMax into *out_max, a non-negative float)
 int launch_row_norm_max(const float* x32, int64_t ld, int64_t n, int d, float* out_max, hipStream_t st);

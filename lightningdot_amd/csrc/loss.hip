@@ -6,6 +6,10 @@
 // bound, not MFMA bound, so the 1/16-rate fp32 matrix path costs nothing that matters.
 #include <math.h>
 
+#include <mutex>
+#include <type_traits>
+#include <vector>
+
 #include "kernels.h"
 
 namespace ldot {
@@ -162,6 +166,319 @@ static void sgemm_dispatch(bool ak, bool bk, dim3 grid, hipStream_t st, const fl
                            K, alpha, accumulate, vec);
 }
 
+
+// ---- small problems (the in-batch loss itself: <= 512 x 1536 x 768): direct-operand GEMM ---------------------------------------------
+// The shapes of the loss are latency class (0.4 - 1.2 GFLOP): the 64 x 64 LDS-staged kernel above runs 64 - 192 workgroups through 24
+// barrier-separated slabs and takes 30 - 46 us where the flops are worth 3 - 8.  Here a workgroup owns ONE 32 x 32 output tile (256 - 768
+// workgroups for the forward shapes) and its four waves split K between them; every wave feeds v_mfma_f32_32x32x2_f32 straight from
+// global memory — no LDS staging, no barrier inside the K loop:
+//   * lane (r = l & 31, h = l >> 5) of the MFMA holds A[m0 + r][k] and B[n0 + r][k] for k = k0 + h of a K pair; a chunk of 32 k is
+//     consumed as 16 MFMAs in the order k = kc + 16 h + t, t = 0..15 (both operands use the same permutation of K inside a chunk, so
+//     every product pairs the right elements), which lets a lane fetch its 16 values of a K-contiguous operand as four float4
+//     (a full 128-B line per row and lane pair), or 16 coalesced dwords of an operand stored K-major;
+//   * chunks are dealt round-robin to the waves (wave w: chunks w, w + 4, ...), three chunk buffers per wave = two chunks in flight
+//     behind the one being multiplied;
+//   * the four partial tiles meet in LDS once, are summed in a fixed order ((w0 + w1) + (w2 + w3)) and leave coalesced.
+// The sum over K is a different (still fixed) order than the fmaf chain of the big kernel; both are exact-product fp32 sums.
+template <int N, typename F, int I = 0>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, F, I + 1>(static_cast<F&&>(f));
+    }
+}
+
+constexpr int kTrLd = 36;                 // floats per row of a wave's transposition area (conflict-free 16-byte writes and reads)
+constexpr int kTrFloats = 32 * kTrLd;     // one 32 x 32 chunk
+
+template <bool KFAST>
+struct DirectChunk {
+    float v[16];
+    // K-major operand (element (row, k) at k * ld + row): lane (r = lane & 31, h = lane >> 5) loads its MFMA values directly,
+    // k = k0 + 16 h + t for t = 0..15 — 16 dword loads, each wave load = two full 128-byte lines.
+    // K-contiguous operand (element (row, k) at row * ld + k): the same distribution would make every lane of a load touch a different
+    // 128-byte line (32 lines per instruction, each visited by four instructions: the L1 tag rate, not the data, bounded the first
+    // version of this kernel at ~25 us for 256 workgroups).  Instead the chunk is fetched COALESCED — instruction i covers rows 8 i .. 8 i + 7,
+    // eight lanes per row, 16 bytes each: 8 full lines per instruction — and redistributed to the MFMA layout through a wave-private
+    // LDS area right before its MFMAs (to_mfma: 4 x 16-byte writes, 4 x 16-byte reads, no barrier: one wave's LDS operations execute
+    // in order).  Rows beyond R are clamped to R - 1: they are computed and never stored.
+    // (whole chunks and 16-byte aligned rows only: the launcher sends ragged K and unaligned operands to the staged kernel — a run-time
+    // "fast" flag made the compiler duplicate every load behind a branch)
+    __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int64_t r0, int64_t R, int64_t k0, int lane) {
+        if (KFAST) {
+            const int kq = 4 * (lane & 7);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t row = min(r0 + 8 * i + (lane >> 3), R - 1);
+                const float4 x = *(const float4*)(P + row * ld + k0 + kq);
+                v[4 * i + 0] = x.x;
+                v[4 * i + 1] = x.y;
+                v[4 * i + 2] = x.z;
+                v[4 * i + 3] = x.w;
+            }
+        } else {
+            const int64_t row = min(r0 + (lane & 31), R - 1);
+            // the 16 addresses of a lane differ by multiples of ld — a UNIFORM base per k (scalar registers) plus one 32-bit lane offset
+            // (row inside the panel, + 16 rows of K for the upper half wave) instead of 16 address pairs per chunk buffer
+            // (the launcher routes operands with 16 ld + 32 >= 2^31 elements to the staged kernel)
+            const uint32_t lo = (uint32_t)(row - r0) + (uint32_t)(16 * (lane >> 5)) * (uint32_t)ld;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float* pu = P + (k0 + t) * ld + r0;   // uniform
+                v[t] = pu[lo];
+            }
+        }
+    }
+    // K-contiguous operands only: coalesced layout -> MFMA layout (lane (r, h): k = 16 h + t) through the wave's LDS area `tr`
+    __device__ __forceinline__ void to_mfma(float* tr, int lane) {
+        if (!KFAST) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *(float4*)(tr + (8 * i + (lane >> 3)) * kTrLd + 4 * (lane & 7)) = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+        const float* rd = tr + (lane & 31) * kTrLd + 16 * (lane >> 5);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 x = *(const float4*)(rd + 4 * c);
+            v[4 * c + 0] = x.x;
+            v[4 * c + 1] = x.y;
+            v[4 * c + 2] = x.z;
+            v[4 * c + 3] = x.w;
+        }
+    }
+};
+
+struct NllFused {   // forward epilogue of the loss (EPI = 1): per (row, column tile) statistics for nll_finish_kernel
+    const int32_t* pos;
+    uint4* stat;         // {max, sum exp(s - max), first arg-max column, -} of a row over one column tile
+    float* spos;         // the positive's score per row
+};
+
+// EPI 0: C = alpha * acc (+ C).  EPI 1 (forward of the loss): C = mix, + the softmax statistics of the tile's rows over its 32 columns.
+template <bool AKF, bool BKF, bool MIX, int EPI>
+__global__ __launch_bounds__(256) void sgemm_direct_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                                           int64_t ldb, const float* __restrict__ B2, float* __restrict__ C, int64_t ldc,
+                                                           int64_t M, int64_t N, int64_t K, float alpha, float w2, int accumulate,
+                                                           NllFused nll) {
+    // LDS: the waves' transposition areas (A, B, B2) during the K loop, the four partial tiles afterwards
+    constexpr int kTrOps = MIX ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) float smem[4 * kTrOps * kTrFloats];
+    static_assert(4 * 32 * 33 <= 4 * 2 * kTrFloats, "partial tiles alias the transposition areas");
+    float (*red)[32][33] = (float (*)[32][33])smem;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: scalar chunk addresses)
+    const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
+    const int64_t nch = (K + 31) / 32;
+    f32x16 acc1, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[r] = acc2[r] = 0.f;
+    // chunk buffers per wave: all six chunks of a wave's K quarter in flight at K = 768 (one memory round trip in front of the MFMAs
+    // instead of three: the problem is latency class); the mix carries a second B operand and keeps four
+    constexpr int NB = MIX ? 4 : 6;
+    DirectChunk<AKF> a[NB];
+    DirectChunk<BKF> b[NB], b2[MIX ? NB : 1];
+    auto fetch = [&](auto bi_tag, int64_t c) {
+        constexpr int bi = decltype(bi_tag)::value;
+        a[bi].load(A, lda, m0, M, c * 32, lane);
+        b[bi].load(B, ldb, n0, N, c * 32, lane);
+        if (MIX) b2[MIX ? bi : 0].load(B2, ldb, n0, N, c * 32, lane);
+    };
+    float* tr = smem + wave * (kTrOps * kTrFloats);
+    auto mult = [&](auto bi_tag) {
+        constexpr int bi = decltype(bi_tag)::value;
+        a[bi].to_mfma(tr, lane);
+        b[bi].to_mfma(tr + kTrFloats, lane);
+        if (MIX) b2[MIX ? bi : 0].to_mfma(tr + 2 * kTrFloats, lane);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[bi].v[t], b[bi].v[t], acc1, 0, 0, 0);
+            if (MIX) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[bi].v[t], b2[MIX ? bi : 0].v[t], acc2, 0, 0, 0);
+        }
+    };
+    // wave w multiplies the chunks w, w + 4, ...; chunk number j of a wave lives in buffer j % NB and is fetched NB - 1 chunks ahead
+    static_for<NB - 1>([&](auto j) {
+        if (wave + 4 * (int64_t)decltype(j)::value < nch) fetch(j, wave + 4 * (int64_t)decltype(j)::value);
+    });
+    for (int64_t c = wave; c < nch; c += 4 * NB) {
+        static_for<NB>([&](auto j) {
+            constexpr int jj = decltype(j)::value;
+            const int64_t cc = c + 4 * jj;
+            if (cc < nch) {
+                if (cc + 4 * (NB - 1) < nch) fetch(std::integral_constant<int, (jj + NB - 1) % NB>{}, cc + 4 * (NB - 1));
+                mult(j);
+            }
+        });
+    }
+    // partial tiles -> LDS (MFMA layout: lane holds column lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+    float fin[4];
+    for (int pass = 0; pass < (MIX ? 2 : 1); ++pass) {
+        __syncthreads();   // (every wave is done with its transposition area / with the previous pass)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][lane & 31] = pass ? acc2[r] : acc1[r];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = (threadIdx.x >> 5) + 8 * i, n = threadIdx.x & 31;
+            const float sum = (red[0][m][n] + red[1][m][n]) + (red[2][m][n] + red[3][m][n]);
+            // (1 - w) q.ctx + w q.cap exactly like the reference: two rounded products, one rounded add
+            fin[i] = pass ? __fadd_rn(fin[i], __fmul_rn(w2, sum)) : __fmul_rn(alpha, sum);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + (threadIdx.x >> 5) + 8 * i, n = n0 + (threadIdx.x & 31);
+        if (m < M && n < N) {
+            float* cp = C + m * ldc + n;
+            if (accumulate) fin[i] = __fadd_rn(*cp, fin[i]);
+            *cp = fin[i];
+        }
+    }
+    if (EPI == 0) return;
+
+    // ---- fused NLL forward: statistics of this tile's 32 columns for each of its rows (a row = the 32 lanes t & 31 of a half wave)
+    const int ntn = gridDim.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + (threadIdx.x >> 5) + 8 * i, n = n0 + (threadIdx.x & 31);
+        const float v = n < N ? fin[i] : -INFINITY;
+        float mx = v;
+        int64_t am = n < N ? n : 0x7fffffffffffffffll;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            const float m2 = __shfl_xor(mx, o);
+            const int64_t a2 = __shfl_xor(am, o);
+            if (m2 > mx || (m2 == mx && a2 < am)) {
+                mx = m2;
+                am = a2;
+            }
+        }
+        float z = n < N ? expf(v - mx) : 0.f;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) z += __shfl_xor(z, o);
+        if (m < M) {
+            if ((threadIdx.x & 31) == 0) {
+                nll.stat[m * ntn + blockIdx.x] = make_uint4(__float_as_uint(mx), __float_as_uint(z), (uint32_t)am, 0u);
+            }
+            if (n < N && (int64_t)nll.pos[m] == n) nll.spos[m] = v;
+        }
+    }
+}
+
+// The rest of the forward: per row, the column tiles' statistics merge into max / first arg-max / logsumexp (online-softmax merge), the
+// NLL at the positive, the correct count and the deterministic loss sum.  A workgroup takes 64 rows (eight threads per row: a single
+// workgroup for all rows was bound by ONE CU's memory bandwidth, 9 - 15 us for 130 - 390 KB of statistics); the workgroups' partial sums
+// meet in the last one to arrive (a handful of workgroups: write-through partials + an agent-scope counter that the last one resets, so
+// the workspace needs no memset), which adds them in workgroup order — the loss sum is deterministic.
+// (Finishing INSIDE the GEMM kernel by "last workgroup to arrive" per row tile was built and measured: with hundreds of workgroups the
+// hand-off chain cost 12 - 18 us on top of a 9 - 24 us GEMM, profiles/r04_loss_kernel_trace_*.txt.)
+__global__ __launch_bounds__(512) void nll_finish_kernel(const uint4* __restrict__ stat, const float* __restrict__ spos,
+                                                         const int32_t* __restrict__ pos, int64_t n1, int ntn,
+                                                         float* __restrict__ row_loss, float* __restrict__ lse_out,
+                                                         int32_t* __restrict__ correct, float* __restrict__ loss_sum,
+                                                         double* __restrict__ part_sum, int32_t* __restrict__ part_ok,
+                                                         int32_t* __restrict__ counter) {
+    __shared__ double sh[512];
+    __shared__ int ok_sh[8];
+    __shared__ int last_flag;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = threadIdx.x & 7;
+    const int64_t m = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 3);
+    float mx = -INFINITY, z = 0.f;
+    int am = 0x7fffffff;
+    if (m < n1)
+        for (int t = sub; t < ntn; t += 8) {
+            const uint4 st = stat[m * ntn + t];
+            const float sx = __uint_as_float(st.x), sz = __uint_as_float(st.y);
+            const int a2 = (int)st.z;
+            if (sx > mx || (sx == mx && a2 < am)) am = a2;
+            const float nm = fmaxf(mx, sx);
+            z = z * expf(mx - nm) + sz * expf(sx - nm);   // (exp(-inf - nm) = 0 for the empty start)
+            mx = nm;
+        }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(mx, o), z2 = __shfl_xor(z, o);
+        const int a2 = __shfl_xor(am, o);
+        if (m2 > mx || (m2 == mx && a2 < am)) am = a2;
+        const float nm = fmaxf(mx, m2);
+        z = (nm == -INFINITY) ? 0.f : z * expf(mx - nm) + z2 * expf(m2 - nm);
+        mx = nm;
+    }
+    double acc = 0.0;
+    int nok = 0;
+    if (m < n1 && sub == 0) {
+        const float l = mx + logf(z);
+        const float rl = l - spos[m];
+        lse_out[m] = l;
+        row_loss[m] = rl;
+        acc = (double)rl;
+        nok = am == pos[m];
+    }
+    sh[threadIdx.x] = acc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nok += __shfl_xor(nok, o);
+    if (lane == 0) ok_sh[wave] = nok;
+    __syncthreads();
+    for (int o = 256; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < 8; ++w) tot += ok_sh[w];
+        // write-through partials, drained, then the arrival counter (agent scope)
+        __hip_atomic_store(&part_sum[blockIdx.x], sh[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&part_ok[blockIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = old == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last_flag || threadIdx.x != 0) return;
+    double total = 0.0;
+    int tot = 0;
+    for (unsigned b = 0; b < gridDim.x; ++b) {   // (workgroup order: deterministic)
+        total += __hip_atomic_load(&part_sum[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tot += __hip_atomic_load(&part_ok[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    loss_sum[0] = (float)total;
+    correct[0] = tot;
+    __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call on this stream
+}
+
+template <int EPI>
+static int launch_sgemm_direct(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbn, int64_t sbk, const float* B2,
+                               float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha, float w2, int accumulate,
+                               const NllFused& nll, hipStream_t st) {
+    const bool ak = (sak == 1), bk = (sbk == 1);
+    const int64_t lda = ak ? sam : sak, ldb = bk ? sbn : sbk;
+    const dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32)), block(256);
+#define LDOT_SGD(AK_, BK_, MIX_)                                                                                              \
+    hipLaunchKernelGGL((sgemm_direct_kernel<AK_, BK_, MIX_, EPI>), grid, block, 0, st, A, lda, B, ldb, B2, C, ldc, M, N, K, alpha, \
+                       w2, accumulate, nll)
+    if (B2) {
+        if (ak && bk) LDOT_SGD(true, true, true);
+        else if (ak && !bk) LDOT_SGD(true, false, true);
+        else if (!ak && bk) LDOT_SGD(false, true, true);
+        else LDOT_SGD(false, false, true);
+    } else {
+        if (ak && bk) LDOT_SGD(true, true, false);
+        else if (ak && !bk) LDOT_SGD(true, false, false);
+        else if (!ak && bk) LDOT_SGD(false, true, false);
+        else LDOT_SGD(false, false, false);
+    }
+#undef LDOT_SGD
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+// small problems take the direct kernel (see there); 128^2 LDS tiles once they alone fill the chip
+static bool sgemm_is_small(int64_t M, int64_t N) { return (M + 127) / 128 * ((N + 127) / 128) < 256; }
+// ... if their operands allow its unguarded loads: whole 32-deep chunks, 16-byte aligned rows of a K-contiguous operand, a K-major
+// operand's 16 ld inside 32 bits
+static bool sgemm_direct_ok(const float* P, int64_t s_row, int64_t s_k, int64_t K) {
+    if (K <= 0 || K % 32) return false;
+    if (s_k == 1) return s_row % 4 == 0 && ((uintptr_t)P & 15) == 0;
+    return s_k < ((int64_t)1 << 26) && ((uintptr_t)P & 3) == 0;
+}
+
 // A(m,k) = A[m*sam + k*sak], B(n,k) = B[n*sbn + k*sbk]; exactly one stride of each operand is 1
 static int launch_sgemm(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbn, int64_t sbk, float* C,
                         int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha, int accumulate, hipStream_t st) {
@@ -169,6 +486,8 @@ static int launch_sgemm(const float* A, int64_t sam, int64_t sak, const float* B
     const bool ak = (sak == 1), bk = (sbk == 1);
     const int64_t lda = ak ? sam : sak, ldb = bk ? sbn : sbk;
     const int vec = ((lda % 4 == 0 && ((uintptr_t)A & 15) == 0) ? 1 : 0) | ((ldb % 4 == 0 && ((uintptr_t)B & 15) == 0) ? 2 : 0);
+    if (sgemm_is_small(M, N) && sgemm_direct_ok(A, sam, sak, K) && sgemm_direct_ok(B, sbn, sbk, K))
+        return launch_sgemm_direct<0>(A, sam, sak, B, sbn, sbk, nullptr, C, ldc, M, N, K, alpha, 0.f, accumulate, NllFused{}, st);
     // 128^2 tiles once they alone fill the chip, else 64^2 (more workgroups: these problems are latency bound)
     if ((M + 127) / 128 * ((N + 127) / 128) >= 256) {
         dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
@@ -186,6 +505,9 @@ int launch_sgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, co
                     int64_t ldc, int64_t M, int64_t N, int64_t K, hipStream_t st) {
     const bool mix = (B2 != nullptr && w != 0.f);
     const float a1 = mix ? (float)(1.0 - (double)w) : 1.f;
+    if (M > 0 && N > 0 && sgemm_is_small(M, N) && sgemm_direct_ok(A, lda, 1, K) && sgemm_direct_ok(B, ldb, 1, K) &&
+        (!mix || sgemm_direct_ok(B2, ldb, 1, K)))   // both products in one launch
+        return launch_sgemm_direct<0>(A, lda, 1, B, ldb, 1, mix ? B2 : nullptr, C, ldc, M, N, K, a1, w, 0, NllFused{}, st);
     int rc = launch_sgemm(A, lda, 1, B, ldb, 1, C, ldc, M, N, K, a1, 0, st);
     if (rc || !mix) return rc;
     return launch_sgemm(A, lda, 1, B2, ldb, 1, C, ldc, M, N, K, w, 1, st);
@@ -303,12 +625,80 @@ int ldot_dot_product_scores(const float* q, const float* ctx, int64_t n1, int64_
     return launch_sgemm_nt(q, d, ctx, d, nullptr, 0.f, out, n2, n1, n2, d, (hipStream_t)stream);
 }
 
+// Workspace of the fused forward (per-tile statistics), one per (device, stream) that ever ran it: calls on
+// different streams may overlap on the GPU, calls on one stream cannot.  Grow-only; a few hundred KB at the config-5 shapes.
+namespace {
+struct LossWs {
+    int device;
+    hipStream_t stream;
+    void* p;
+    size_t bytes;
+};
+std::mutex g_loss_mu;
+std::vector<LossWs> g_loss_ws;
+
+int loss_workspace(hipStream_t st, size_t need, char** out) {
+    int dev = 0;
+    LDOT_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_loss_mu);
+    LossWs* ws = nullptr;
+    for (LossWs& w : g_loss_ws)
+        if (w.device == dev && w.stream == st) ws = &w;
+    if (!ws) {
+        g_loss_ws.push_back(LossWs{dev, st, nullptr, 0});
+        ws = &g_loss_ws.back();
+    }
+    if (ws->bytes < need) {
+        if (ws->p) {
+            LDOT_HIP_CHECK(hipStreamSynchronize(st));   // (the previous call on this stream may still be reading it)
+            (void)hipFree(ws->p);
+            ws->p = nullptr;
+            ws->bytes = 0;
+        }
+        LDOT_HIP_CHECK(hipMalloc(&ws->p, need));
+        ws->bytes = need;
+        LDOT_HIP_CHECK(hipMemsetAsync(ws->p, 0, 256, st));   // the finish kernel's arrival counter: zero now, reset by its last workgroup
+    }
+    *out = (char*)ws->p;
+    return LDOT_OK;
+}
+}  // namespace
+
+// forward of the loss in two launches: the score tiles with the softmax statistics of their rows in the epilogue (max, first arg-max,
+// sum of exponentials, the positive's score: sgemm_direct_kernel, EPI = 1 — the scores are never re-read), and one workgroup that merges
+// the tiles' statistics into logsumexp / NLL / correct count / loss sum.  SURVEY 2b K4's "fused score + logsumexp + NLL + argmax"
+// (dvl/models/bi_encoder.py:624,649-655)
+static int launch_nll_fwd_fused(const float* q, const float* ctx, const float* cap, float w, const int32_t* pos, int64_t n1, int64_t n2,
+                                int64_t d, float* scores, float* row_loss, float* lse, int32_t* correct, float* loss_sum, hipStream_t st) {
+    const bool mix = (cap != nullptr && w != 0.f);
+    const float a1 = mix ? (float)(1.0 - (double)w) : 1.f;
+    const int64_t ntn = (n2 + 31) / 32;
+    const int64_t nfin = (n1 + 63) / 64;   // workgroups of the finish kernel
+    // workspace: [arrival counter (kept zero between calls) | per-tile statistics | positives' scores | finish partials]
+    const size_t b_cnt = 256, b_st = (size_t)round_up(n1 * ntn * 16, 256), b_spos = (size_t)round_up(n1 * 4, 256),
+                 b_ps = (size_t)round_up(nfin * 8, 256), b_po = (size_t)round_up(nfin * 4, 256);
+    char* ws = nullptr;
+    int rc = loss_workspace(st, b_cnt + b_st + b_spos + b_ps + b_po, &ws);
+    if (rc) return rc;
+    NllFused nll;
+    nll.pos = pos;
+    nll.stat = (uint4*)(ws + b_cnt);
+    nll.spos = (float*)(ws + b_cnt + b_st);
+    if ((rc = launch_sgemm_direct<1>(q, d, 1, ctx, d, 1, mix ? cap : nullptr, scores, n2, n1, n2, d, a1, w, 0, nll, st))) return rc;
+    hipLaunchKernelGGL(nll_finish_kernel, dim3((unsigned)nfin), dim3(512), 0, st, nll.stat, nll.spos, pos, n1, (int)ntn, row_loss, lse, correct,
+                       loss_sum, (double*)(ws + b_cnt + b_st + b_spos), (int32_t*)(ws + b_cnt + b_st + b_spos + b_ps), (int32_t*)ws);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
 int ldot_inbatch_nll_fwd(const float* q, const float* ctx, const float* cap, float w, const int32_t* pos, int64_t n1,
                          int64_t n2, int64_t d, float* scores, float* row_loss, float* lse, int32_t* correct,
                          float* loss_sum, void* stream) {
     LDOT_REQUIRE(q && ctx && pos && scores && row_loss && lse && correct && loss_sum, LDOT_EINVAL, "NULL buffer");
     LDOT_REQUIRE(n1 > 0 && n2 > 0 && d > 0, LDOT_EINVAL, "bad shape");
     hipStream_t st = (hipStream_t)stream;
+    if (sgemm_is_small(n1, n2) && sgemm_direct_ok(q, d, 1, d) && sgemm_direct_ok(ctx, d, 1, d) && (!cap || sgemm_direct_ok(cap, d, 1, d)))
+        return launch_nll_fwd_fused(q, ctx, cap, w, pos, n1, n2, d, scores, row_loss, lse, correct, loss_sum, st);
     int rc = launch_sgemm_nt(q, d, ctx, d, cap, w, scores, n2, n1, n2, d, st);
     if (rc) return rc;
     return launch_nll_rows(scores, n1, n2, pos, row_loss, lse, correct, loss_sum, st);

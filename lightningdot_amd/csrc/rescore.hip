@@ -16,7 +16,7 @@ __global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __rest
                                                              const int32_t* __restrict__ list_i, int kp, int k,
                                                              int do_rescore, const float* __restrict__ floor,
                                                              float* __restrict__ out_s,
-                                                             int64_t* __restrict__ out_l) {
+                                                             int64_t* __restrict__ out_l, RescoreOut lay) {
     __shared__ __attribute__((aligned(16))) uint64_t keys[4096];   // next power of two >= kMaxKp
     static_assert(kMaxKp <= 4096, "re-score key buffer");
     const int64_t q = blockIdx.x;
@@ -101,14 +101,18 @@ __global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __rest
     for (int e = m + threadIdx.x; e < P; e += kRsThreads) keys[e] = ~0ull;
     __syncthreads();
     bitonic_sort_lds(keys, P);
+    // dense outputs [nq][k], or blocks of block_rows queries (the send buffer of a sharded search: one block per destination rank)
+    const int64_t blk = lay.block_rows > 0 ? q / lay.block_rows : 0, in_blk = lay.block_rows > 0 ? q - blk * lay.block_rows : q;
+    float* os = out_s + blk * lay.stride_s + in_blk * k;
+    int64_t* ol = out_l + blk * lay.stride_l + in_blk * k;
     for (int e = threadIdx.x; e < k; e += kRsThreads) {
         const uint64_t key = (e < m) ? keys[e] : ~0ull;
         if (key != ~0ull) {
-            out_s[q * k + e] = desc_key_to_float((uint32_t)(key >> 32));
-            out_l[q * k + e] = (int64_t)(uint32_t)(key & 0xffffffffu);
+            os[e] = desc_key_to_float((uint32_t)(key >> 32));
+            ol[e] = (int64_t)(uint32_t)(key & 0xffffffffu) + lay.label_base;
         } else {
-            out_s[q * k + e] = LDOT_PAD_SCORE;
-            out_l[q * k + e] = LDOT_PAD_LABEL;
+            os[e] = LDOT_PAD_SCORE;
+            ol[e] = LDOT_PAD_LABEL;
         }
     }
 }
@@ -246,14 +250,15 @@ int launch_verify_exact(const float* q32, int64_t ldq, int d, int64_t nq, const 
 
 int launch_rescore(const float* q32, int64_t ldq, const float* x32, int64_t ldx, int dpad, int64_t nq,
                    const float* list_s, const int32_t* list_i, int kp, int k, int do_rescore, const float* floor,
-                   float* out_s, int64_t* out_l, hipStream_t st) {
+                   float* out_s, int64_t* out_l, hipStream_t st, const RescoreOut* layout) {
     if (nq <= 0) return LDOT_OK;
+    const RescoreOut lay = layout ? *layout : RescoreOut{0, 0, 0, 0};
     if (nq <= 128)
         hipLaunchKernelGGL(rescore_kernel<1024>, dim3((unsigned)nq), dim3(1024), 0, st, q32, ldq, x32, ldx, dpad, list_s,
-                           list_i, kp, k, do_rescore, floor, out_s, out_l);
+                           list_i, kp, k, do_rescore, floor, out_s, out_l, lay);
     else
         hipLaunchKernelGGL(rescore_kernel<256>, dim3((unsigned)nq), dim3(256), 0, st, q32, ldq, x32, ldx, dpad, list_s,
-                           list_i, kp, k, do_rescore, floor, out_s, out_l);
+                           list_i, kp, k, do_rescore, floor, out_s, out_l, lay);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

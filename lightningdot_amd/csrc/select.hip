@@ -982,7 +982,7 @@ __global__ __launch_bounds__(kSelThreads) void select_pools_block_kernel(const u
 // explicit lists source (sharded merge): parts laid out [nparts][nq][k_in], int64 labels (< 2^32-1), -1 = empty
 __global__ __launch_bounds__(kSelThreads) void select_lists_kernel(const float* __restrict__ cand_s,
                                                                    const int64_t* __restrict__ cand_l,
-                                                                   int64_t part_stride, int nparts, int k_in,
+                                                                   int64_t part_stride, int64_t part_stride_l, int nparts, int k_in,
                                                                    int k_out, int cap, float* __restrict__ out_s,
                                                                    int64_t* __restrict__ out_l) {
     extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
@@ -998,10 +998,9 @@ __global__ __launch_bounds__(kSelThreads) void select_lists_kernel(const float* 
         uint64_t key = kEmptyKey;
         if (valid) {
             const int p = sl / k_in, e = sl % k_in;
-            const int64_t off = (int64_t)p * part_stride + q * k_in + e;
-            const int64_t l = cand_l[off];
+            const int64_t l = cand_l[(int64_t)p * part_stride_l + q * k_in + e];
             valid = l >= 0;
-            if (valid) key = make_key(cand_s[off], (uint32_t)l);
+            if (valid) key = make_key(cand_s[(int64_t)p * part_stride + q * k_in + e], (uint32_t)l);
         }
         sel.push(key, valid);
     }
@@ -1360,12 +1359,12 @@ int launch_apply_stats(int64_t nq, const float* stat, float* tau, hipStream_t st
     return LDOT_OK;
 }
 
-int launch_select_lists(const float* cand_s, const int64_t* cand_l, int64_t part_stride, int nparts, int k_in,
+int launch_select_lists(const float* cand_s, const int64_t* cand_l, int64_t part_stride, int64_t part_stride_l, int nparts, int k_in,
                         int64_t nq, int k_out, float* out_s, int64_t* out_l, hipStream_t st) {
     if (nq <= 0) return LDOT_OK;
     const int cap = select_cap(k_out, 1024, kSelThreads);
     hipLaunchKernelGGL(select_lists_kernel, dim3((unsigned)nq), dim3(kSelThreads), (size_t)cap * 8, st, cand_s, cand_l,
-                       part_stride, nparts, k_in, k_out, cap, out_s, out_l);
+                       part_stride, part_stride_l, nparts, k_in, k_out, cap, out_s, out_l);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

@@ -260,6 +260,21 @@ class FlatIPIndex:
                                                    ctypes.c_void_p(labels.data_ptr()), L.DEVICE, _stream_ptr(self.device)))
         return scores, labels
 
+    def search_finish_blocked(self, floor, blocks, block_rows: int, block_bytes: int, label_base: int):
+        """search_finish into the send buffer of a sharded search's all-to-all (``blocks``: a uint8 CUDA tensor of
+        ceil(nq / block_rows) * block_bytes bytes, layout in ldot.h); labels come out global (+ label_base)."""
+        if self._pending is None:
+            raise L.LdotError(-5, 'search_finish without a pending search_begin')
+        (nq, k, dev), self._pending = self._pending, None
+        assert blocks.is_cuda and blocks.is_contiguous() and blocks.numel() * blocks.element_size() >= -(-nq // block_rows) * block_bytes
+        fptr = ctypes.c_void_p(0)
+        if floor is not None:
+            floor = floor.to(device=dev, dtype=floor.dtype).contiguous()
+            assert floor.shape == (nq,) and floor.dtype.is_floating_point and floor.element_size() == 4
+            fptr = ctypes.c_void_p(floor.data_ptr())
+        L.check(self._lib.ldot_index_search_finish_blocked(self._h, fptr, ctypes.c_void_p(blocks.data_ptr()), int(block_rows),
+                                                           int(block_bytes), int(label_base), _stream_ptr(self.device)))
+
     def get_rows(self, row0: int, n: int) -> np.ndarray:
         out = np.empty((n, self.d), dtype=np.float32)
         L.check(self._lib.ldot_index_get_rows(self._h, int(row0), int(n), ctypes.c_void_p(out.ctypes.data), L.HOST,

@@ -48,10 +48,10 @@ class _InBatchNll(torch.autograd.Function):
             raise ValueError('shape mismatch between q / ctx / caption vectors')
         dev = qf.device
         scores = torch.empty((n1, n2), dtype=torch.float32, device=dev)
-        row_loss = torch.empty((n1,), dtype=torch.float32, device=dev)
-        lse = torch.empty((n1,), dtype=torch.float32, device=dev)
-        correct = torch.empty((1,), dtype=torch.int32, device=dev)
-        loss_sum = torch.empty((1,), dtype=torch.float32, device=dev)
+        # one allocation for the small outputs: row_loss [n1] | lse [n1] | loss_sum [1] | correct [1] (int32 view)
+        small = torch.empty((2 * n1 + 2,), dtype=torch.float32, device=dev)
+        row_loss, lse, loss_sum = small[:n1], small[n1:2 * n1], small[2 * n1:2 * n1 + 1]
+        correct = small[2 * n1 + 1:].view(torch.int32)
         L.check(lib.ldot_inbatch_nll_fwd(_ptr(qf), _ptr(cf), _ptr(capf), float(w), _ptr(pos), n1, n2, d,
                                          _ptr(scores), _ptr(row_loss), _ptr(lse), _ptr(correct), _ptr(loss_sum),
                                          _stream()))
@@ -59,17 +59,21 @@ class _InBatchNll(torch.autograd.Function):
         ctx.w = float(w)
         ctx.has_cap = capf is not None
         ctx.in_dtypes = (q.dtype, c.dtype, cap.dtype if cap is not None else None)
-        ctx.mark_non_differentiable(correct, loss_sum)
+        ctx.mark_non_differentiable(correct)
         return row_loss, scores, correct, loss_sum
 
     @staticmethod
-    def backward(ctx, g_row, g_scores, _gc, _gs):
+    def backward(ctx, g_row, g_scores, _gc, g_sum):
         lib = L.load_library()
         qf, cf, capf, pos, scores, lse = ctx.saved_tensors
         capf = capf if ctx.has_cap else None
         n1, d = qf.shape
         n2 = cf.shape[0]
         dev = qf.device
+        # loss_sum = sum(row_loss) (the kernel's deterministic sum): its gradient reaches every row
+        if g_sum is not None:
+            g_sum = g_sum.float().reshape(1).expand(n1)
+            g_row = g_sum.contiguous() if g_row is None else g_row.float() + g_sum
         g_row = torch.zeros((n1,), dtype=torch.float32, device=dev) if g_row is None else g_row.float().contiguous()
         g_scores = None if g_scores is None else g_scores.float().contiguous()
         need_q, need_c, need_cap = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
@@ -155,10 +159,11 @@ class BiEncoderNllLoss(object):
             d = torch.diag(scores)
             experiment.log_metric('score_diag_mean', d.mean().item())
             experiment.log_metric('score_offdiag_mean', (scores.sum() - d.sum()) / (torch.numel(scores) - len(d)))
+        # (mean / sum come from the forward kernel's own deterministic fp64-tree sum of the row losses, not from another reduction kernel)
         if reduction == 'mean':
-            loss = row_loss.mean()
+            loss = loss_sum.reshape(()) / row_loss.shape[0]
         elif reduction == 'sum':
-            loss = row_loss.sum()
+            loss = loss_sum.reshape(())
         elif reduction == 'none':
             loss = row_loss
         else:

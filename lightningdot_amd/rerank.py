@@ -92,16 +92,35 @@ def first_stage_candidates(bi_encoder, indexer_img, indexer_txt, dataloader: Ite
 
     def hits(labels, pos):
         return {top: int((labels[:, :top, None] == pos[:, None, :]).any(dim=2).any(dim=1).sum().item()) for top in RECALL_TOPS}
+    # The reference's text-retrieval loop runs over the DISTINCT image ids and divides by their number (rerank.py:275-289; its
+    # ranking_res_txt keeps the LAST occurrence of an id, :191-192): the row selection and the denominator that reproduce it
+    last = {}
+    for j, i in enumerate(img_ids):
+        last[i] = j
+    img_unique_rows = torch.as_tensor(list(last.values()), dtype=torch.int64, device=dev)
     return dict(txt_ids=txt_ids, img_ids=img_ids, labels_img=lab_img, labels_txt=lab_txt, pos_img=pos_img, pos_txt=pos_txt,
-                recall_img=hits(lab_img, pos_img), recall_txt=hits(lab_txt, pos_txt), total_len=len(txt_ids))
+                recall_img=hits(lab_img, pos_img), recall_txt=hits(lab_txt, pos_txt), total_len=len(txt_ids),
+                img_unique_rows=img_unique_rows, img_unique_ids=list(last.keys()))
 
 
 def rerank_recall_device(labels: torch.Tensor, ext_scores: torch.Tensor, positives: torch.Tensor,
-                         thresholds: Sequence[int] = THRESHOLDS, denominator: int = None, missing: float = -1000.0):
+                         thresholds: Sequence[int] = THRESHOLDS, denominator: int = None, missing: float = -1000.0,
+                         rows: torch.Tensor = None, pad_as_last_id: bool = True):
     """rerank.py:256-290 on the device, for an external scorer given as a matrix (the reference's ``scores_mat`` form, :229-233):
     ``labels`` [nq, K] first-stage candidates (index rows, -1 = padding), ``ext_scores`` [nq, n_db] the cross-encoder's score of
     (query, index row), ``positives`` [nq, P] the rows that count as hits (-2 = unused).  For every threshold the scorer's top 10 of
-    the first ``threshold`` candidates are kept and Recall@{1,5,10} counted.  -> {threshold: {1: r, 5: r, 10: r}}"""
+    the first ``threshold`` candidates are kept and Recall@{1,5,10} counted.  -> {threshold: {1: r, 5: r, 10: r}}
+
+    ``rows`` selects the query rows that count (text retrieval: ``first_stage_candidates(...)['img_unique_rows']`` — one row per distinct
+    image id, the last occurrence, which is what the reference's dict keeps and its loop over ``img_ids`` visits, rerank.py:275-289);
+    the default denominator is the number of rows counted, i.e. ``len(img_ids)`` of the reference with that selection and ``total_len``
+    for image retrieval.  A padding label (-1: the index holds fewer rows than candidates were asked for) is what the reference's
+    ``index_id_to_db_id[-1]`` turns into the LAST db id (dvl/indexer/faiss_indexers.py:85); ``pad_as_last_id`` mirrors that, False gives
+    such candidates the ``missing`` score instead."""
+    if rows is not None:
+        labels, ext_scores, positives = labels[rows], ext_scores[rows], positives[rows]
+    if pad_as_last_id:
+        labels = torch.where(labels >= 0, labels, labels.new_full((), ext_scores.shape[1] - 1))
     den = labels.shape[0] if denominator is None else denominator
     out = {}
     for threshold in thresholds:

@@ -54,7 +54,7 @@ def _hip_merge(scores: torch.Tensor, labels: torch.Tensor, k: int, out=None):
 class ShardedFlatIndexer:
     def __init__(self, vector_sz: int, group=None, local_search: Optional[Callable] = None,
                  merge: Optional[Callable] = None, normalize: bool = False, exchange: str = 'all_to_all',
-                 exchange_warmup: bool = True):
+                 exchange_warmup: bool = True, equal_query_counts: bool = False):
         if exchange not in ('all_to_all', 'all_gather'):
             raise ValueError("exchange must be 'all_to_all' or 'all_gather'")
         self.group = group
@@ -63,6 +63,10 @@ class ShardedFlatIndexer:
         self.d = vector_sz
         self.exchange = exchange
         self.exchange_warmup = exchange_warmup   # thresholds agreed after the warm-up (False: only after the candidate pass, as in round 3)
+        # the caller promises that every rank passes the same number of queries to every search: the per-search exchange of the
+        # query counts (a small all-gather + a host synchronisation) is skipped
+        self.equal_query_counts = equal_query_counts
+        self._blocks = {}                        # send buffers of the blocked exchange, by size
         self._custom = local_search is not None
         self.local = None if self._custom else DenseFlatIndexer(vector_sz, normalize=normalize)
         self._local_search = local_search
@@ -115,6 +119,27 @@ class ShardedFlatIndexer:
         dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=[int(c) for c in counts.tolist()], group=self.group)
         return list(recv.split(rc))
 
+    def _local_id_kind(self) -> int:
+        """0 no ids, 1 integers that fit int64, 2 strings, 3 anything else (validated over ALL local ids, cached until ids are added)"""
+        n = len(self.local_ids)
+        cached = getattr(self, '_id_kind_cache', None)
+        if cached is not None and cached[0] == n:
+            return cached[1]
+        import numbers
+        import numpy as _np
+        ids = self.local_ids
+        if not ids:
+            kind = 0
+        elif all(isinstance(i, (numbers.Integral, _np.integer)) and not isinstance(i, (bool, _np.bool_)) and -2 ** 63 <= int(i) < 2 ** 63
+                 for i in ids):
+            kind = 1
+        elif all(isinstance(i, str) for i in ids):
+            kind = 2
+        else:
+            kind = 3
+        self._id_kind_cache = (n, kind)
+        return kind
+
     def resolve_ids(self, labels) -> list:
         """Global row labels (nested lists / array, -1 = padding) -> external ids, resolved on the ranks that own the rows.
         Collective: every rank must call it (with its own, possibly empty, labels).  Tensor collectives only: the requested rows travel as
@@ -134,18 +159,23 @@ class ShardedFlatIndexer:
                 else:
                     want[bisect.bisect_right(self.offsets, g) - 1].add(g)
         want = [sorted(w) for w in want]
-        # what kind of ids does the index hold?  (agreed globally: a rank without rows has no opinion)
-        kind = 0 if not self.local_ids else (1 if all(isinstance(i, (int,)) and not isinstance(i, bool) for i in self.local_ids[:64]) else
-                                             2 if all(isinstance(i, str) for i in self.local_ids[:64]) else 3)
-        kt = torch.tensor([kind], dtype=torch.int64, device=self._tensor_device())
+        # what kind of ids does the index hold?  Decided from ALL local ids and agreed globally BEFORE the first payload collective
+        # (a rank without rows has no opinion; ranks that disagree — ints here, strings there — or hold anything else take the pickling
+        # path together: a wire format picked from a sample could raise on one rank in the middle of the all-to-all sequence while the
+        # others block in the collective)
+        kind = self._local_id_kind()
+        kt = torch.zeros(4, dtype=torch.int64, device=self._tensor_device())
+        kt[kind] = 1
         dist.all_reduce(kt, op=dist.ReduceOp.MAX, group=self.group)
-        kind = int(kt.item())
+        present = [j for j in (1, 2, 3) if int(kt[j]) > 0]
+        kind = present[0] if len(present) == 1 else (3 if present else 0)
         lo = self.offsets[self.rank]
         if kind in (1, 2):
             asked = self._exchange_rows([torch.tensor(w, dtype=torch.int64) for w in want])      # asked[r]: rows rank r wants from me
             mine = [[self.local_ids[int(g) - lo] for g in a.tolist()] for a in asked]
             table = {}
             if kind == 1:
+                mine = [[int(i) for i in m] for m in mine]          # (numpy integers travel as int64 too)
                 got = self._exchange_rows([torch.tensor(m, dtype=torch.int64) for m in mine])
                 for r in range(self.world):
                     table.update(zip(want[r], got[r].tolist()))
@@ -174,8 +204,10 @@ class ShardedFlatIndexer:
     def _gather_queries(self, q: torch.Tensor) -> Tuple[torch.Tensor, List[int]]:
         # query counts travel as one small tensor (no pickling; one host sync)
         nccl = dist.get_backend(self.group) == 'nccl'
-        mine = torch.tensor([q.shape[0]], dtype=torch.int64, device=q.device)
-        if nccl:
+        mine = torch.tensor([q.shape[0]], dtype=torch.int64, device=q.device) if not self.equal_query_counts else None
+        if self.equal_query_counts:
+            counts = [int(q.shape[0])] * self.world
+        elif nccl:
             call = torch.empty(self.world, dtype=torch.int64, device=q.device)
             dist.all_gather_into_tensor(call, mine, group=self.group)
             counts = [int(c) for c in call.tolist()]
@@ -240,6 +272,9 @@ class ShardedFlatIndexer:
                 tau = ix.search_begin(q_all, k)
             if self.world > 1:
                 self._all_reduce_max(tau)
+            mx = max(counts)
+            if (self.exchange == 'all_to_all' and self._merge is _hip_merge and min(counts) == mx and mx > 0 and q_all.is_cuda):
+                return self._finish_blocked(ix, tau, mx, k, out)
             s, l = ix.search_finish(tau)
         l = torch.where(l >= 0, l + self.offsets[self.rank], l)          # local row -> global row, padding stays -1
         starts = [0]
@@ -274,6 +309,35 @@ class ShardedFlatIndexer:
             torch.cuda.current_stream().synchronize()
             return res
         return self._merge(part_s.contiguous(), part_l.contiguous(), k)
+
+    def _finish_blocked(self, ix, tau, mx: int, k: int, out):
+        """Equal query slices: the re-score kernel writes every destination rank's block of the send buffer (scores + global labels),
+        ONE all-to-all moves the blocks, the merge kernel reads the receive buffer in place — no torch op touches the lists."""
+        lib = L.load_library()
+        lab_off = (mx * k * 4 + 15) // 16 * 16
+        block_bytes = (lab_off + mx * k * 8 + 15) // 16 * 16
+        dev = tau.device
+        send = self._blocks.get((self.world, block_bytes))
+        if send is None or send.device != dev:
+            send = torch.empty((self.world, block_bytes), dtype=torch.uint8, device=dev)
+            self._blocks = {(self.world, block_bytes): send}
+        ix.search_finish_blocked(tau, send, mx, block_bytes, self.offsets[self.rank])
+        recv = self._all_to_all(send)
+        if out is not None:
+            out_s, out_l = out
+            if not (out_s.is_pinned() and out_l.is_pinned() and out_s.is_contiguous() and out_l.is_contiguous()
+                    and tuple(out_s.shape) == (mx, k) and tuple(out_l.shape) == (mx, k)
+                    and out_s.dtype == torch.float32 and out_l.dtype == torch.int64):
+                raise ValueError('out must be pinned contiguous (float32, int64) host tensors of shape [nq, k]')
+        else:
+            out_s = torch.empty((mx, k), dtype=torch.float32, device=dev)
+            out_l = torch.empty((mx, k), dtype=torch.int64, device=dev)
+        L.check(lib.ldot_merge_topk_blocked(ctypes.c_void_p(recv.data_ptr()), self.world, mx, block_bytes, mx, k, k,
+                                            ctypes.c_void_p(out_s.data_ptr()), ctypes.c_void_p(out_l.data_ptr()),
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        if out is not None:
+            torch.cuda.current_stream().synchronize()
+        return out_s, out_l
 
     def search_knn(self, local_queries, top_docs: int):
         """DenseIndexer-style result for the local queries: [(ids, scores ndarray)]."""

@@ -28,7 +28,15 @@ CASES = {2: dict(bounds=[0, 610, 1500], qb=[0, 11, 37]),
 
 
 def _mk_id(kind, i):
+    if kind == 'mixed':          # integers on the first rank of the 2-rank case, strings on the second: the ranks must fall back TOGETHER
+        return (7 * i + 3) if i < 610 else f'id{i}'
+    if kind == 'npint':          # numpy integers travel as int64 like Python ints (and come back as Python ints)
+        return np.int64(7 * i + 3)
     return f'id{i}' if kind == 'str' else (7 * i + 3) if kind == 'int' else ('id', i)
+
+
+def _expect_repr(kind, i):
+    return repr(7 * i + 3) if kind == 'npint' else repr(_mk_id(kind, i))
 
 
 def _worker(rank, world, port, out_dir, exchange, gather_ids, id_kind='str'):
@@ -74,7 +82,8 @@ def _worker(rank, world, port, out_dir, exchange, gather_ids, id_kind='str'):
 
 @pytest.mark.parametrize('world,exchange,gather_ids,id_kind', [(2, 'all_to_all', False, 'str'), (3, 'all_to_all', False, 'str'),
                                                                 (2, 'all_gather', True, 'str'), (3, 'all_gather', False, 'int'),
-                                                                (3, 'all_to_all', False, 'tuple')])
+                                                                (3, 'all_to_all', False, 'tuple'), (2, 'all_to_all', False, 'mixed'),
+                                                                (2, 'all_to_all', False, 'npint')])
 def test_sharded_search_gloo(tmp_path, world, exchange, gather_ids, id_kind):
     # (resolve_ids: string ids travel as UTF-8 bytes, integer ids as int64 — tensor all-to-alls —, other id types are pickled)
     from oracle import oracle_np as O
@@ -93,4 +102,4 @@ def test_sharded_search_gloo(tmp_path, world, exchange, gather_ids, id_kind):
         assert a['l'].shape == (qb[r + 1] - qb[r], k)
         np.testing.assert_array_equal(a['l'], el[qb[r]:qb[r + 1]])
         np.testing.assert_allclose(a['s'], es[qb[r]:qb[r + 1]], rtol=1e-6, atol=1e-6)
-        assert [list(row) for row in a['ids']] == [[repr(_mk_id(id_kind, int(i))) for i in row] for row in el[qb[r]:qb[r + 1]]]
+        assert [list(row) for row in a['ids']] == [[_expect_repr(id_kind, int(i)) for i in row] for row in el[qb[r]:qb[r + 1]]]

@@ -95,6 +95,41 @@ def test_s3_config5_shape_vs_fp64_oracle(n1, n2, nh, w):
     np.testing.assert_allclose(tc2.grad.cpu().numpy(), gr.astype(np.float64).T @ q, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('n1,n2,d,w', [(1, 1, 1, 0.0), (31, 5, 17, 0.0), (33, 100, 100, 0.25), (70, 64, 32, 0.0), (64, 97, 96, 0.1),
+                                      (129, 1000, 770, 0.0), (5, 1537, 768, 0.1)])
+def test_direct_kernel_edge_shapes_vs_fp64_oracle(n1, n2, d, w):
+    """The 32 x 32-tile direct GEMM + fused NLL forward (csrc/loss.hip: sgemm_direct_kernel) at shapes that are not multiples of its
+    tile, of its K chunk (32) or of a float4, with and without the caption mix; ties on the row maximum resolve to the first column."""
+    import torch
+    from lightningdot_amd.loss import BiEncoderNllLoss
+    rng = np.random.default_rng(1000 * n1 + n2 + d)
+    q = (rng.standard_normal((n1, d)) * 0.3).astype(np.float32)
+    ctx = (rng.standard_normal((n2, d)) * 0.3).astype(np.float32)
+    if n2 > 40:                      # two identical context rows: equal scores in columns 3 and 37 (different column tiles)
+        ctx[37] = ctx[3]
+    cap = (rng.standard_normal((n2, d)) * 0.3).astype(np.float32) if w else None
+    if cap is not None and n2 > 40:
+        cap[37] = cap[3]
+    pos = [int(v) for v in rng.integers(0, n2, n1)]
+    for reduction in ('mean', 'none'):
+        tq, tc = _cuda(q, True), _cuda(ctx, True)
+        tcap = _cuda(cap, True) if w else None
+        loss, correct, scores = BiEncoderNllLoss().calc(tq, tc, tcap, pos, None, w if w else 0.1, None, reduction)
+        l64, c64, s64 = O.biencoder_nll_loss(q, ctx, cap, pos, w if w else 0.1, reduction, dtype=np.float64)
+        np.testing.assert_allclose(scores.detach().cpu().numpy(), s64, rtol=0, atol=5e-5)
+        np.testing.assert_allclose(loss.detach().cpu().numpy(), l64, rtol=1e-5, atol=1e-4)
+        # the oracle's arg-max is taken on fp64 scores: count with the SAME first-maximum rule on the returned fp32 scores
+        s32 = scores.detach().cpu().numpy()
+        assert int(correct.item()) == int((s32.argmax(axis=1) == np.asarray(pos)).sum())
+        gl = rng.standard_normal(loss.shape).astype(np.float32)
+        loss.backward(_cuda(gl).reshape(loss.shape))
+        dq, dctx, dcap = O.biencoder_nll_grads(q, ctx, cap, pos, w if w else 0.1, reduction, grad_loss=gl)
+        np.testing.assert_allclose(tq.grad.cpu().numpy(), dq, rtol=2e-4, atol=2e-6)
+        np.testing.assert_allclose(tc.grad.cpu().numpy(), dctx, rtol=2e-4, atol=2e-6)
+        if w:
+            np.testing.assert_allclose(tcap.grad.cpu().numpy(), dcap, rtol=2e-4, atol=2e-6)
+
+
 def test_loss_rejects_cpu_tensors():
     import torch
     from lightningdot_amd import LdotError

@@ -218,3 +218,7 @@ def test_reranker_candidate_export_on_device_equals_host_loops():
     got_tr_u = rerank_recall_device(devr['labels_txt'][sel.cuda()], mat.T[q_rows[sel]].contiguous().cuda(), devr['pos_txt'][sel.cuda()],
                                     denominator=150)
     assert got_tr_u == want_tr and all(abs(got_tr[t][k] - 5 * want_tr[t][k]) < 1e-9 for t in got_tr for k in (1, 5, 10))
+    # the selection + denominator of the reference's loop (distinct image ids, last occurrence) come with the candidates
+    assert devr['img_unique_ids'] == list(uniq_last.keys()) and devr['img_unique_rows'].cpu().tolist() == list(uniq_last.values())
+    got_tr_r = rerank_recall_device(devr['labels_txt'], mat.T[q_rows].contiguous().cuda(), devr['pos_txt'], rows=devr['img_unique_rows'])
+    assert got_tr_r == want_tr
