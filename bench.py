@@ -60,6 +60,7 @@ def main():
     ap.add_argument('--split-bf16', action='store_true',
                     help='LDOT_OPT_PRECISION=1: split-bf16 candidate pass (3 MFMA products per element); not the headline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary workloads measured after the timed region')
     ap.add_argument('--no-kernel-events', action='store_true',
                     help='measurement aid: do not bracket the score kernels with HIP events (the roofline object is then empty); '
                          'shows what the events themselves cost the timed region')
@@ -269,9 +270,102 @@ def main():
         out['cpu_baseline'], out['parity_vs_cpu_fp32'] = cpu_baseline(x_local, q_all, K, args.cpu_sample_queries,
                                                                       s_np, l_np)
         # (the CPU figures at the S2 shapes are part of `bench.py --workload flickr|coco`: each of those lines carries its own)
+    if not sharded and not args.no_secondary:
+        try:
+            out['secondary'] = secondary_metrics(dev, flat, D, K)
+        except Exception as e:                       # the headline line must not depend on the secondary shapes
+            out['secondary'] = {'error': f'{type(e).__name__}: {e}'}
     print(json.dumps(out), flush=True)
     if sharded:
         dist.destroy_process_group()
+
+
+def _time_ms(fn, n, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def secondary_metrics(dev, flat_main, D, K):
+    """The other workloads of BASELINE.json / SURVEY 8d on the same box, measured AFTER the timed region so that the line the driver
+    records carries them (each a few tens of milliseconds of GPU work; none of them enters `value`):
+      * retrieval evaluation at the Flickr30k-1k and MSCOCO-5k shapes (configs[1] / [2], `--workload flickr|coco` in full): ms per
+        evaluation = text->image over all captions + image->text over every image id once, results on the host;
+      * serving latency (dvl/utils.py:204-211 retrieve_query): 1 and 64 queries over the headline index and over 123 287 rows (the
+        reference demo's COCO index), device query -> pinned host results, with the fraction of the 8 TB/s HBM peak the WHOLE search
+        reaches (algorithmic bytes = the bf16 index read once);
+      * the approximate index (f-4) over 123 287 clustered rows: one query, 32 probed lists, recall@10 against the exact top-10."""
+    from lightningdot_amd.indexer import DenseFlatIndexer, FlatIPIndex
+    from lightningdot_amd.synthetic import s2_embeddings
+    sec = {}
+    # ---- S2 shapes -------------------------------------------------------------------------------------------
+    for name, n_img in (('flickr_1k', 1000), ('coco_5k', 5000)):
+        img, txt = s2_embeddings(n_img, D, 5, seed=7, device=dev)
+        ix_img, ix_txt = FlatIPIndex(D), FlatIPIndex(D)
+        ix_img.add(img)
+        ix_txt.add(txt)
+        hs = [torch.empty((n, K), dtype=torch.float32).pin_memory() for n in (txt.shape[0], n_img)]
+        hl = [torch.empty((n, K), dtype=torch.int64).pin_memory() for n in (txt.shape[0], n_img)]
+
+        def step():
+            ix_img.search_into(txt, K, hs[0], hl[0])
+            ix_txt.search_into(img, K, hs[1], hl[1])
+        ms = _time_ms(step, 10)
+        gt = torch.arange(txt.shape[0]) // 5
+        sec[name] = {'ms_per_evaluation': ms, 'queries_searched': int(txt.shape[0] + n_img),
+                     'queries_per_s': (txt.shape[0] + n_img) / ms * 1e3,
+                     'recall_t2i@1': float((hl[0][:, 0] == gt).float().mean()),
+                     'recall_i2t@1': float(((hl[1][:, 0] // 5) == torch.arange(n_img)).float().mean())}
+        del ix_img, ix_txt
+    # ---- serving latency ---------------------------------------------------------------------------------------
+    g = torch.Generator(device='cpu').manual_seed(99)
+    x_small = torch.randn(123_287, D, generator=g).to(dev)
+    small = FlatIPIndex(D)
+    small.add(x_small)
+    serving = {}
+    for label, ix, n in (('headline_index', flat_main, flat_main.ntotal), ('123k', small, 123_287)):
+        for nq in (1, 64):
+            rows = (torch.arange(nq, dtype=torch.int64) * 7919) % n
+            base = x_small[rows.to(dev)] if ix is small else None
+            if base is None:       # rows of the headline index: fetched through the library (the bench does not keep the index tensor)
+                base = torch.from_numpy(np.concatenate([ix.get_rows(int(r), 1) for r in rows.tolist()])).to(dev)
+            q = base + 0.5 * torch.randn(nq, D, generator=g).to(dev)
+            hs_ = torch.empty((nq, K), dtype=torch.float32).pin_memory()
+            hl_ = torch.empty((nq, K), dtype=torch.int64).pin_memory()
+            ms = _time_ms(lambda: ix.search_into(q, K, hs_, hl_), 50)
+            serving[f'{nq}q_x_{label}'] = {'rows': int(n), 'ms': ms, 'hbm_frac_whole_search': n * D * 2 / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                                           'rank1_ok': bool((hl_[:, 0] == rows).all())}
+    sec['serving_latency'] = serving
+    # ---- approximate index ---------------------------------------------------------------------------------------
+    from lightningdot_amd.ivf import DenseIVFFlatIndexer
+    gc = torch.Generator(device=dev).manual_seed(0)
+    cent = 0.2 * torch.randn(500, D, device=dev, generator=gc)
+    xc = cent[torch.randint(0, 500, (123_287,), device=dev, generator=gc)] + 0.5 * torch.randn(123_287, D, device=dev, generator=gc)
+    qc = cent[torch.randint(0, 500, (256,), device=dev, generator=gc)] + 0.5 * torch.randn(256, D, device=dev, generator=gc)
+    exact = DenseFlatIndexer(D)
+    exact.index_tensor(list(range(123_287)), xc)
+    _, el = exact.search_knn_tensors(qc, 10)
+    t0 = time.perf_counter()
+    ivf = DenseIVFFlatIndexer(D, nprobe=32)
+    ivf.index_tensor(list(range(123_287)), xc)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    inv = torch.as_tensor(ivf.index_id_to_db_id, device=dev)
+    _, l = ivf.search_knn_tensors(qc, 10, 32, exact_when_cheaper=False)
+    orig = torch.where(l >= 0, inv[l.clamp_min(0)], l)
+    rec = float(sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(orig, el)) / (10 * qc.shape[0]))
+    q1 = qc[:1].contiguous()
+    ms_ivf = _time_ms(lambda: ivf.search_knn_tensors(q1, 10, 32, exact_when_cheaper=False), 50)
+    ms_exact = _time_ms(lambda: exact.search_knn_tensors(q1, 10), 50)
+    sec['ivf_123k'] = {'nlist': int(ivf.nlist), 'nprobe': 32, 'ms_1_query': ms_ivf, 'ms_1_query_exact_flat': ms_exact,
+                       'recall@10_vs_exact': rec, 'build_s': build_s,
+                       'data': '123 287 rows = 500 overlapping Gaussian clusters (centroid spread 0.2, noise 0.5), 768-d'}
+    return sec
 
 
 PEAK_HBM_GBPS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured with a float4 copy)

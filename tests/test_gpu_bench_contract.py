@@ -34,6 +34,16 @@ def test_headline_line_has_the_contract_fields():
     c = d['cpu_baseline']
     assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == 'queries/s' and c['sample']
     assert d['recall@1'] == 1.0 and d['overflowed_queries'] == 0
+    # the secondary workloads ride on the same line (measured after the timed region; none of them enters `value`)
+    sec = d['secondary']
+    assert 'error' not in sec, sec
+    for name in ('flickr_1k', 'coco_5k'):
+        assert sec[name]['ms_per_evaluation'] > 0 and sec[name]['recall_t2i@1'] == 1.0 and sec[name]['recall_i2t@1'] == 1.0
+    for key in ('1q_x_headline_index', '64q_x_headline_index', '1q_x_123k', '64q_x_123k'):
+        e = sec['serving_latency'][key]
+        assert e['ms'] > 0 and 0.0 < e['hbm_frac_whole_search'] < 1.0 and e['rank1_ok']
+    iv = sec['ivf_123k']
+    assert iv['ms_1_query'] > 0 and iv['recall@10_vs_exact'] > 0.8 and iv['nprobe'] == 32
 
 
 def test_serving_line_reports_an_hbm_roofline():
