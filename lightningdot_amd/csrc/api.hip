@@ -130,6 +130,10 @@ struct ldot_index {
     // ... or in three (ldot_index_search_warmup / _scan / _finish, the sharded search): what _scan needs to know.  split_path: 0 none
     // pending, 1 narrow search, 2 dense scan, 3 fused scan whose warm-up has run
     int split_path = 0, split_parts = 1;
+    // optimistic thresholds (LDOT_OPT_OPTIMISTIC, fused_rest_chunk): what the filter compares with while the guaranteed threshold
+    // (w_tau: the list's own k'-th best) is still far below the final one
+    int optimistic = 1;
+    DevBuf w_tau_opt;
     int cur_parts = 1;   // shards of the search in progress (1 = plain search): sizes the warm-up of a fused scan, fused_warm_rows
 };
 
@@ -211,6 +215,7 @@ int ldot_index_destroy(ldot_index_t* ix) {
     for (DevBuf* b : bufs) b->release();
     ix->w_over_sum.release();
     ix->w_qcnt.release();
+    ix->w_tau_opt.release();
     ix->w_unproven.release();
     ix->w_norm.release();
     ix->w_nmax.release();
@@ -315,6 +320,10 @@ int ldot_index_set_option(ldot_index_t* ix, int option, int64_t value) {
             LDOT_HIP_CHECK(hipDeviceSynchronize());
             return index_reserve(ix, std::max<int64_t>(value, ix->ntotal), nullptr);
         }
+        case LDOT_OPT_OPTIMISTIC:
+            LDOT_REQUIRE(value == 0 || value == 1, LDOT_EINVAL, "LDOT_OPT_OPTIMISTIC is 0 or 1");
+            ix->optimistic = (int)value;
+            return LDOT_OK;
         case LDOT_OPT_GROWTH_PCT:
             LDOT_REQUIRE(value >= 5 && value <= 10000, LDOT_EINVAL, "growth_pct must be in [5, 10000]");
             ix->growth_pct = (int)value;
@@ -670,8 +679,10 @@ constexpr int64_t kFewBlockGrowthPct = 1600;   // launch growth with ONE query b
 // one fused-filter launch over index rows [r, r + len) for the queries [q0, q0 + nq) + the pool select that folds its records into
 // the running lists and raises the thresholds
 static int fused_launch_and_select(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_pad, int kp, int64_t r, int64_t len,
-                                   hipStream_t st) {
+                                   hipStream_t st, float* tau_opt = nullptr, int opt_m_next = 0) {
     float* tau = (float*)ix->w_tau.p + q0;
+    // (the optimistic scan filters with w_tau_opt; the selects keep the guaranteed w_tau and refresh w_tau_opt for the next launch)
+    const float* filter_tau = tau_opt ? tau_opt : tau;
     float* ls = (float*)ix->w_ls.p + q0 * kp;
     int32_t* li = (int32_t*)ix->w_li.p + q0 * kp;
     const uint16_t* q16 = (const uint16_t*)ix->w_q16b.p + q0 * ix->ld16();
@@ -680,7 +691,7 @@ static int fused_launch_and_select(ldot_index* ix, int64_t q0, int64_t nq, int64
     const int64_t nslices = 256 / qg, nsubs = kPoolSubsPerSlice * nslices;
     int rc;
     prof_begin(ix, st, 2.0 * nq * len * ix->d, (double)len * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * kp * 8);
-    rc = launch_score_filter(ix->x16b, ix->ld16(), r, len, q16, ix->ld16(), nq_pad, (int)ix->ld16(), tau, (uint4*)ix->w_pool.p,
+    rc = launch_score_filter(ix->x16b, ix->ld16(), r, len, q16, ix->ld16(), nq_pad, (int)ix->ld16(), filter_tau, (uint4*)ix->w_pool.p,
                              (int32_t*)ix->w_pool_cnt.p, st);
     prof_end(ix, st);
     if (rc) return rc;
@@ -698,7 +709,7 @@ static int fused_launch_and_select(ldot_index* ix, int64_t q0, int64_t nq, int64
         return launch_merge_parts_into_lists(ps, pl, G, nq, kp, ls, li, tau, st);
     }
     return launch_select_pools((const uint4*)ix->w_pool.p, (const int32_t*)ix->w_pool_cnt.p, (int)nsubs, nq, (int32_t)ix->ntotal, ls,
-                               li, kp, tau, over, (int32_t*)ix->w_over_sum.p, (int32_t*)ix->w_qcnt.p + q0, st);
+                               li, kp, tau, over, (int32_t*)ix->w_over_sum.p, (int32_t*)ix->w_qcnt.p + q0, st, tau_opt, opt_m_next);
 }
 
 // candidate pools + counters for nq_pad queries (the counters are all-zero between searches)
@@ -758,10 +769,84 @@ static int fused_warm_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_p
     return dense_scan_all(ix, nq, 0, warm, kp, (float*)ix->w_tau.p, nq <= 64, st, q0);
 }
 
+// ---- optimistic thresholds (round 4) ---------------------------------------------------------------------------------------------------
+// The guaranteed threshold of a query — the k'-th best score among the r rows scanned so far — admits k' / r of the following rows:
+// k' ln(N / warm) ~ 700 records per query over a 1M-row scan in the limit of continuous refresh, ~1150 with six launches, a third of
+// them in the first launch.  But the FINAL threshold is known in distribution long before: if the rows are exchangeable (no order in the
+// index that correlates with the query), the number of the index's k' best rows among the first r is Poisson(k' r / N), so the m-th best
+// score seen so far is BELOW the final k'-th best with probability 1 - P(Poisson(k' r / N) >= m).  The scan therefore filters with
+// tau_opt = the m(r)-th best so far, m(r) = the smallest m with P(Poisson(k' r / N) >= m) <= kOptEps (8 at r = 4096 of 1M rows, 18 at
+// 28 672, 60 at 225 280, k' from ~620 000 on): ~350 records per query in FOUR launches (each as long as the pool bound and the
+// launch-length knee of DESIGN 5.2b allow) instead of ~1150 in six.
+// It stays exact without the assumption: every row was admitted iff it scored >= the tau_opt in force, so a query whose final list holds
+// k' rows at or above its last (largest) tau_opt has lost nothing that belongs to its top k' — verify_tau_opt_kernel checks exactly that
+// and flags the others (rows stored in an order that front-loads a query's best rows, e.g. its own cluster first), which redo_flagged
+// searches again on guaranteed thresholds like pool overflows.  The guaranteed threshold w_tau (k'-th best of the admitted rows, a lower
+// bound of the k'-th best of all rows seen) keeps being maintained by the selects: the recovery, LDOT_OPT_VERIFY and the sharded
+// exchange use it.
+constexpr double kOptEps = 1e-7;                 // per query and launch; 10 000 queries x 4 launches: one redo in ~250 searches
+constexpr int64_t kOptMaxLaunchRows = 393216;    // launches beyond ~0.6 GB of rows run slower per row
+constexpr int64_t kOptGrowthX = 7;               // a launch covers up to 7x the rows already scanned
+
+static int optimistic_m(int kp, int64_t r, int64_t n, double eps) {
+    const double x = (double)kp * (double)r / (double)n;
+    double term = exp(-x), cdf = 0.0;            // P(Poisson(x) < m), accumulated term by term
+    for (int m = 1; m < kp; ++m) {
+        cdf += term;                             // now cdf = P(Poisson < m)
+        if (1.0 - cdf <= eps) return m;
+        term *= x / m;
+    }
+    return kp;
+}
+
+static int fused_rest_chunk_optimistic(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_pad, int kp, hipStream_t st) {
+    int rc;
+    constexpr int64_t kFill = kPoolCap / 4;
+    const int64_t bm = fused_tile_rows();
+    const int qg = fused_query_group(nq_pad);
+    const int64_t nslices = 256 / qg, nsubs = kPoolSubsPerSlice * nslices, unit = bm * nslices;
+    const int64_t warm = fused_warm_rows(ix, nq, nq_pad, kp), N = ix->ntotal;
+    if (warm >= N) return LDOT_OK;
+    if ((rc = fused_pools(ix, nq_pad, st))) return rc;
+    float* tau = (float*)ix->w_tau.p + q0;
+    float* tau_opt = (float*)ix->w_tau_opt.p + q0;
+    const float* ls = (const float*)ix->w_ls.p + q0 * kp;
+    const int32_t* li = (const int32_t*)ix->w_li.p + q0 * kp;
+    if ((rc = launch_init_tau_opt(tau_opt, nq, nq_pad, st))) return rc;
+    double eps = kOptEps;
+    int64_t growth_x = kOptGrowthX, max_rows = kOptMaxLaunchRows;
+#ifdef LDOT_ABLATION
+    if (const char* e = getenv("LDOT_DEBUG_OPT_EPS")) eps = atof(e);
+    if (const char* e = getenv("LDOT_DEBUG_OPT_GROWTHX")) growth_x = atoll(e);
+    if (const char* e = getenv("LDOT_DEBUG_OPT_MAXROWS")) max_rows = atoll(e);
+#endif
+    int64_t r = warm;
+    // the first thresholds come from the warm-up's list; every pool select then leaves the next launch's behind (and the last one checks)
+    if ((rc = launch_tau_opt(ls, li, kp, nq, optimistic_m(kp, r, N, eps), tau, tau_opt, st))) return rc;
+    while (r < N) {
+        const int m = optimistic_m(kp, r, N, eps);
+        // expected records per query of a launch over len rows: len m / r, kept <= kFill per sub-pool like the guaranteed schedule's bound
+        int64_t len = std::min<int64_t>(std::min<int64_t>(r * growth_x, max_rows), r * kFill * nsubs / m);
+        len = std::max<int64_t>(len / unit * unit, unit);
+        len = std::min(len, N - r);
+        if (N - r - len < len / 4 && N - r <= max_rows + unit) len = N - r;   // no short tail launch
+        const int m_next = r + len < N ? optimistic_m(kp, r + len, N, eps) : 0;   // (0: the last select verifies)
+        if ((rc = fused_launch_and_select(ix, q0, nq, nq_pad, kp, r, len, st, tau_opt, m_next))) return rc;
+        ix->stats[3] += len * nq;
+        r += len;
+    }
+    ix->pools_clean = true;
+    return LDOT_OK;
+}
+
 // the fused launches after the warm-up.  parts > 1 (sharded search): the thresholds were raised to a bound the `parts` ranks agreed on
 // after their warm-ups (ldot_index_search_scan) — it is worth about parts x warm scanned rows, so the pool bound allows that much longer
 // launches, and one long launch on it beats two that each pay a pool select.
 static int fused_rest_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_pad, int kp, int parts, hipStream_t st) {
+    // large batches of a plain search: optimistic thresholds (few-query searches have their own launch schedule, sharded searches
+    // their agreed thresholds)
+    if (ix->optimistic && parts == 1 && ix->cur_parts == 1 && nq > kFewSelectMaxQueries)
+        return fused_rest_chunk_optimistic(ix, q0, nq, nq_pad, kp, st);
     int rc;
     constexpr int64_t kFill = kPoolCap / 4;
     const int64_t bm = fused_tile_rows();
@@ -816,6 +901,7 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
         if ((rc = ix->w_over.ensure(over_bytes))) return rc;
         if ((rc = ix->w_over_sum.ensure(16))) return rc;
         if ((rc = ix->w_qcnt.ensure((size_t)nq_pad * 4))) return rc;
+        if ((rc = ix->w_tau_opt.ensure((size_t)nq_pad * 4))) return rc;
         LDOT_HIP_CHECK(hipMemsetAsync(ix->w_qcnt.p, 0, (size_t)nq_pad * 4, st));
         ix->qcnt_n = nq;
         if (!ix->h_over_sum) LDOT_HIP_CHECK(hipHostMalloc((void**)&ix->h_over_sum, 16));

@@ -112,9 +112,11 @@ int launch_parts_to_lists(const float* out_s, const int64_t* out_l, int64_t n, f
                           float* tau, hipStream_t st);
 // row_end: records may carry rows of the zero padding behind the last index row (>= row_end): dropped here.
 // qcnt[q] (optional) += the number of records read for q.  overflow_flags[q] is set (and *over_sum incremented once per query) when one of q's sub-pools held more than kPoolCap records.
+// tau_opt / opt_m (optimistic scan, large batches only): tau_opt[q] = max(tau_opt[q], opt_m-th best of the new list) for the next launch;
+// opt_m = 0: the end-of-scan check instead (the list's own threshold must reach tau_opt[q], else the query is flagged like an overflow)
 int launch_select_pools(const uint4* pool, const int32_t* pool_cnt, int nsubs, int64_t nq, int32_t row_end, float* list_s,
                         int32_t* list_i, int kp, float* tau, int32_t* overflow_flags, int32_t* over_sum, int32_t* qcnt,
-                        hipStream_t st);
+                        hipStream_t st, float* tau_opt = nullptr, int opt_m = 0);
 // few queries x many sub-pools: G waves per query write partial top-kp lists part_[sl][g][q][kp] (merged by launch_select_lists
 // together with the running list); kp + 512 <= 1024
 int launch_select_pools_parts(const uint4* pool, const int32_t* pool_cnt, int nsubs, int64_t nq, int G, int32_t row_end, int kp,
@@ -125,6 +127,10 @@ int launch_select_pools_parts(const uint4* pool, const int32_t* pool_cnt, int ns
 int launch_list_stats(const float* list_s, const int32_t* list_i, int kp, int64_t nq, int m, const float* tau, float* stat, hipStream_t st);
 int launch_neutral_stats(int64_t nq, float* stat, hipStream_t st);
 int launch_apply_stats(int64_t nq, const float* stat, float* tau, hipStream_t st);
+// optimistic thresholds of the fused scan: tau_opt = max(tau_opt, m-th best of the list); initial values; end-of-scan verification
+int launch_tau_opt(const float* list_s, const int32_t* list_i, int kp, int64_t nq, int m, const float* tau, float* tau_opt, hipStream_t st);
+int launch_init_tau_opt(float* tau_opt, int64_t nq, int64_t nq_pad, hipStream_t st);
+int launch_verify_tau_opt(const float* tau, const float* tau_opt, int64_t nq, int32_t* overflow, int32_t* over_sum, hipStream_t st);
 int launch_merge_parts_into_lists(const float* part_s, const int64_t* part_l, int nparts, int64_t nq, int kp, float* list_s,
                                   int32_t* list_i, float* tau, hipStream_t st);
 // generic merge of explicit candidate lists: cand_[sl] is [nq][ncand] (labels int64, -1 = empty) -> [nq][k_out]

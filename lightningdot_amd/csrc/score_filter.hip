@@ -192,6 +192,29 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
     sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)l_t * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
     sb.rsrc = ring_make_rsrc_n(Q16 + (int64_t)(qsub + l_q * qg) * kRBN * ldq_b, kRBN * ldq_b);
     int64_t issued = 0;
+    // VAR & 256 (experiment): L2 touch-ahead of the row panel.  The eight workgroups of an XCD that multiply the same row tile with
+    // different query blocks all fetch it within microseconds of each other; whoever comes first takes the HBM latency in its
+    // 4-slab LDS ring.  Here the workgroup with qsub == 0 requests every 128-byte line of the row slab kTouchLead slabs AHEAD of the load
+    // cursor (waves 0..2, one line per lane, 192 lines = the 24 KiB slab) with a plain load whose result nobody reads, so that the
+    // direct-to-LDS loads of all eight find the lines in L2.
+    constexpr bool kTouch = (VAR & 256) != 0;
+    constexpr int kTouchLead = 6;
+    const bool toucher = kTouch && qsub == 0 && wave < 3;
+    int t_t = t0, t_k = kTouchLead;    // touch cursor: (row tile, slab) — nk = 24 > kTouchLead for the shapes this experiment runs on
+    uint32_t touch_sink = 0;
+    auto touch = [&]() {
+        if (toucher) {
+            const uint32_t ln = lane_now();
+            const uint32_t voff = ((uint32_t)wave * 8u + (ln >> 3)) * 16u * (uint32_t)ldx_b + (ln & 7u) * 128u;
+            const char* base = X16 + (row0 + (int64_t)t_t * Geo::kBM) * ldx_b + (int64_t)t_k * 1024;
+            asm volatile("global_load_dword %0, %1, %2" : "+v"(touch_sink) : "v"(voff), "s"(base) : "memory");
+        }
+        if (++t_k == nk) {
+            t_k = 0;
+            t_t += nslices;
+            while (t_t >= ntiles) t_t -= ntiles;
+        }
+    };
     // one slab = kLoads pieces per wave (3 of the row panel, 2 of the query panel); issue() sends them into the stage of slab
     // `issued` as a burst and moves the cursor on
     auto issue = [&]() {
@@ -205,6 +228,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(sb.rsrc, (rg_lptr_t)(st + Geo::kAOpBytes + ((j - Geo::kALoads) * 8 + wave) * 1024),
                                                          16, vo, k0b + (j - Geo::kALoads) * jstep, 0, 0);
         }
+        if (kTouch) touch();
         ++issued;
         if (issued < S) {
             if (++l_k == nk) {   // next unit of this stream
@@ -225,7 +249,10 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
     issue();
     issue();
     issue();
-    wait_vmcnt<3 * Geo::kLoads>();
+    if (toucher)
+        wait_vmcnt<3 * Geo::kLoads + 4>();   // (a toucher's counter also carries its touches: four of them are younger than slab 0's pieces)
+    else
+        wait_vmcnt<3 * Geo::kLoads>();
     __builtin_amdgcn_s_barrier();
 
     // ---- compute side --------------------------------------------------------------------------------------------------------
@@ -265,7 +292,10 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
                 // every fragment of stage s is in registers or consumed (its stage may be refilled), slab s + 1 must have landed
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of slab s are complete (WAR on its stage)
-                wait_vmcnt<2 * Geo::kLoads>();                       // slab s+1 has landed (this thread's part) ...
+                if (kTouch && toucher)
+                    wait_vmcnt<2 * Geo::kLoads + 3>();               // (+ the three touches issued behind slab s+1's pieces)
+                else
+                    wait_vmcnt<2 * Geo::kLoads>();                   // slab s+1 has landed (this thread's part) ...
                 __builtin_amdgcn_s_barrier();                        // ... and everybody else's
             }
 #pragma unroll
@@ -357,6 +387,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
     }
     store_counts(cur_q);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing dummy loads must land before the LDS is released
+    if (kTouch) asm volatile("" ::"v"(touch_sink));    // (the touches' destination register stays allocated until they have landed)
 }
 
 // index rows per fused tile (the host sizes launches and the row padding of the index with it)
@@ -386,7 +417,7 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
 #ifdef LDOT_ABLATION
     // Ablation builds only (python -m lightningdot_amd.build --ablation -> libldot_ablation.so; tools/ab.sh): LDOT_DEBUG_VARIANT selects
     // a profiling variant of the kernel.  Results are meaningless under most of them, so the product library does not contain this hook.
-    //   16 tau = +inf (filter fast path only), 17 no filter at all, 8 no record stores, 128 program order not pinned
+    //   16 tau = +inf (filter fast path only), 17 no filter at all, 8 no record stores, 128 program order not pinned, 256 L2 touch-ahead
     static int variant = -1;
     if (variant < 0) {
         const char* e = getenv("LDOT_DEBUG_VARIANT");
@@ -396,6 +427,8 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     if (variant == 17) rk = score_filter_t16_kernel<17>;
     if (variant == 8) rk = score_filter_t16_kernel<8>;
     if (variant == 128) rk = score_filter_t16_kernel<128>;    // row blocks NOT pinned in program order (the scheduler sinks the fragment loads)
+    if (variant == 256) rk = score_filter_t16_kernel<256>;    // L2 touch-ahead of the row panel (see the kernel)
+    if (variant == 272) rk = score_filter_t16_kernel<272>;    // ... with tau = +inf
     LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<6>::kLds));
 #else
     static bool attr_set[kAttrDevices];

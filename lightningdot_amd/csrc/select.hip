@@ -277,6 +277,32 @@ struct WaveSelector {
             *tau_out = keep_max ? fmaxf(*tau_out, t) : t;
         }
     }
+    // after finish(): the m-th best SCORE of the list (keys[0 .. n) are the kept set, sorted on the LDS-sort path); -inf if n < m
+    template <int R>
+    __device__ __forceinline__ float mth_best_regs(int m) const {
+        const int lane = threadIdx.x & 63;
+        uint32_t hi[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) hi[r] = (r * 64 + lane < n) ? (uint32_t)(keys[r * 64 + lane] >> 32) : 0xffffffffu;
+        uint32_t T = 0;   // smallest score word with #(words <= T) >= m
+        for (int b = 31; b >= 0; --b) {
+            const uint32_t trial = T | ((1u << b) - 1u);
+            int c = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) c += __popcll(__ballot(hi[r] <= trial && r * 64 + lane < n));
+            if (c < m) T |= 1u << b;
+        }
+        return desc_key_to_float(T);
+    }
+    __device__ inline float mth_best(int m) const {
+        if (n < m) return -INFINITY;
+        wave_sync();
+        if (cap > kRegKeys * 64) return desc_key_to_float((uint32_t)(keys[m - 1] >> 32));   // (sorted)
+        if (n <= 128) return mth_best_regs<2>(m);
+        if (n <= 256) return mth_best_regs<4>(m);
+        if (n <= 512) return mth_best_regs<8>(m);
+        return mth_best_regs<16>(m);
+    }
 };
 
 __global__ __launch_bounds__(kSelThreads) void init_lists_kernel(float* ls, int32_t* li, int64_t n, float* tau,
@@ -782,7 +808,8 @@ __global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(con
                                                                        float* __restrict__ tau,
                                                                        int32_t* __restrict__ overflow,
                                                                        int32_t* __restrict__ over_sum,
-                                                                       int32_t* __restrict__ qcnt, int dbg) {
+                                                                       int32_t* __restrict__ qcnt, int dbg,
+                                                                       float* __restrict__ tau_opt, int opt_m) {
     extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
     // QPW independent waves per workgroup, one query each (no workgroup-level synchronisation anywhere): the grid of
     // one-wave workgroups was bound by the workgroup dispatch rate, not by the work
@@ -826,13 +853,27 @@ __global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(con
     }
     const bool any_over = __any(over);
     if (dbg & 2) return;
+    const float t_prev = (tau_opt && tau) ? tau[q] : -INFINITY;
     sel.finish(ls, li, tau ? tau + q : nullptr, true);
+    bool unproven = false;
+    if (tau_opt) {
+        // optimistic scan (api.hip: fused_rest_chunk_optimistic): the threshold of the NEXT launch = max(so far, m-th best of the new
+        // list); after the last launch (opt_m = 0) the check that makes the scheme exact: k' admitted rows at or above every
+        // threshold the rows were filtered with, i.e. the list's own threshold >= tau_opt
+        const float t_guar = fmaxf(t_prev, sel.n >= kp ? desc_key_to_float((uint32_t)(sel.tau >> 32)) : -INFINITY);
+        if (opt_m > 0) {
+            const float tm = opt_m >= kp ? t_guar : sel.mth_best(opt_m);
+            if (lane == 0) tau_opt[q] = fmaxf(tau_opt[q], tm);
+        } else {
+            unproven = !(t_guar >= tau_opt[q]);
+        }
+    }
     if (qcnt) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) nrec += __shfl_xor(nrec, o);
         if (lane == 0) qcnt[q] += nrec;   // (one wave per query: no atomics)
     }
-    if (lane == 0 && any_over && atomicExch(&overflow[q], 1) == 0) atomicAdd(over_sum, 1);   // queries counted once
+    if (lane == 0 && (any_over || unproven) && atomicExch(&overflow[q], 1) == 0) atomicAdd(over_sum, 1);   // queries counted once
 }
 
 // Few queries (the serving shape), many sub-pools: G waves per query, wave g folds sub-pools [g * nsubs / G, (g + 1) * nsubs / G)
@@ -1233,8 +1274,9 @@ int launch_parts_to_lists(const float* out_s, const int64_t* out_l, int64_t n, f
 
 int launch_select_pools(const uint4* pool, const int32_t* pool_cnt, int nsubs, int64_t nq, int32_t row_end, float* list_s,
                         int32_t* list_i, int kp, float* tau, int32_t* overflow_flags, int32_t* over_sum, int32_t* qcnt,
-                        hipStream_t st) {
+                        hipStream_t st, float* tau_opt, int opt_m) {
     if (nq <= 0) return LDOT_OK;
+    LDOT_REQUIRE(tau_opt == nullptr || nq > 256, LDOT_EINVAL, "optimistic thresholds are a large-batch schedule");
     if (nq <= 256) {   // few queries: block-per-query walk
         const int bcap = select_cap(kp, 2048, 4 * kSelThreads);   // a step appends up to 4 x 256 candidates on top of a full list
         hipLaunchKernelGGL(select_pools_block_kernel, dim3((unsigned)nq), dim3(kSelThreads), (size_t)bcap * 8, st, pool,
@@ -1256,10 +1298,11 @@ int launch_select_pools(const uint4* pool, const int32_t* pool_cnt, int nsubs, i
         constexpr int QPW = 4;
         hipLaunchKernelGGL((select_pools_kernel<4, QPW>), dim3((unsigned)((nq + QPW - 1) / QPW)),
                            dim3(kPoolSelThreads * QPW), (size_t)cap * 8 * QPW, st, pool, (int32_t*)pool_cnt, nsubs, nq,
-                           row_end, list_s, list_i, kp, cap, tau, overflow_flags, over_sum, qcnt, dbg);
+                           row_end, list_s, list_i, kp, cap, tau, overflow_flags, over_sum, qcnt, dbg, tau_opt, opt_m);
     } else {   // kp > 512: LDS sort path, one wave per workgroup
         hipLaunchKernelGGL((select_pools_kernel<4, 1>), dim3((unsigned)nq), dim3(kPoolSelThreads), (size_t)cap * 8 + kSlotWin, st,
-                           pool, (int32_t*)pool_cnt, nsubs, nq, row_end, list_s, list_i, kp, cap, tau, overflow_flags, over_sum, qcnt, dbg);
+                           pool, (int32_t*)pool_cnt, nsubs, nq, row_end, list_s, list_i, kp, cap, tau, overflow_flags, over_sum, qcnt, dbg,
+                           tau_opt, opt_m);
     }
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
@@ -1326,6 +1369,87 @@ int launch_list_stats(const float* list_s, const int32_t* list_i, int kp, int64_
         hipLaunchKernelGGL(list_stats_kernel<16>, grid, block, 0, st, list_s, list_i, kp, nq, m, tau, stat);
     else
         hipLaunchKernelGGL(list_stats_kernel<48>, grid, block, 0, st, list_s, list_i, kp, nq, m, tau, stat);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+// ---- optimistic thresholds of the fused scan (api.hip: fused_rest_chunk) ---------------------------------------------------------------
+// tau_opt[q] = max(tau_opt[q], m-th best score of q's list); m = kp takes the list's own threshold tau[q] (its k'-th best, -inf while
+// the list is not full).  Pad queries (q >= nq) stay at +inf.
+template <int R>
+__global__ __launch_bounds__(256) void tau_opt_kernel(const float* __restrict__ ls, const int32_t* __restrict__ li, int kp, int64_t nq, int m,
+                                                      const float* __restrict__ tau, float* __restrict__ tau_opt) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    float tm = tau[q];
+    if (m < kp) {
+        uint32_t key[R];
+        int nvalid = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int e = r * 64 + lane;
+            const bool valid = e < kp && li[q * kp + e] >= 0;
+            key[r] = valid ? desc_key(ls[q * kp + e]) : 0xffffffffu;
+            nvalid += __popcll(__ballot(valid));
+        }
+        tm = -INFINITY;
+        if (nvalid >= m) {
+            uint32_t T = 0;   // smallest key with #(keys <= T) >= m  (descending keys: the m-th best score)
+            for (int b = 31; b >= 0; --b) {
+                const uint32_t trial = T | ((1u << b) - 1u);
+                int c = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) c += __popcll(__ballot(key[r] <= trial && key[r] != 0xffffffffu));
+                if (c < m) T |= 1u << b;
+            }
+            tm = desc_key_to_float(T);
+        }
+    }
+    if (lane == 0) tau_opt[q] = fmaxf(tau_opt[q], tm);
+}
+
+int launch_tau_opt(const float* list_s, const int32_t* list_i, int kp, int64_t nq, int m, const float* tau, float* tau_opt, hipStream_t st) {
+    if (nq <= 0) return LDOT_OK;
+    const dim3 grid((unsigned)((nq + 3) / 4)), block(256);
+    if (kp <= 128)
+        hipLaunchKernelGGL(tau_opt_kernel<2>, grid, block, 0, st, list_s, list_i, kp, nq, m, tau, tau_opt);
+    else if (kp <= 256)
+        hipLaunchKernelGGL(tau_opt_kernel<4>, grid, block, 0, st, list_s, list_i, kp, nq, m, tau, tau_opt);
+    else if (kp <= 1024)
+        hipLaunchKernelGGL(tau_opt_kernel<16>, grid, block, 0, st, list_s, list_i, kp, nq, m, tau, tau_opt);
+    else
+        hipLaunchKernelGGL(tau_opt_kernel<48>, grid, block, 0, st, list_s, list_i, kp, nq, m, tau, tau_opt);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+// tau_opt = -inf for the queries, +inf for the pad rows of the last query block (they never produce candidates)
+__global__ __launch_bounds__(256) void init_tau_opt_kernel(float* __restrict__ tau_opt, int64_t nq, int64_t nq_pad) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q < nq_pad) tau_opt[q] = q < nq ? -INFINITY : INFINITY;
+}
+
+int launch_init_tau_opt(float* tau_opt, int64_t nq, int64_t nq_pad, hipStream_t st) {
+    if (nq_pad <= 0) return LDOT_OK;
+    hipLaunchKernelGGL(init_tau_opt_kernel, dim3((unsigned)((nq_pad + 255) / 256)), dim3(256), 0, st, tau_opt, nq, nq_pad);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+// End of an optimistic scan: a query's list is its exact top-k' iff at least k' admitted rows score at or above every threshold its rows
+// were filtered with, i.e. its final k'-th best (tau) >= tau_opt.  The others are flagged like pool overflows (redo_flagged searches
+// them again on guaranteed thresholds).
+__global__ __launch_bounds__(256) void verify_tau_opt_kernel(const float* __restrict__ tau, const float* __restrict__ tau_opt, int64_t nq,
+                                                             int32_t* __restrict__ overflow, int32_t* __restrict__ over_sum) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    if (!(tau[q] >= tau_opt[q]) && atomicExch(&overflow[q], 1) == 0) atomicAdd(over_sum, 1);
+}
+
+int launch_verify_tau_opt(const float* tau, const float* tau_opt, int64_t nq, int32_t* overflow, int32_t* over_sum, hipStream_t st) {
+    if (nq <= 0) return LDOT_OK;
+    hipLaunchKernelGGL(verify_tau_opt_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, tau, tau_opt, nq, overflow, over_sum);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

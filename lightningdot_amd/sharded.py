@@ -7,7 +7,10 @@ One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Rank 
        candidate thresholds (Q x 4 B), exact re-score of the local candidates at or above the global threshold
     3. exchange of the partial top-k lists by query slice               (all-to-all; Q x k x 12 B per rank)
     4. merge of the G partial lists of the local query slice           (ldot_merge_topk, HIP)
-so every rank ends with the final global top-k of the queries it contributed.  The scores against disjoint row
+so every rank ends with the final global top-k of the queries it contributed.  With equal query slices (the bench's shape) steps 2-4
+touch no torch op: the re-score kernel writes every destination rank's block of the send buffer (scores + global labels), ONE
+all-to-all moves the blocks, the merge kernel reads the receive buffer in place (ldot_index_search_finish_blocked /
+ldot_merge_topk_blocked); ``equal_query_counts=True`` also drops the per-search exchange of the query counts.  The scores against disjoint row
 shards are independent, so there is no other data-path collective.
 
 External ids stay on the rank that owns the rows: ``index_local_shard`` exchanges only the shard SIZES (row offsets); ``search_knn``
@@ -54,7 +57,7 @@ def _hip_merge(scores: torch.Tensor, labels: torch.Tensor, k: int, out=None):
 class ShardedFlatIndexer:
     def __init__(self, vector_sz: int, group=None, local_search: Optional[Callable] = None,
                  merge: Optional[Callable] = None, normalize: bool = False, exchange: str = 'all_to_all',
-                 exchange_warmup: bool = True, equal_query_counts: bool = False):
+                 exchange_warmup: bool = False, equal_query_counts: bool = False):
         if exchange not in ('all_to_all', 'all_gather'):
             raise ValueError("exchange must be 'all_to_all' or 'all_gather'")
         self.group = group
@@ -62,7 +65,10 @@ class ShardedFlatIndexer:
         self.world = dist.get_world_size(group)
         self.d = vector_sz
         self.exchange = exchange
-        self.exchange_warmup = exchange_warmup   # thresholds agreed after the warm-up (False: only after the candidate pass, as in round 3)
+        # True: the shards agree on thresholds after their warm-ups as well (ldot_index_search_warmup / _scan).  Built and measured in
+        # round 4: with the optimistic thresholds of the plain scan a shard admits FEWER records on its own (327 vs 640 per query at
+        # 8 x 125 000 rows) and saves the extra all-reduce — 1.99 vs 2.23 ms per rank (tools/shard_floor.py) —, so the default is off
+        self.exchange_warmup = exchange_warmup
         # the caller promises that every rank passes the same number of queries to every search: the per-search exchange of the
         # query counts (a small all-gather + a host synchronisation) is skipped
         self.equal_query_counts = equal_query_counts
@@ -260,9 +266,9 @@ class ShardedFlatIndexer:
             # candidates on this shard, then ONE small all-reduce (MAX) of the per-query candidate thresholds: at least k'
             # candidates score >= that maximum globally, so every shard re-scores only its candidates at or above it
             # (~k'/G per shard instead of k'): the re-score gather is the largest per-query cost of a shard
-            # Round 4: the shards agree on thresholds BEFORE the candidate pass as well — every shard warms up on its first few thousand
-            # rows, one all-reduce(MAX) of two numbers per query turns the warm-ups into a bound worth world x as many rows, and the
-            # candidate pass admits ~1/world of the records (one fused launch + one pool select instead of four of each).
+            # exchange_warmup (option): the shards agree on thresholds BEFORE the candidate pass as well — every shard warms up on its
+            # first few thousand rows and one all-reduce(MAX) of two numbers per query turns the warm-ups into a bound worth ~0.7 x world
+            # x as many rows (one or two fused launches per shard).  Default: each shard's own optimistic thresholds (see __init__).
             ix = self.local.index
             if self.world > 1 and self.exchange_warmup:
                 stat = ix.search_warmup(q_all, k, self.world)

@@ -22,7 +22,7 @@ from typing import Callable, Dict, Iterable, Optional
 import numpy as np
 import torch
 
-from .train import allreduce_gradients, broadcast_parameters, get_optimizer, get_schedule_linear
+from .train import GradientBucketReducer, allreduce_gradients, broadcast_parameters, get_optimizer, get_schedule_linear
 from .data import EvalLoader          # noqa: F401  (re-exported: the evaluation-style loader of the CLI below)
 from .towers import CheckpointState, save_checkpoint
 
@@ -91,6 +91,14 @@ def TRAIN(args, bi_encoder, train_dataset, val_dataloader, val_img2txt: Dict, *,
 
     optimizer = get_optimizer(bi_encoder, args.learning_rate)
     broadcast_parameters(bi_encoder)                                        # C2: every rank starts from rank 0's weights
+    # C1: gradients are exchanged bucket by bucket WHILE backward runs (the reference relies on horovod's optimizer hooks);
+    # args.grad_reduce_dtype = 'bf16' halves the bytes on xGMI, args.overlap_grad_reduce = False falls back to one pass after backward
+    reducer = None
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1 \
+            and getattr(args, 'overlap_grad_reduce', True):
+        rd = getattr(args, 'grad_reduce_dtype', None)
+        reducer = GradientBucketReducer(bi_encoder.parameters(),
+                                        reduce_dtype=torch.bfloat16 if rd in ('bf16', torch.bfloat16) else None)
     # (counted, not iterated: a dry pass over the loader would read and collate every item and image feature once more)
     if hasattr(make_train_loader, 'steps_per_epoch'):
         steps_per_epoch = int(make_train_loader.steps_per_epoch(train_dataset, args))
@@ -140,9 +148,15 @@ def TRAIN(args, bi_encoder, train_dataset, val_dataloader, val_img2txt: Dict, *,
             epoch_correct += float(is_correct)
             epoch_loss += float(loss.item())
             n_steps += 1
+            last_micro = (step + 1) % gas == 0
+            if reducer is not None and last_micro:
+                reducer.arm()
             loss.backward()
-            if (step + 1) % gas == 0:
-                allreduce_gradients(bi_encoder.parameters())                # C1 (the reference relies on horovod's optimizer hook)
+            if last_micro:
+                if reducer is not None:
+                    reducer.finish()                                        # C1: only the first layers' bucket is still in flight here
+                else:
+                    allreduce_gradients(bi_encoder.parameters())
                 mg = float(getattr(args, 'max_grad_norm', 2.0) or 0.0)
                 if mg > 0:
                     torch.nn.utils.clip_grad_norm_(bi_encoder.parameters(), mg)                                  # :262

@@ -184,6 +184,51 @@ def test_overflow_recovery_redoes_only_the_flagged_queries(L):
     np.testing.assert_array_equal(l2, l)
 
 
+def test_optimistic_thresholds_are_verified_and_front_loaded_rows_are_redone(L):
+    """LDOT_OPT_OPTIMISTIC (default on, large batches): the fused scan filters with order statistics of the rows seen so far that lie
+    below the final threshold — unless the row ORDER front-loads a query's best rows.  Here the sixteen best rows of half the queries
+    sit in the warm-up region (the first threshold of this scan is the 14th best warm-up score: k' r / N = 2.6 of the final top k' are
+    expected there): their optimistic thresholds end far above their final k'-th best, the end-of-scan check flags them, and the recovery
+    searches them again on guaranteed thresholds.  Results equal the dense path's bit for bit either way; with i.i.d. row order nothing
+    is flagged and the scan admits a fraction of the candidates the guaranteed schedule does."""
+    rng = np.random.default_rng(77)
+    n, d, nq = 200000, 64, 512
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    for j in range(4096):                                   # rows 0 .. 4095: sixteen near-copies of each of the first 256 queries
+        x[j] = q[j % 256] * (1.0 + 0.01 * rng.standard_normal())
+    ix = _index(x, mode=L.MODE_FUSED, warm_rows=4096)
+    s, l = ix.search(q, 100)
+    st = ix.last_stats()
+    assert 256 <= st['overflowed_queries'] < 300, st        # the front-loaded queries failed the check and were searched again
+    ixd = _index(x, mode=L.MODE_DENSE)
+    sd, ld = ixd.search(q, 100)
+    np.testing.assert_array_equal(l, ld)
+    np.testing.assert_array_equal(s, sd)
+    assert_topk_matches(q, x, s, l, 100)
+    # the same rows in random order: nothing is flagged, and the optimistic schedule admits far fewer records than the guaranteed one
+    perm = rng.permutation(n)
+    xs = x[perm]
+    ix2 = _index(xs, mode=L.MODE_FUSED, warm_rows=4096)
+    s2, l2 = ix2.search(q, 100)
+    st2 = ix2.last_stats()
+    assert st2['overflowed_queries'] == 0, st2
+    ix3 = _index(xs, mode=L.MODE_FUSED, warm_rows=4096)
+    ix3.set_option(L.OPT_OPTIMISTIC, 0)
+    s3, l3 = ix3.search(q, 100)
+    st3 = ix3.last_stats()
+    np.testing.assert_array_equal(l2, l3)
+    np.testing.assert_array_equal(s2, s3)
+    assert st2['fused_candidates'] < 0.6 * st3['fused_candidates'], (st2, st3)
+    # ... and the same answer as in the front-loaded order: identical fp32 scores; identical rows wherever a score is unique in its list
+    # (equal scores are ordered by row number, which the permutation changes)
+    np.testing.assert_array_equal(s2, s)
+    uniq = np.ones_like(s, dtype=bool)
+    uniq[:, 1:] &= s[:, 1:] != s[:, :-1]
+    uniq[:, :-1] &= s[:, :-1] != s[:, 1:]
+    np.testing.assert_array_equal(perm[l2][uniq], l[uniq])
+
+
 def test_no_rescore_reports_bf16_input_scores(L):
     rng = np.random.default_rng(12)
     x = rng.standard_normal((4000, 768)).astype(np.float32)

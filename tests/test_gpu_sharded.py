@@ -111,16 +111,17 @@ def _worker4(rank, world, port, out_dir):
         q = _gen_queries(int(qs[-1]), c['d'], 500 + ci, c['bounds'][-1])[qs[rank]:qs[rank + 1]].contiguous()
         from lightningdot_amd import _lib as L
         sh.local.index.set_option(L.OPT_PROFILE, 1)
-        sh.exchange_warmup = False            # round 3's exchange (thresholds agreed only after the candidate pass), for comparison
-        s0, l0 = sh.search(q, c['k'])
-        st0, n0 = sh.local.index.last_stats(), sh.local.index.last_profile()['launches']
-        sh.exchange_warmup = True
+        assert sh.exchange_warmup is False    # default: every shard scans on its own (optimistic) thresholds, one exchange after the pass
         s, l = sh.search(q, c['k'])
         st, n1 = sh.local.index.last_stats(), sh.local.index.last_profile()['launches']
+        sh.exchange_warmup = True             # option: thresholds agreed after the warm-ups (ldot_index_search_warmup / _scan)
+        s0, l0 = sh.search(q, c['k'])
+        st0, n0 = sh.local.index.last_stats(), sh.local.index.last_profile()['launches']
+        sh.exchange_warmup = False
         assert torch.equal(s, s0) and torch.equal(l, l0)
         np.savez(os.path.join(out_dir, f'{name}_r{rank}.npz'), s=s.cpu().numpy(), l=l.cpu().numpy(),
                  fused_pairs=st['fused_pairs'], fused_candidates=st['fused_candidates'], overflowed=st['overflowed_queries'],
-                 fused_candidates_local=st0['fused_candidates'], launches=n1, launches_local=n0)
+                 fused_candidates_agreed=st0['fused_candidates'], launches=n1, launches_agreed=n0)
         del sh
         torch.cuda.empty_cache()
         dist.barrier()
@@ -153,14 +154,14 @@ def test_sharded_search_four_ranks_fused_path_baseline_shapes(tmp_path):
             assert int(a['overflowed']) == 0
             if name == 'shard125k':   # every rank scanned its shard with the fused filter (all queries x its rows beyond the warm-up)
                 assert int(a['fused_pairs']) > 0.9 * int(qs[-1]) * 125000
-                cand.append((int(a['fused_candidates']), int(a['fused_candidates_local']), int(a['launches']), int(a['launches_local'])))
+                cand.append((int(a['fused_candidates']), int(a['fused_candidates_agreed']), int(a['launches']), int(a['launches_agreed'])))
             elif name == 'equal':
                 assert int(a['fused_pairs']) > 0.8 * int(qs[-1]) * 40000
             else:
                 assert int(a['fused_pairs']) == 0
         if name == 'shard125k':
-            # thresholds agreed after the warm-ups: fewer score launches (each followed by a pool select) per shard — the launches are
-            # stretched to the pool bound, so the admitted records only have to stay below the local schedule's
-            assert all(a <= b and la < lb for a, b, la, lb in cand), cand
+            # both schedules give the same lists (asserted in the workers); the default (optimistic local thresholds) admits fewer
+            # records than the agreed-threshold option in no more launches — which is why it is the default (tools/shard_floor.py)
+            assert all(a < b and la <= lb for a, b, la, lb in cand), cand
         del ix
         torch.cuda.empty_cache()
