@@ -134,6 +134,13 @@ struct ldot_index {
     // (w_tau: the list's own k'-th best) is still far below the final one
     int optimistic = 1;
     DevBuf w_tau_opt;
+    // rows stored in an order that correlates with the queries (cluster-sorted rows: what the inverted-file index keeps) fail the
+    // end-of-scan check for a large share of the queries on EVERY search, and a failed query costs a second scan: after a search that
+    // flagged more than 1 / 64 of its queries the optimistic schedule is skipped for `opt_backoff` searches, twice as many after every
+    // further failure (reset by a search that passes)
+    int opt_backoff = 0, opt_penalty = 16;
+    bool opt_used = false;           // the scan in progress filtered with optimistic thresholds
+    int64_t opt_nq = 0;
     int cur_parts = 1;   // shards of the search in progress (1 = plain search): sizes the warm-up of a fused scan, fused_warm_rows
 };
 
@@ -812,7 +819,6 @@ static int fused_rest_chunk_optimistic(ldot_index* ix, int64_t q0, int64_t nq, i
     float* tau_opt = (float*)ix->w_tau_opt.p + q0;
     const float* ls = (const float*)ix->w_ls.p + q0 * kp;
     const int32_t* li = (const int32_t*)ix->w_li.p + q0 * kp;
-    if ((rc = launch_init_tau_opt(tau_opt, nq, nq_pad, st))) return rc;
     double eps = kOptEps;
     int64_t growth_x = kOptGrowthX, max_rows = kOptMaxLaunchRows;
 #ifdef LDOT_ABLATION
@@ -845,8 +851,10 @@ static int fused_rest_chunk_optimistic(ldot_index* ix, int64_t q0, int64_t nq, i
 static int fused_rest_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_pad, int kp, int parts, hipStream_t st) {
     // large batches of a plain search: optimistic thresholds (few-query searches have their own launch schedule, sharded searches
     // their agreed thresholds)
-    if (ix->optimistic && parts == 1 && ix->cur_parts == 1 && nq > kFewSelectMaxQueries)
+    if (ix->optimistic && ix->opt_backoff == 0 && parts == 1 && ix->cur_parts == 1 && nq > kFewSelectMaxQueries) {
+        ix->opt_used = true;
         return fused_rest_chunk_optimistic(ix, q0, nq, nq_pad, kp, st);
+    }
     int rc;
     constexpr int64_t kFill = kPoolCap / 4;
     const int64_t bm = fused_tile_rows();
@@ -902,11 +910,13 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
         if ((rc = ix->w_over_sum.ensure(16))) return rc;
         if ((rc = ix->w_qcnt.ensure((size_t)nq_pad * 4))) return rc;
         if ((rc = ix->w_tau_opt.ensure((size_t)nq_pad * 4))) return rc;
-        LDOT_HIP_CHECK(hipMemsetAsync(ix->w_qcnt.p, 0, (size_t)nq_pad * 4, st));
+        ix->opt_used = false;
+        ix->opt_nq = nq;
+        if (ix->opt_backoff > 0 && nq > kFewSelectMaxQueries) --ix->opt_backoff;   // (counted in large-batch searches, the ones it applies to)
+        if ((rc = launch_init_fused_scan((float*)ix->w_tau_opt.p, (int32_t*)ix->w_qcnt.p, (int32_t*)ix->w_over_sum.p, nq, nq_pad, st))) return rc;
         ix->qcnt_n = nq;
         if (!ix->h_over_sum) LDOT_HIP_CHECK(hipHostMalloc((void**)&ix->h_over_sum, 16));
         if (fresh_flags || !ix->flags_clean) LDOT_HIP_CHECK(hipMemsetAsync(ix->w_over.p, 0, ix->w_over.bytes, st));
-        LDOT_HIP_CHECK(hipMemsetAsync(ix->w_over_sum.p, 0, 16, st));
         ix->flags_clean = false;
     }
     for (int64_t q0 = 0; q0 < nq; q0 += kFusedQueryChunk) {
@@ -947,6 +957,15 @@ static bool fused_overflow_check(ldot_index* ix) {
     const int64_t n_over = ix->h_over_sum[0];
     ix->stats[1] = n_over;
     ix->flags_clean = n_over == 0;
+    if (ix->opt_used) {
+        ix->opt_used = false;
+        if (n_over * 64 > ix->opt_nq) {
+            ix->opt_backoff = ix->opt_penalty;
+            ix->opt_penalty = std::min(2 * ix->opt_penalty, 1024);
+        } else if (n_over == 0) {
+            ix->opt_penalty = 16;
+        }
+    }
     return n_over > 0;
 }
 

@@ -129,7 +129,7 @@ int launch_neutral_stats(int64_t nq, float* stat, hipStream_t st);
 int launch_apply_stats(int64_t nq, const float* stat, float* tau, hipStream_t st);
 // optimistic thresholds of the fused scan: tau_opt = max(tau_opt, m-th best of the list); initial values; end-of-scan verification
 int launch_tau_opt(const float* list_s, const int32_t* list_i, int kp, int64_t nq, int m, const float* tau, float* tau_opt, hipStream_t st);
-int launch_init_tau_opt(float* tau_opt, int64_t nq, int64_t nq_pad, hipStream_t st);
+int launch_init_fused_scan(float* tau_opt, int32_t* qcnt, int32_t* over_sum, int64_t nq, int64_t nq_pad, hipStream_t st);
 int launch_verify_tau_opt(const float* tau, const float* tau_opt, int64_t nq, int32_t* overflow, int32_t* over_sum, hipStream_t st);
 int launch_merge_parts_into_lists(const float* part_s, const int64_t* part_l, int nparts, int64_t nq, int kp, float* list_s,
                                   int32_t* list_i, float* tau, hipStream_t st);

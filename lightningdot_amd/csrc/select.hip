@@ -1424,15 +1424,21 @@ int launch_tau_opt(const float* list_s, const int32_t* list_i, int kp, int64_t n
     return LDOT_OK;
 }
 
-// tau_opt = -inf for the queries, +inf for the pad rows of the last query block (they never produce candidates)
-__global__ __launch_bounds__(256) void init_tau_opt_kernel(float* __restrict__ tau_opt, int64_t nq, int64_t nq_pad) {
+// per-search state of a fused scan in one launch (instead of two memset nodes and a kernel): the per-query record counters and the
+// overflow summary zeroed, tau_opt = -inf for the queries and +inf for the pad rows of the last query block (they never produce candidates)
+__global__ __launch_bounds__(256) void init_fused_scan_kernel(float* __restrict__ tau_opt, int32_t* __restrict__ qcnt,
+                                                              int32_t* __restrict__ over_sum, int64_t nq, int64_t nq_pad) {
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (q < nq_pad) tau_opt[q] = q < nq ? -INFINITY : INFINITY;
+    if (q < nq_pad) {
+        tau_opt[q] = q < nq ? -INFINITY : INFINITY;
+        qcnt[q] = 0;
+    }
+    if (q < 4) over_sum[q] = 0;
 }
 
-int launch_init_tau_opt(float* tau_opt, int64_t nq, int64_t nq_pad, hipStream_t st) {
+int launch_init_fused_scan(float* tau_opt, int32_t* qcnt, int32_t* over_sum, int64_t nq, int64_t nq_pad, hipStream_t st) {
     if (nq_pad <= 0) return LDOT_OK;
-    hipLaunchKernelGGL(init_tau_opt_kernel, dim3((unsigned)((nq_pad + 255) / 256)), dim3(256), 0, st, tau_opt, nq, nq_pad);
+    hipLaunchKernelGGL(init_fused_scan_kernel, dim3((unsigned)((nq_pad + 255) / 256)), dim3(256), 0, st, tau_opt, qcnt, over_sum, nq, nq_pad);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

@@ -104,6 +104,9 @@ class DenseIVFFlatIndexer(DenseIndexer):
         super().__init__(buffer_size=buffer_size)
         self.d = vector_sz
         self.index = FlatIPIndex(vector_sz)              # the rows, sorted by list
+        # (cluster-sorted rows are the order the optimistic thresholds of the exact scan must not assume away: a query's best rows
+        # sit together, often early — the scan would flag and redo most queries; the library also backs off by itself)
+        self.index.set_option(L.OPT_OPTIMISTIC, 0)
         self.nlist, self.nprobe = nlist, nprobe
         self.train_iters, self.train_rows_per_list, self.seed = train_iters, train_rows_per_list, seed
         # longest list allowed (None: 4 x the mean list length, at least 64 rows, when nlist is chosen automatically; 0: lists as

@@ -201,6 +201,12 @@ def test_optimistic_thresholds_are_verified_and_front_loaded_rows_are_redone(L):
     s, l = ix.search(q, 100)
     st = ix.last_stats()
     assert 256 <= st['overflowed_queries'] < 300, st        # the front-loaded queries failed the check and were searched again
+    # an index whose searches keep failing the check stops trying for a while (16 searches, then 32, ...): the next search runs on
+    # guaranteed thresholds, flags nothing and returns the same lists
+    sb, lb = ix.search(q, 100)
+    assert ix.last_stats()['overflowed_queries'] == 0
+    np.testing.assert_array_equal(lb, l)
+    np.testing.assert_array_equal(sb, s)
     ixd = _index(x, mode=L.MODE_DENSE)
     sd, ld = ixd.search(q, 100)
     np.testing.assert_array_equal(l, ld)

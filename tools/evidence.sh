@@ -19,7 +19,7 @@ timeout 600 python bench.py --workload serving --rows 123287 --steps 50 --warmup
 timeout 300 python tools/gemm_ref.py > $O/vendor_gemm.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt -o k --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 2 --no-cpu-baseline > $O/bench_profiled.json 2> $O/rocprof.err
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt -o k --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 2 --no-cpu-baseline --no-secondary > $O/bench_profiled.json 2> $O/rocprof.err
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 rm -rf /tmp/kts
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kts -o k --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --workload serving --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_serving_profiled.json 2>> $O/rocprof.err

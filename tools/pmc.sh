@@ -15,7 +15,7 @@ rm -f $OUT/pmc_$TAG.txt
 i=0
 for g in "${PMCG[@]}"; do
   rm -rf /tmp/pmc_$i
-  timeout 600 rocprofv3 --pmc $g --kernel-trace -d /tmp/pmc_$i -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > /tmp/pmc_$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $g --kernel-trace -d /tmp/pmc_$i -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary "$@" > /tmp/pmc_$i.log 2>&1
   f=$(find /tmp/pmc_$i -name "*counter_collection.csv" | head -1)
   python - "$f" >> $OUT/pmc_$TAG.txt <<'PY'
 import csv, sys, collections

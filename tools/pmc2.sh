@@ -2,7 +2,7 @@
 # usage: tools/pmc2.sh "<counters>"  -> per-kernel sums for one PMC group
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmcx
-timeout 600 rocprofv3 --pmc $1 --kernel-trace -d /tmp/pmcx -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /tmp/pmcx.log 2>&1
+timeout 600 rocprofv3 --pmc $1 --kernel-trace -d /tmp/pmcx -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > /tmp/pmcx.log 2>&1
 f=$(find /tmp/pmcx -name "*counter_collection.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys, collections

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel stats of bench.py (args forwarded)
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kb
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kb -o k --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > /tmp/kb.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kb -o k --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary "$@" > /tmp/kb.log 2>&1
 python - <<PY
 import csv,glob
 f=glob.glob("/tmp/kb/**/*kernel_stats.csv",recursive=True)[0]

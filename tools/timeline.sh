@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-step timeline of bench.py from a rocprofv3 kernel + memory-copy trace: kernels/copies of the LAST search pass with gaps
 mkdir -p $GRAFT_REPO_ROOT/gpurun_out; cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tl
-timeout 600 rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/tl -o t --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline "$@" > /tmp/tl.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/tl -o t --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary "$@" > /tmp/tl.log 2>&1
 python - > $GRAFT_REPO_ROOT/gpurun_out/timeline.txt <<'PY'
 import csv, glob
 ev = []
