@@ -177,7 +177,8 @@ int ldot_index_load(const char* path, ldot_index_t** out);
 /* copy rows [row0,row0+n) of the fp32 master copy to a caller buffer (inspection / resharding) */
 int ldot_index_get_rows(ldot_index_t* ix, int64_t row0, int64_t n, float* out, int out_mem, void* stream);
 /* statistics of the last search on this index: [0]=candidate records appended by the fused filter (8 scores each), [1]=queries
- * that overflowed their candidate pools and were redone densely, [2]=(query,row) pairs scored densely, [3]=pairs scored fused */
+ * that were searched again — a candidate pool overflowed, or the end-of-scan check of the optimistic thresholds failed
+ * (LDOT_OPT_OPTIMISTIC) —, [2]=(query,row) pairs scored densely, [3]=pairs scored fused */
 int ldot_index_last_stats(const ldot_index_t* ix, int64_t out[4]);
 /* LDOT_OPT_VERIFY = 1: flags_out [nq of the last search] (host, may be NULL) receives 1 for every query whose result is not proven
  * exact, *count_out their number.  No reference counterpart (faiss IndexFlatIP is fp32 end to end); this is how the bf16 candidate
