@@ -788,6 +788,141 @@ static void run_w1(K k, int lds_bytes, int slab_multiple, const char* name, cons
     fflush(stdout);
 }
 
+
+// T16B (round 4): the product kernel's eight waves arranged 4 (rows) x 2 (queries): wave tile 96 x 128 = 6 x 8 tiles, the same 192 accumulator
+// registers, 6 + 8 = 14 fragment reads per slab and wave instead of 12 + 4 = 16 (-12.5 % LDS read bytes).  The eight query fragments are
+// single-buffered and refilled IN PLACE during the last row block (b[j] right after its last MFMA: seven MFMAs = 112 cycles before its first
+// use in the next slab); A fragments in a ring of three as before.  The slab barrier sits before row block 3, where the first fragment of
+// the next stage is read.  FEED 1: fragment stream only, 2: + slab-load burst, 5: loads spread.
+template <int FEED>
+__global__ __launch_bounds__(512, 2) void ceiling16b_kernel(const char* __restrict__ src, int64_t src_region, int nslab,
+                                                            float* __restrict__ sink, uint64_t* __restrict__ ticks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int xcd = blockIdx.x & 7;
+    const char* base = src + (int64_t)xcd * src_region;
+    __amdgpu_buffer_rsrc_t rs = ring_make_rsrc_n(base, src_region);
+    const int vo = lane * 16;
+    int issued = 0, so = 0;
+    const int so_end = (int)src_region - kStage;
+    auto issue_piece = [&](const int j) {
+        char* st = smem + (issued & 3) * kStage;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (rg_lptr_t)(st + (j * 8 + wave) * 1024), 16, vo, so + (j * 8 + wave) * 1024, 0, 0);
+        if (j == 4) {
+            ++issued;
+            so += kStage;
+            if (so >= so_end) so = 0;
+        }
+    };
+    auto issue = [&]() {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) issue_piece(j);
+    };
+    issue();
+    issue();
+    issue();
+    issue();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int row = lane & 15;
+    const int foff = row * 64 + (((lane >> 4) ^ ((row >> 1) & 3)) << 4);
+    f32x4 acc[6][8];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8_t a[3], b[8];
+    const char* a_w0 = smem + wm * (96 * 64) + foff;
+    const char* b_w0 = smem + kAOp + wn * (128 * 64) + foff;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a[i] = *(const bf16x8_t*)(a_w0 + i * 1024);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = *(const bf16x8_t*)(b_w0 + j * 1024);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" ::: "memory");
+    const uint64_t t0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+    auto slab = [&](const char* st0, const char* st1) {
+        const char* a_cur = st0 + wm * (96 * 64) + foff;
+        const char* a_nxt = st1 + wm * (96 * 64) + foff;
+        const char* b_nxt = st1 + kAOp + wn * (128 * 64) + foff;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i == 3) {   // every fragment of this stage is in registers; the next stage's first fragment is read below
+                __builtin_amdgcn_sched_barrier(0);
+                if (FEED == 2 || FEED == 5) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i % 3], b[j], acc[i][j], 0, 0, 0);
+                if (i == 5) b[j] = *(const bf16x8_t*)(b_nxt + j * 1024);
+            }
+            a[i % 3] = *(const bf16x8_t*)((i + 3 < 6 ? a_cur + (i + 3) * 1024 : a_nxt + (i + 3 - 6) * 1024));
+            if (FEED == 5) {   // the slab that goes into the stage vacated at the barrier: pieces after row blocks 3, 4, 5 and 0, 1 of the next slab
+                if (i >= 3) issue_piece(i - 3);
+                if (i <= 1) issue_piece(3 + i);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (FEED == 2) issue();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll 1
+    for (int s = 0; s + 1 < nslab; s += 2) {
+        slab(smem + (s & 3) * kStage, smem + ((s + 1) & 3) * kStage);
+        slab(smem + ((s + 1) & 3) * kStage, smem + ((s + 2) & 3) * kStage);
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    const uint64_t t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sum == 12345.678f) sink[blockIdx.x * blockDim.x + threadIdx.x] = sum;
+    if (threadIdx.x == 0) {
+        ticks[blockIdx.x * 2] = t1 - t0;
+        ticks[blockIdx.x * 2 + 1] = r1 - r0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int FEED>
+static void run16b(const char* name, const char* src, int64_t region, float* sink, uint64_t* ticks, double target_ms) {
+    auto k = ceiling16b_kernel<FEED>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kStage));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const double flop_per_slab = 2.0 * 384 * 256 * 32 * 256;
+    int nslab = 2000;
+    float ms = 0.f;
+    for (int it = 0; it < 4; ++it) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k, dim3(256), dim3(512), 4 * kStage, 0, src, region, nslab, sink, ticks);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (it == 0) nslab = (int)(nslab * target_ms / ms);
+        if (it >= 2) {
+            std::vector<uint64_t> h(512);
+            CK(hipMemcpy(h.data(), ticks, 512 * 8, hipMemcpyDeviceToHost));
+            double cyc = 0, real = 0;
+            for (int i = 0; i < 256; ++i) {
+                cyc += (double)h[2 * i];
+                real += (double)h[2 * i + 1];
+            }
+            const double tf = flop_per_slab * nslab / (ms * 1e-3) / 1e12;
+            printf("%-34s %8.3f ms  %8.1f TFLOP/s  %5.1f %% of 2500  clock %.3f GHz  pipe-issue %.1f %%\n", name, ms, tf, tf / 25.0,
+                   cyc / real * 0.1, 48.0 * 2 * nslab * 16.0 / (cyc / 256) * 100);
+        }
+    }
+    fflush(stdout);
+}
+
 int main(int argc, char** argv) {
     const double target_ms = argc > 1 ? atof(argv[1]) : 12.0;
     const int64_t region = 16ll << 20;   // per XCD window of the slab source (8 x 16 MiB: Infinity-Cache resident)
@@ -806,6 +941,9 @@ int main(int argc, char** argv) {
     CK(hipMemset(zsrc, 0, region * 8));
     for (int rep = 0; rep < 1; ++rep) {
         printf("---- repetition %d (target %.1f ms per launch) ----\n", rep, target_ms);
+        run16b<1>("T16B (4x2 waves) mfma+ds_read  random", src, region, sink, ticks, target_ms);
+        run16b<2>("T16B mfma+ds_read+lds-dma     random", src, region, sink, ticks, target_ms);
+        run16b<5>("T16B full, dma interleaved    random", src, region, sink, ticks, target_ms);
         run_w1(ceiling16w1_kernel<1>, 4 * kStage, 2, "T16W1 mfma+ds_read         random", src, region, sink, ticks, target_ms);
         run_w1(ceiling16w1_kernel<2>, 4 * kStage, 2, "T16W1 mfma+ds_read+lds-dma random", src, region, sink, ticks, target_ms);
         run_w1(ceiling16w1_kernel<5>, 4 * kStage, 2, "T16W1 full, dma interleaved random", src, region, sink, ticks, target_ms);
