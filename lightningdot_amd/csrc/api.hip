@@ -745,13 +745,13 @@ constexpr int64_t kWarmSelectFastCols = 5120;   // the warm-up's select keeps a 
 // rows of the dense warm-up of a fused scan
 static int64_t fused_warm_rows(const ldot_index* ix, int64_t nq, int64_t nq_pad, int kp) {
     // Pool sizing rule: a launch over `len` rows after `r` scanned rows admits ~kp*len/r candidates per query,
-    // spread over nsubs lane-private sub-pools of kPoolCap records.  Keeping the expectation <= kPoolCap / 4 per sub-pool
+    // spread over nsubs sub-pools of kPoolCap records (four lane groups of kPoolGroupCap each).  Keeping the expectation <= kPoolFill per sub-pool
     // (16 records, expectation 4: overflow probability ~1e-6 per sub-pool and launch WHERE THIS BOUND IS THE ACTIVE ONE, i.e. for k' in the
     // thousands; at the default growth of 150 % and k' = 128 the expectation is 0.75 and the probability ~1e-17; an overflow costs the
     // flagged queries one more fused launch, redo_flagged) bounds len <= r * kFill * nsubs / kp (1024 r / kp at 256 sub-pools; 8x that for the
     // 2048 sub-pools of a single query block, whose search is then ONE fused launch); the smallest launch is one tile
     // per row slice, hence the warm-up covers at least bm * nslices * kp / (kFill * nsubs) rows.
-    constexpr int64_t kFill = kPoolCap / 4;
+    constexpr int64_t kFill = kPoolFill;
     const int64_t bm = fused_tile_rows();
     const int qg = fused_query_group(nq_pad);
     const int64_t nslices = 256 / qg, nsubs = kPoolSubsPerSlice * nslices;
@@ -808,7 +808,7 @@ static int optimistic_m(int kp, int64_t r, int64_t n, double eps) {
 
 static int fused_rest_chunk_optimistic(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_pad, int kp, hipStream_t st) {
     int rc;
-    constexpr int64_t kFill = kPoolCap / 4;
+    constexpr int64_t kFill = kPoolFill;
     const int64_t bm = fused_tile_rows();
     const int qg = fused_query_group(nq_pad);
     const int64_t nslices = 256 / qg, nsubs = kPoolSubsPerSlice * nslices, unit = bm * nslices;
@@ -851,12 +851,16 @@ static int fused_rest_chunk_optimistic(ldot_index* ix, int64_t q0, int64_t nq, i
 static int fused_rest_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_pad, int kp, int parts, hipStream_t st) {
     // large batches of a plain search: optimistic thresholds (few-query searches have their own launch schedule, sharded searches
     // their agreed thresholds)
-    if (ix->optimistic && ix->opt_backoff == 0 && parts == 1 && ix->cur_parts == 1 && nq > kFewSelectMaxQueries) {
+    bool opt_on = ix->optimistic && ix->opt_backoff == 0;
+#ifdef LDOT_ABLATION
+    if (getenv("LDOT_DEBUG_NOOPT")) opt_on = false;   // (the kernel ablation variants produce no candidates: the end-of-scan check would redo every query)
+#endif
+    if (opt_on && parts == 1 && ix->cur_parts == 1 && nq > kFewSelectMaxQueries) {
         ix->opt_used = true;
         return fused_rest_chunk_optimistic(ix, q0, nq, nq_pad, kp, st);
     }
     int rc;
-    constexpr int64_t kFill = kPoolCap / 4;
+    constexpr int64_t kFill = kPoolFill;
     const int64_t bm = fused_tile_rows();
     const int qg = fused_query_group(nq_pad);
     const int64_t nslices = 256 / qg, nsubs = kPoolSubsPerSlice * nslices;

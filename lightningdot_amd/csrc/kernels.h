@@ -11,19 +11,29 @@ constexpr int kMaxK = 2048;        // largest k of a search
 constexpr int kMaxKp = 3072;       // largest candidate-list length k' = k + margin: k' + 1024 keys fit a 32 KiB LDS buffer
 constexpr int kSelThreads = 256;
 
-// fused-filter candidate pools: per query, nsubs = kPoolSubsPerSlice * (row slices) lane-private sub-pools of kPoolCap RECORDS.  A
-// record is what one lane holds when its 8-score test fires: the 4 + 4 scores of two vertically adjacent 16x16 MFMA tiles (rows
-// rb + {0,1,2,3} and rb + kPoolRecHiRow + {0,1,2,3}) and rb — three 16-byte planes {s0..s3}, {s4..s7}, {rb,-,-,-}, laid out entry-major
-// and plane-major: pool[((q * kPoolCap + e) * 3 + plane) * nsubs + sub].  The filter does not localise the hit (no per-score compares,
-// no nested branches on the matrix pipe's critical path: three stores straight from the accumulator registers); the pool select
-// applies the threshold to the 8 scores of every record.
-// sub-pool id = ((slice * 2 + wm) * 4 + (lane >> 4)); slices = 256 / (query blocks per XCD) = 32 .. 256
-constexpr int kPoolCap = 16;
+// fused-filter candidate pools: per query, nsubs = kPoolSubsPerSlice * (row slices) sub-pools of kPoolCap RECORDS.  A record is what
+// one lane holds when its 8-score test fires: the 4 + 4 scores of two vertically adjacent 16x16 MFMA tiles (rows rb + {0,1,2,3} and
+// rb + kPoolRecHiRow + {0,1,2,3}) and rb — three 16-byte planes {s0..s3}, {s4..s7}, {rb,-,-,-}, laid out entry-major and plane-major:
+// pool[((q * kPoolCap + e) * 3 + plane) * nsubs + sub].  The filter does not localise the hit (no per-score compares, no nested
+// branches on the matrix pipe's critical path: three stores straight from the accumulator registers); the pool select applies the
+// threshold to the 8 scores of every record.
+// A sub-pool (id = slice * 4 + wm: one per row slice and wave row) is shared by the four lanes of a query column — the four row
+// quads (lane >> 4) of a 16-row MFMA block — WITHOUT any coordination between them: lane group g owns the entries
+// [g * kPoolGroupCap, (g + 1) * kPoolGroupCap) and byte g of the sub-pool's 32-bit counter (its own count, saturating at 255).  The
+// select reads ONE counter word per sub-pool (128 per query at 32 row slices; round 3's 256 lane-private sub-pools cost it 109 us per
+// launch against 86 us with 128) and maps the records of a sub-pool to their entries through its four byte counts (pool_entry_of).
+// (Cursors shared by the four lanes — consecutive slots from a ballot — were built first: the rare path grew from ~12 to ~33
+// instructions and the admissions from 0.21 to 0.45 ms per pass, profiles/r04_ab_t16b.txt.)
+constexpr int kPoolGroups = 4;
+constexpr int kPoolGroupCap = 8;
+constexpr int kPoolCap = kPoolGroups * kPoolGroupCap;   // entries of a sub-pool
+constexpr int kPoolFill = 4;           // launches are sized for <= this many expected records per sub-pool (1 per lane group of capacity 8:
+                                       // P(Poisson(1) > 8) ~ 1e-6 per cell and launch where the bound is the active one)
 constexpr int kPoolPlanes = 3;
 constexpr int kPoolRecBytes = 16 * kPoolPlanes;
-constexpr int kPoolSubsPerSlice = 8;   // 2 wave rows x 4 lane groups (the C/D layout of v_mfma_f32_16x16x32: lane l holds rows (l >> 4) * 4 .. + 4)
+constexpr int kPoolSubsPerSlice = 4;   // 4 wave rows (round 3: 2 wave rows x 4 lane-private groups)
 constexpr int kPoolRecHiRow = 16;      // row offset of a record's second quad (the 16-row MFMA tile below)
-constexpr int kPoolSubsMax = 2048;     // query-group width 1: 256 row slices x 8
+constexpr int kPoolSubsMax = 1024;     // query-group width 1: 256 row slices x 4
 
 // rows: convert n rows of `dtype` (row stride ld_src elements, d valid columns) into the padded fp32 master copy
 // and/or its bf16 shadow (row stride dpad, zero padded); optional L2 normalisation.  Rows [n, n_pad) are zero-filled.

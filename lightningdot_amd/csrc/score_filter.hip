@@ -10,23 +10,27 @@
 // v_mfma_f32_32x32x16_bf16.  Same flops per clock on paper; under the chip's power limit, with random operands, the 16x16x32 shape
 // sustains 2020 TFLOP/s MFMA-only against 1725 (it accumulates twice the K per accumulator read-modify-write), and this kernel's slab
 // loop (LDS fragment stream + direct-to-LDS slab loads) 1600-1615 against 1405-1455 (tools/mfma_ceiling.hip, lines "T16" / "W2").
-//   * workgroup = 512 threads = 8 waves (2 along M x 4 along N), wave tile 192 x 64 = 12 x 4 MFMA tiles, 192 accumulator VGPRs;
-//     workgroup tile 384 rows x 256 queries; 4-stage LDS ring of 32-deep K slabs (4 x 40 KiB = all 160 KiB), ONE k-step per slab;
+//   * workgroup = 512 threads = 8 waves; workgroup tile 384 rows x 256 queries; 4-stage LDS ring of 32-deep K slabs (4 x 40 KiB = all
+//     160 KiB), ONE k-step per slab;
+//   * Round 4: the waves are arranged 4 (rows) x 2 (queries) — wave tile 96 x 128 = 6 x 8 MFMA tiles, the same 192 accumulator VGPRs
+//     — instead of 2 x 4 (192 x 64): 6 + 8 = 14 fragment reads per slab and wave instead of 12 + 4 = 16, and in tools/mfma_ceiling.hip
+//     ("T16B") the slab loop carries 67.3-67.5 % of the peak against 64.8-65.2 % on the same box (profiles/r04_mfma_ceiling_t16b.txt);
 //   * a fragment (16 rows x 32 k) is one 1-KiB block of the ring image: lane l reads row l & 15, 16-byte chunk (l >> 4) ^ ((row >> 1) & 3)
 //     (the swizzle is applied on the per-lane SOURCE address of the direct-to-LDS loads, conflict-free ds_read_b128);
-//   * A fragments live in a ring of THREE register quads (row block i uses a[i % 3], refilled with block i + 3 right after its four
-//     MFMAs — 12 MFMAs = 192 cycles ahead); the four B fragments of the next slab are fetched during the last three row blocks;
-//   * slabs are issued 3 ahead and retired by a counted s_waitcnt vmcnt + one raw s_barrier per slab, placed before row block 9: by
+//   * A fragments live in a ring of THREE register quads (row block i uses a[i % 3], refilled with block i + 3 right after its eight
+//     MFMAs); the EIGHT B fragments are single-buffered and refilled in place during the last row block of a slab (b[j] right after its
+//     last MFMA: seven MFMAs = 112 cycles before its first use in the next slab);
+//   * slabs are issued 3 ahead and retired by a counted s_waitcnt vmcnt + one raw s_barrier per slab, placed before row block 3: by
 //     then every fragment of the current stage is in registers (the stage is free for the slab 4 ahead) and the next stage is about
 //     to be read.
 //
-// C/D layout of 16x16x32: lane l holds rows (l >> 4) * 4 .. + 4 of column l & 15.  A lane therefore owns FOUR query columns (column
-// block j = 0..3: query wn * 64 + j * 16 + (l & 15)) and, per column, 4 rows of each of the wave's 12 row blocks.
+// C/D layout of 16x16x32: lane l holds rows (l >> 4) * 4 .. + 4 of column l & 15.  A lane therefore owns EIGHT query columns (column
+// block j = 0..7: query wn * 128 + j * 16 + (l & 15)) and, per column, 4 rows of each of the wave's 6 row blocks.
 //
-// Appends go to lane-private sub-pools in HBM (cursor in a VGPR byte, no atomics, no LDS; letting lanes l and l ^ 32 SHARE a sub-pool —
-// identical cursor copies, both run the rare path when either fires — halves the sub-pools the select walks but costs the kernel what it
-// saves the select: 12.84 vs 12.82 ms per pass, profiles/r03_subpool_sharing_ab.txt): for a query q each of the
-// 8 (wave row, lane group) x (row slices) that can produce candidates owns kPoolCap RECORDS.  A record is what a lane holds when its
+// Appends go to sub-pools in HBM (cursor in a VGPR byte, no atomics, no LDS).  For a query q each of the 4 (wave rows) x (row slices) that
+// can produce candidates owns a sub-pool of kPoolCap RECORDS, in which the four lanes of a query column (lanes c, c + 16, c + 32, c + 48:
+// the four row quads of a 16-row block) own eight entries and one counter byte each — 128 sub-pools and counter words per query at 32 row
+// slices, with lane-private cursors (kernels.h).  A record is what a lane holds when its
 // max-of-8 test fires: the 4 + 4 scores of two vertically adjacent tiles (rows rb + {0,1,2,3} and rb + 16 + {0,1,2,3}) and rb — three
 // 16-byte planes, stored entry-major and plane-major, pool[((q * kPoolCap + e) * 3 + plane) * nsubs + sub] in 16-byte units, so that the
 // select kernel, which folds the pools into the running top-k' list between launches and raises tau, reads one entry level of
@@ -97,58 +101,61 @@ __device__ __forceinline__ uint32_t lane_now() {
     return l;
 }
 
-constexpr int kT16RowBlocks = 12;   // 16-row blocks of a wave tile (192 rows)
-constexpr int kT16ColBlocks = 4;    // 16-query blocks of a wave tile (64 queries)
+constexpr int kT16RowBlocks = 6;    // 16-row blocks of a wave tile (96 rows)
+constexpr int kT16ColBlocks = 8;    // 16-query blocks of a wave tile (128 queries)
 
-// threshold filter of one PAIR of row blocks (2p, 2p + 1) of the wave tile: the lane's four query columns, eight scores per test
-// (three v_max3 + v_max + compare + branch on the fast path).  A firing test does NOT localise the hit: the lane appends one
-// record = the 8 scores (two 16-byte stores straight from the accumulator registers) + their base row to its sub-pool (cursor
-// byte j of `curp`, clamped at kPoolCap; the true count — saturating at 255 — is kept so that overflow is detectable) and the pool
-// select thresholds them.  Record address in 16-byte units: (q * kPoolCap * 3) * nsubs + sub + (e * 3 + plane) * nsubs with
-// q = q_u + 16 j + (lane & 15) and sub = sub_u + (lane >> 4): pbase_u carries the wave-uniform part (a scalar), the lane's part is
-// derived in the rare path.
-// the compares, ONE wave-uniform branch, and the rare admissions of a pair whose maxima m are complete
+constexpr int kFiltCols = 4;        // column blocks per filter call (half a wave tile: the thresholds of a half are unpacked together)
+
+// threshold filter of one PAIR of row blocks (2p, 2p + 1) over FOUR of the lane's eight query columns (column blocks jbase .. jbase + 3),
+// eight scores per test (three v_max3 + v_max + compare on the fast path, one wave-uniform branch per call).  A firing test does NOT
+// localise the hit: the lane appends one record = the 8 scores (two 16-byte stores straight from the accumulator registers) + their
+// base row to ITS entries of the column's sub-pool and the pool select thresholds them.  Cursor byte jj of `curp` is the lane's own count
+// for column block jbase + jj (saturating at 255, so that overflow is detectable; records beyond kPoolGroupCap are dropped).  Record
+// address in 16-byte units: (q * kPoolCap * 3) * nsubs + sub + (e * 3 + plane) * nsubs with q = q_u + 16 j + (lane & 15) and
+// e = (lane >> 4) * kPoolGroupCap + count: pbase_u carries the wave-uniform part incl. the sub-pool (a scalar), the lane's part is derived in
+// the rare path.
 template <bool NOSTORE>
-__device__ __forceinline__ void filter_admit(const f32x4 (&lo)[kT16ColBlocks], const f32x4 (&hi)[kT16ColBlocks], int p,
-                                             const float (&m)[kT16ColBlocks], const float (&tau)[kT16ColBlocks], uint32_t& curp,
-                                             uint32_t pbase_u, uint32_t pstep, uint32_t nsubs, uint4* __restrict__ pool, uint32_t vo0,
-                                             int32_t rb0) {
+__device__ __forceinline__ void filter_admit(const f32x4* lo, const f32x4* hi, int p, int jbase, const float (&m)[kFiltCols],
+                                             const float (&tau)[kFiltCols], uint32_t& curp, uint32_t pbase_u, uint32_t pstep,
+                                             uint32_t nsubs, uint4* __restrict__ pool, int32_t row_w) {
     const bool any = (m[0] >= tau[0]) | (m[1] >= tau[1]) | (m[2] >= tau[2]) | (m[3] >= tau[3]);
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(any) == 0, 1)) return;   // (rare otherwise: a few per tile and wave; laid out of line)
-    // The rare path's cost follows its INSTRUCTION count (one wave issuing dependent instructions: ~8 cycles each, 11.7 M admissions per
-    // pass), not its store count (records of 4 scores and two stores were measured: slower).  Everything per lane that does not depend on
-    // the hit — byte offset of the lane's sub-pool entry 0 (vo0), first row of the lane's rows in the tile (rb0) — is computed once per
-    // tile by the caller, from lane_now() (values that live across the slab loop would be spilled, see there).
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(any) == 0, 1)) return;   // (laid out of line)
+    // The rare path's cost follows its INSTRUCTION count (one wave issuing dependent instructions), not its store count.  Everything per
+    // lane that does not depend on the hit — byte offset of the first of the lane's entries (vo0), first of the lane's rows in the pair
+    // (rb) — is derived here from lane_now(): values that live across the slab loop would be spilled (see there).
+    const uint32_t ln = lane_now();
+    const uint32_t g4 = ln >> 4;
+    const uint32_t vo0 = (((ln & 15u) * (pstep >> 4)) << 4) + g4 * (kPoolGroupCap * kPoolPlanes * 16u) * nsubs;
+    const int32_t rb = row_w + 4 * (int32_t)g4 + p * 32;
 #pragma unroll
-    for (int j = 0; j < kT16ColBlocks; ++j) {
-        const f32x4 a = lo[j], b = hi[j];
-        if (m[j] >= tau[j]) {
-            const uint32_t e = (curp >> (8 * j)) & 255u;
-            if (e < 255u) curp += 1u << (8 * j);
-            if (e < (uint32_t)kPoolCap && !NOSTORE) {
+    for (int jj = 0; jj < kFiltCols; ++jj) {
+        if (m[jj] >= tau[jj]) {
+            const uint32_t e = (curp >> (8 * jj)) & 255u;
+            if (e < 255u) curp += 1u << (8 * jj);
+            if (e < (uint32_t)kPoolGroupCap && !NOSTORE) {
                 // buffer stores: the wave-uniform base lives in the (scalar) resource, the plane and the column block in the scalar
                 // offset, so the lane's address is ONE register
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void*)(pool + pbase_u), 0, (int)(pstep * 64u), 0x00020000);
+                const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void*)(pool + pbase_u), 0, (int)(pstep * 16u * kT16ColBlocks), 0x00020000);
                 const uint32_t vo = vo0 + e * (kPoolPlanes * nsubs * 16u);
-                const uint32_t so = (uint32_t)j * pstep * 16u;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), pr, vo, so, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, b), pr, vo, so + nsubs * 16u, 0);
-                __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(rb0 + p * 32), pr, vo, so + nsubs * 32u, 0);
+                const uint32_t so = (uint32_t)(jbase + jj) * pstep * 16u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo[jj]), pr, vo, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi[jj]), pr, vo, so + nsubs * 16u, 0);
+                __builtin_amdgcn_raw_buffer_store_b32((uint32_t)rb, pr, vo, so + nsubs * 32u, 0);
             }
         }
     }
 }
 
-// maxima (two statements of two interleaved chains) + admission of a pair in one block (first pair of the fused slab, stand-alone epilogue)
+// maxima (two statements of two interleaved chains) + admission of a pair over four column blocks
 template <bool NOSTORE>
-__device__ __forceinline__ void filter_pair(const f32x4 (&lo)[kT16ColBlocks], const f32x4 (&hi)[kT16ColBlocks], int p,
-                                            const float (&tau)[kT16ColBlocks], uint32_t& curp, uint32_t pbase_u, uint32_t pstep,
-                                            uint32_t nsubs, uint4* __restrict__ pool, uint32_t vo0, int32_t rb0) {
-    float m[kT16ColBlocks];
+__device__ __forceinline__ void filter_pair(const f32x4* lo, const f32x4* hi, int p, int jbase, const float (&tau)[kFiltCols],
+                                            uint32_t& curp, uint32_t pbase_u, uint32_t pstep, uint32_t nsubs, uint4* __restrict__ pool,
+                                            int32_t row_w) {
+    float m[kFiltCols];
     max8x2_raw(lo[0], hi[0], lo[1], hi[1], m[0], m[1]);
     max8x2_raw(lo[2], hi[2], lo[3], hi[3], m[2], m[3]);
-    filter_admit<NOSTORE>(lo, hi, p, m, tau, curp, pbase_u, pstep, nsubs, pool, vo0, rb0);
+    filter_admit<NOSTORE>(lo, hi, p, jbase, m, tau, curp, pbase_u, pstep, nsubs, pool, row_w);
 }
 
 // VAR (ablation builds): 1 no filter at all, 8 no record stores, 16 tau = +inf (fast path only), 128 program order not pinned.
@@ -163,11 +170,11 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave >> 1, wn = wave & 1;           // 4 wave rows x 2 wave columns: wave tile 96 rows x 128 queries
     const int qg = 1 << qg_log2;                       // query blocks in flight per XCD
     const int nstream = 32 >> qg_log2;                 // row streams per XCD
     const int nslices = 8 * nstream;                   // row slices of the launch
-    const int nsubs = nslices * kPoolSubsPerSlice;     // lane-private sub-pools per query
+    const int nsubs = nslices * kPoolSubsPerSlice;     // sub-pools per query (one per row slice and wave row)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int qsub = slot & (qg - 1), nsub = slot >> qg_log2;
     const int slice = xcd * nstream + nsub;
@@ -192,29 +199,6 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
     sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)l_t * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
     sb.rsrc = ring_make_rsrc_n(Q16 + (int64_t)(qsub + l_q * qg) * kRBN * ldq_b, kRBN * ldq_b);
     int64_t issued = 0;
-    // VAR & 256 (experiment): L2 touch-ahead of the row panel.  The eight workgroups of an XCD that multiply the same row tile with
-    // different query blocks all fetch it within microseconds of each other; whoever comes first takes the HBM latency in its
-    // 4-slab LDS ring.  Here the workgroup with qsub == 0 requests every 128-byte line of the row slab kTouchLead slabs AHEAD of the load
-    // cursor (waves 0..2, one line per lane, 192 lines = the 24 KiB slab) with a plain load whose result nobody reads, so that the
-    // direct-to-LDS loads of all eight find the lines in L2.
-    constexpr bool kTouch = (VAR & 256) != 0;
-    constexpr int kTouchLead = 6;
-    const bool toucher = kTouch && qsub == 0 && wave < 3;
-    int t_t = t0, t_k = kTouchLead;    // touch cursor: (row tile, slab) — nk = 24 > kTouchLead for the shapes this experiment runs on
-    uint32_t touch_sink = 0;
-    auto touch = [&]() {
-        if (toucher) {
-            const uint32_t ln = lane_now();
-            const uint32_t voff = ((uint32_t)wave * 8u + (ln >> 3)) * 16u * (uint32_t)ldx_b + (ln & 7u) * 128u;
-            const char* base = X16 + (row0 + (int64_t)t_t * Geo::kBM) * ldx_b + (int64_t)t_k * 1024;
-            asm volatile("global_load_dword %0, %1, %2" : "+v"(touch_sink) : "v"(voff), "s"(base) : "memory");
-        }
-        if (++t_k == nk) {
-            t_k = 0;
-            t_t += nslices;
-            while (t_t >= ntiles) t_t -= ntiles;
-        }
-    };
     // one slab = kLoads pieces per wave (3 of the row panel, 2 of the query panel); issue() sends them into the stage of slab
     // `issued` as a burst and moves the cursor on
     auto issue = [&]() {
@@ -228,7 +212,6 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(sb.rsrc, (rg_lptr_t)(st + Geo::kAOpBytes + ((j - Geo::kALoads) * 8 + wave) * 1024),
                                                          16, vo, k0b + (j - Geo::kALoads) * jstep, 0, 0);
         }
-        if (kTouch) touch();
         ++issued;
         if (issued < S) {
             if (++l_k == nk) {   // next unit of this stream
@@ -249,62 +232,67 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
     issue();
     issue();
     issue();
-    if (toucher)
-        wait_vmcnt<3 * Geo::kLoads + 4>();   // (a toucher's counter also carries its touches: four of them are younger than slab 0's pieces)
-    else
-        wait_vmcnt<3 * Geo::kLoads>();
+    wait_vmcnt<3 * Geo::kLoads>();
     __builtin_amdgcn_s_barrier();
 
     // ---- compute side --------------------------------------------------------------------------------------------------------
-    float tau[kT16ColBlocks];
-    uint32_t curp = 0;                                                // four 8-bit sub-pool cursors (one per column block)
-    uint32_t pbase_u = 0;                                             // (uniform) record base of query column 0 / lane group 0 of the wave
+    // The thresholds of the wave's 128 query columns live PACKED in two registers (a lane owns eight columns, but its column's four
+    // lanes would hold four copies of each): lane (g4 = lane >> 4, c = lane & 15) keeps tau of column block g4 in tq[0] and of column
+    // block 4 + g4 in tq[1]; the filter unpacks the four thresholds of a half with ds_bpermute once per tile.  (Eight threshold
+    // registers per lane were spilled around the slab loop, and a scratch reload is an s_waitcnt vmcnt(0) that drains the LDS-DMA ring.)
+    float tq[2];
+    uint32_t curp[2] = {0u, 0u};                                      // eight 8-bit sub-pool cursors (one per column block)
+    uint32_t pbase_u = 0;                                             // (uniform) record base of query column 0 of the wave, its sub-pool included
     const uint32_t pstep = 16u * kPoolCap * kPoolPlanes * (uint32_t)nsubs;   // ... the next column block is 16 queries further
     f32x4 acc[kT16RowBlocks][kT16ColBlocks];
-    bf16x8_t a[3], b[2][kT16ColBlocks];
+    constexpr int kARing = 2;      // A fragment ring (row block i uses a[i % kARing], refilled with block i + kARing after its eight MFMAs)
+    bf16x8_t a[kARing], b[kT16ColBlocks];
     const int frow = lane & 15;
     const int foff = frow * 64 + (((lane >> 4) ^ ((frow >> 1) & 3)) << 4);   // lane's 16 bytes inside a 1-KiB fragment block
     {
-        const char* a_w = smem + wm * (192 * 64) + foff;
-        const char* b_w = smem + Geo::kAOpBytes + wn * (64 * 64) + foff;
+        const char* a_w = smem + wm * (96 * 64) + foff;
+        const char* b_w = smem + Geo::kAOpBytes + wn * (128 * 64) + foff;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) a[i] = *(const bf16x8_t*)(a_w + i * 1024);
-#pragma unroll
-        for (int j = 0; j < kT16ColBlocks; ++j) b[0][j] = *(const bf16x8_t*)(b_w + j * 1024);
+        for (int i = 0; i < kARing; ++i) a[i] = *(const bf16x8_t*)(a_w + i * 1024);
+        (void)b_w;   // (the first slab of every tile fetches its B fragments itself, see slab())
     }
     int64_t s = 0;
-    int32_t epi_row_wave0 = 0;    // (uniform) first row of the wave's block of the tile whose filter is pending
-    // MODE 0: a slab inside a tile.  MODE 1: the first slab of a tile (its MFMAs take C = 0 instead of a cleared accumulator).
-    // (Until the A/B of profiles/r03_t16_standalone.txt the filter of a finished tile was FUSED into the first slab of the next one —
-    // MODE 2, with the slab-load burst deferred around it; that code is in the history, commit 7a1f30d.)
-    auto slab = [&](auto mode_tag, auto cur_tag) {
+    // MODE 0: a slab inside a tile.  MODE 1: the first slab of a tile (its MFMAs take C = 0 instead of a cleared accumulator; it fetches its
+    // own eight B fragments first).  MODE 2: the last slab of a tile: it does NOT prefetch the next slab's B fragments, so that their 32
+    // registers are free during the tile's filter — with them live the filter's rare path spilled, and a scratch reload is an
+    // s_waitcnt vmcnt(0) that drains the LDS-DMA ring (the price: one exposed LDS round trip per tile, ~150 cycles of 40 000).
+    // (Earlier forms — the filter fused into the next tile's first slab, 12 x 4 wave tiles with double-buffered B fragments — are in
+    // the history: commits 7a1f30d, 10d3493.)
+    auto slab = [&](auto mode_tag) {
         constexpr int MODE = decltype(mode_tag)::value;
-        constexpr int CUR = decltype(cur_tag)::value;
         const char* st0 = smem + (int)(s & 3) * Geo::kStage;
         const char* st1 = smem + (int)((s + 1) & 3) * Geo::kStage;
-        const char* a_cur = st0 + wm * (192 * 64) + foff;
-        const char* a_nxt = st1 + wm * (192 * 64) + foff;
-        const char* b_nxt = st1 + Geo::kAOpBytes + wn * (64 * 64) + foff;
+        const char* a_cur = st0 + wm * (96 * 64) + foff;
+        const char* a_nxt = st1 + wm * (96 * 64) + foff;
+        const char* b_nxt = st1 + Geo::kAOpBytes + wn * (128 * 64) + foff;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if (MODE == 1) {
+            const char* b_cur = st0 + Geo::kAOpBytes + wn * (128 * 64) + foff;
+#pragma unroll
+            for (int j = 0; j < kT16ColBlocks; ++j) b[j] = *(const bf16x8_t*)(b_cur + j * 1024);
+        }
 #pragma unroll
         for (int i = 0; i < kT16RowBlocks; ++i) {
-            if (i == 9) {
-                // every fragment of stage s is in registers or consumed (its stage may be refilled), slab s + 1 must have landed
+            if (i == kT16RowBlocks - kARing) {
+                // every fragment of stage s is in registers or consumed (its stage may be refilled), slab s + 1 must have landed: its
+                // first fragment is read right below
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of slab s are complete (WAR on its stage)
-                if (kTouch && toucher)
-                    wait_vmcnt<2 * Geo::kLoads + 3>();               // (+ the three touches issued behind slab s+1's pieces)
-                else
-                    wait_vmcnt<2 * Geo::kLoads>();                   // slab s+1 has landed (this thread's part) ...
+                wait_vmcnt<2 * Geo::kLoads>();                       // slab s+1 has landed (this thread's part) ...
                 __builtin_amdgcn_s_barrier();                        // ... and everybody else's
             }
 #pragma unroll
-            for (int j = 0; j < kT16ColBlocks; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i % 3], b[CUR][j], MODE == 0 ? acc[i][j] : z, 0, 0, 0);
-            a[i % 3] = *(const bf16x8_t*)(i + 3 < kT16RowBlocks ? a_cur + (i + 3) * 1024 : a_nxt + (i + 3 - kT16RowBlocks) * 1024);
-            if (i >= 9) b[CUR ^ 1][i - 9] = *(const bf16x8_t*)(b_nxt + (i - 9) * 1024);
-            if (i == 11) b[CUR ^ 1][3] = *(const bf16x8_t*)(b_nxt + 3 * 1024);
-            if (!(VAR & 128)) __builtin_amdgcn_sched_barrier(0);   // program order pinned after every row block (VAR & 128: left to the scheduler, +0.35 ms)
+            for (int j = 0; j < kT16ColBlocks; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i % kARing], b[j], MODE == 1 ? z : acc[i][j], 0, 0, 0);
+                if (i == kT16RowBlocks - 1 && MODE != 2) b[j] = *(const bf16x8_t*)(b_nxt + j * 1024);   // in place: next slab's fragment j
+            }
+            a[i % kARing] = *(const bf16x8_t*)(i + kARing < kT16RowBlocks ? a_cur + (i + kARing) * 1024 : a_nxt + (i + kARing - kT16RowBlocks) * 1024);
+            if (!(VAR & 128)) __builtin_amdgcn_sched_barrier(0);   // program order pinned after every row block (VAR & 128: left to the scheduler)
         }
         __builtin_amdgcn_sched_barrier(0);
         ++s;
@@ -313,44 +301,40 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
     };
     using M0 = std::integral_constant<int, 0>;
     using M1 = std::integral_constant<int, 1>;
-    using C0 = std::integral_constant<int, 0>;
-    using C1 = std::integral_constant<int, 1>;
-    // (the B double buffer alternates with the slab parity.  A tile has an EVEN number of slabs — the row stride is a multiple of 64
-    // elements —, so the first slab of every tile has parity 0 and the parity of every call below is a compile-time constant: a
-    // run-time dispatch on (s & 1) doubled the slab body behind a branch and cost the register allocator 1500 spills)
+    using M2 = std::integral_constant<int, 2>;
 
-    // the counters' query index is recomputed at store time (registers are scarce across the tile loop)
+    // the counters' query index is recomputed at store time (registers are scarce across the tile loop); a lane stores ITS byte of the
+    // sub-pool's counter word
     auto store_counts = [&](int g) {
 #pragma unroll
         for (int j = 0; j < kT16ColBlocks; ++j) {
             const uint32_t ln = lane_now();
-            const int64_t qi = (int64_t)(qsub + g * qg) * kRBN + wn * 64 + j * 16 + (int)(ln & 15u);
-            pool_cnt[qi * nsubs + (slice * 2 + wm) * 4 + (int)(ln >> 4)] = (int32_t)((curp >> (8 * j)) & 255u);
+            const int64_t qi = (int64_t)(qsub + g * qg) * kRBN + wn * 128 + j * 16 + (int)(ln & 15u);
+            ((unsigned char*)pool_cnt)[(qi * nsubs + slice * kPoolSubsPerSlice + wm) * 4 + (ln >> 4)] =
+                (unsigned char)((curp[j >> 2] >> (8 * (j & 3))) & 255u);
         }
     };
     auto setup_group = [&](int g) {
 #pragma unroll
-        for (int j = 0; j < kT16ColBlocks; ++j) {
-            const int64_t qi = (int64_t)(qsub + g * qg) * kRBN + wn * 64 + j * 16 + (int)(lane_now() & 15u);
-            tau[j] = (VAR & 16) ? INFINITY : ring_launder(tau_g[qi]);
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t ln = lane_now();
+            const int64_t qi = (int64_t)(qsub + g * qg) * kRBN + wn * 128 + (4 * h + (int)(ln >> 4)) * 16 + (int)(ln & 15u);
+            tq[h] = (VAR & 16) ? INFINITY : ring_launder(tau_g[qi]);
         }
-        pbase_u = (uint32_t)(((int64_t)(qsub + g * qg) * kRBN + wn * 64) * kPoolCap * kPoolPlanes * nsubs + (slice * 2 + wm) * 4);
-        curp = 0;
+        pbase_u = (uint32_t)(((int64_t)(qsub + g * qg) * kRBN + wn * 128) * kPoolCap * kPoolPlanes * nsubs + slice * kPoolSubsPerSlice + wm);
+        curp[0] = curp[1] = 0;
     };
     int c_q = g0, c_t = t0, cur_q = g0;
     setup_group(c_q);
-    slab(M1{}, C0{});
+    slab(M1{});
 #pragma unroll 1
     for (int jt = 0; jt < ntile_total; ++jt) {
 #pragma unroll 1
-        for (int kk = 1; kk + 1 < nk; kk += 2) {
-            slab(M0{}, C1{});
-            slab(M0{}, C0{});
-        }
-        slab(M0{}, C1{});
+        for (int kk = 1; kk + 1 < nk; ++kk) slab(M0{});
+        slab(M2{});    // (nk >= 2: the row stride is a multiple of 64 elements)
         // tile jt is complete in acc
         const int64_t trow = row0 + (int64_t)c_t * Geo::kBM;
-        epi_row_wave0 = (int32_t)trow + wm * 192;
+        const int32_t row_w = (int32_t)trow + wm * 96;    // (uniform) first row of the wave's block of the tile
         c_t += nslices;
         while (c_t >= ntiles) {
             c_t -= ntiles;
@@ -359,16 +343,20 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
         const bool more = jt + 1 < ntile_total;
         if (!(VAR & 1)) {
             // the filter of the finished tile, on its own: all eight waves run it at the same time and the matrix pipe idles meanwhile
-            // (~0.6 us per tile without admissions, 0.24 ms per pass).  Hiding it in the next tile's first slab was not faster in the
-            // final build and 0.4 ms SLOWER in the one before (profiles/r03_t16_standalone.txt, r03_final_variants.txt).
+            // (~0.6 us per tile without admissions).  Hiding it in the next tile's first slab was not faster (profiles/r03_t16_standalone.txt).
             filter_hazard_cover();
-            const uint32_t ln = lane_now();
-            const uint32_t g4 = (ln >> 4) & 3u;
-            const uint32_t vo0 = ((ln & 15u) * (pstep >> 4) + g4) << 4;      // byte offset of entry 0 of the lane's sub-pool (column block 0)
-            const int32_t rb0 = epi_row_wave0 + 4 * (int32_t)g4;             // first of the lane's rows in row block 0 of the tile
 #pragma unroll
-            for (int p = 0; p < kT16RowBlocks / 2; ++p)
-                filter_pair<(VAR & 8) != 0>(acc[2 * p], acc[2 * p + 1], p, tau, curp, pbase_u, pstep, (uint32_t)nsubs, pool, vo0, rb0);
+            for (int h = 0; h < 2; ++h) {
+                float tau[kFiltCols];
+                const int bp = (int)((lane_now() & 15u) << 2);     // byte address of lane c (lane group 0) for ds_bpermute
+#pragma unroll
+                for (int jj = 0; jj < kFiltCols; ++jj)
+                    tau[jj] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bp + jj * 64, __builtin_bit_cast(int, tq[h])));
+#pragma unroll
+                for (int p = 0; p < kT16RowBlocks / 2; ++p)
+                    filter_pair<(VAR & 8) != 0>(&acc[2 * p][4 * h], &acc[2 * p + 1][4 * h], p, 4 * h, tau, curp[h], pbase_u, pstep,
+                                                (uint32_t)nsubs, pool, row_w);
+            }
             __builtin_amdgcn_sched_barrier(0);
         } else if (!more) {
 #pragma unroll
@@ -377,7 +365,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
                 for (int j = 0; j < kT16ColBlocks; ++j) asm volatile("" ::"v"(acc[i][j]));
         }
         if (more) {
-            slab(M1{}, C0{});
+            slab(M1{});
             if (c_q != cur_q) {             // (uniform) the stream moves on to the next query group
                 store_counts(cur_q);
                 cur_q = c_q;
@@ -387,7 +375,6 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
     }
     store_counts(cur_q);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing dummy loads must land before the LDS is released
-    if (kTouch) asm volatile("" ::"v"(touch_sink));    // (the touches' destination register stays allocated until they have landed)
 }
 
 // index rows per fused tile (the host sizes launches and the row padding of the index with it)
@@ -417,7 +404,7 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
 #ifdef LDOT_ABLATION
     // Ablation builds only (python -m lightningdot_amd.build --ablation -> libldot_ablation.so; tools/ab.sh): LDOT_DEBUG_VARIANT selects
     // a profiling variant of the kernel.  Results are meaningless under most of them, so the product library does not contain this hook.
-    //   16 tau = +inf (filter fast path only), 17 no filter at all, 8 no record stores, 128 program order not pinned, 256 L2 touch-ahead
+    //   16 tau = +inf (filter fast path only), 17 no filter at all, 8 no record stores, 128 program order not pinned
     static int variant = -1;
     if (variant < 0) {
         const char* e = getenv("LDOT_DEBUG_VARIANT");
@@ -427,8 +414,6 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     if (variant == 17) rk = score_filter_t16_kernel<17>;
     if (variant == 8) rk = score_filter_t16_kernel<8>;
     if (variant == 128) rk = score_filter_t16_kernel<128>;    // row blocks NOT pinned in program order (the scheduler sinks the fragment loads)
-    if (variant == 256) rk = score_filter_t16_kernel<256>;    // L2 touch-ahead of the row panel (see the kernel)
-    if (variant == 272) rk = score_filter_t16_kernel<272>;    // ... with tau = +inf
     LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<6>::kLds));
 #else
     static bool attr_set[kAttrDevices];

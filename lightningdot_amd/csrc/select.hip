@@ -751,7 +751,32 @@ __device__ __forceinline__ int pool_rec_row(int j) { return j < 4 ? j : j - 4 + 
 // LDS per workgroup would cost a workgroup per CU: 160 KiB / 33 KiB = 4 instead of 5).
 constexpr int kSlotWin = 256;
 constexpr int kSlotKeys = kSlotWin / 8;
-__device__ __forceinline__ void walk_subpools(WaveSelector& sel, const uint4* __restrict__ base, int nsubs, int s0, int c,
+
+// A sub-pool's counter word packs the counts of its four lane groups (kernels.h).  pool_counts: the word with every byte clamped to the
+// group capacity, the total, and whether a group overflowed.  pool_entry_of: the entry of the sub-pool's e-th record (records numbered
+// group by group): group g owns the entries [g * kPoolGroupCap, ...).
+__device__ __forceinline__ uint32_t pool_counts(uint32_t word, int& total, bool& over) {
+    uint32_t clamped = 0;
+    total = 0;
+#pragma unroll
+    for (int g = 0; g < kPoolGroups; ++g) {
+        const uint32_t b = (word >> (8 * g)) & 255u;
+        over |= b > (uint32_t)kPoolGroupCap;
+        const uint32_t cb = b < (uint32_t)kPoolGroupCap ? b : (uint32_t)kPoolGroupCap;
+        clamped |= cb << (8 * g);
+        total += (int)cb;
+    }
+    return clamped;
+}
+__device__ __forceinline__ int pool_entry_of(int e, uint32_t clamped) {
+    const int p0 = (int)(clamped & 255u), p1 = p0 + (int)((clamped >> 8) & 255u), p2 = p1 + (int)((clamped >> 16) & 255u);
+    const int g = (e >= p0) + (e >= p1) + (e >= p2);
+    const int before = g == 0 ? 0 : g == 1 ? p0 : g == 2 ? p1 : p2;
+    return g * kPoolGroupCap + (e - before);
+}
+
+// (c = the sub-pool's record total, cw = its clamped counter word)
+__device__ __forceinline__ void walk_subpools(WaveSelector& sel, const uint4* __restrict__ base, int nsubs, int s0, int c, uint32_t cw,
                                               int32_t row_end, unsigned char* slot) {
     const int lane = threadIdx.x & 63;
     int incl = c;
@@ -776,7 +801,7 @@ __device__ __forceinline__ void walk_subpools(WaveSelector& sel, const uint4* __
             const int j = r0 + lane;
             const bool have = j < wend;
             const int sub = have ? (int)slot[j - w0] : 0;
-            const int e = j - __shfl(excl, sub);
+            const int e = pool_entry_of(j - __shfl(excl, sub), (uint32_t)__shfl((int)cw, sub));
             const uint4* rec = base + (int64_t)e * kPoolPlanes * nsubs + s0 + sub;
             n0 = have ? rec[0] : make_uint4(0u, 0u, 0u, 0u);
             n1 = have ? rec[nsubs] : make_uint4(0u, 0u, 0u, 0u);
@@ -844,12 +869,12 @@ __global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(con
     // feed site: the selector's compaction is inlined there once).
     for (int s0 = 0; s0 < nsubs; s0 += kPoolSelThreads) {
         const int sidx = s0 + lane;
-        over |= cn > kPoolCap;
-        const int c = cn < kPoolCap ? cn : kPoolCap;
+        int c;
+        const uint32_t cw = pool_counts((uint32_t)cn, c, over);
         nrec += c;
         if (sidx < nsubs) cnt[sidx] = 0;
         cn = sidx + kPoolSelThreads < nsubs ? cnt[sidx + kPoolSelThreads] : 0;   // next step's counters
-        walk_subpools(sel, base, nsubs, s0, (dbg & 1) ? 0 : c, row_end, slot);
+        walk_subpools(sel, base, nsubs, s0, (dbg & 1) ? 0 : c, cw, row_end, slot);
     }
     const bool any_over = __any(over);
     if (dbg & 2) return;
@@ -907,12 +932,12 @@ __global__ __launch_bounds__(kPoolSelThreads) void select_pools_parts_kernel(con
     int nrec = 0;
     for (int s0 = s_beg; s0 < s_end; s0 += kPoolSelThreads) {
         const int sidx = s0 + lane;
-        int cn = sidx < s_end ? cnt[sidx] : 0;
+        const int cn = sidx < s_end ? cnt[sidx] : 0;
         if (sidx < s_end) cnt[sidx] = 0;
-        over |= cn > kPoolCap;
-        const int c = cn < kPoolCap ? cn : kPoolCap;
+        int c;
+        const uint32_t cw = pool_counts((uint32_t)cn, c, over);
         nrec += c;
-        walk_subpools(sel, base, nsubs, s0, sidx < s_end ? c : 0, row_end, slot);
+        walk_subpools(sel, base, nsubs, s0, sidx < s_end ? c : 0, cw, row_end, slot);
     }
     sel.compact();
     WaveSelector::wave_sync();
@@ -968,12 +993,14 @@ __global__ __launch_bounds__(kSelThreads) void select_pools_block_kernel(const u
         }
         if (s0 == 0) sel.load_list(ls, li);
         int cm = 0;
+        uint32_t cw[SPT];   // clamped counter words (four lane groups per sub-pool)
 #pragma unroll
         for (int g = 0; g < SPT; ++g) {
             const int sidx = s0 + g * kSelThreads + threadIdx.x;
             if (sidx < nsubs) cnt[sidx] = 0;
-            over |= c[g] > kPoolCap;
-            c[g] = c[g] < kPoolCap ? c[g] : kPoolCap;
+            int tot;
+            cw[g] = pool_counts((uint32_t)c[g], tot, over);
+            c[g] = tot;
             nrec += c[g];
             cm = max(cm, c[g]);
         }
@@ -984,8 +1011,8 @@ __global__ __launch_bounds__(kSelThreads) void select_pools_block_kernel(const u
             for (int g = 0; g < SPT; ++g)
 #pragma unroll
                 for (int u = 0; u < LV; ++u) {
-                    const uint4* rec = base + (int64_t)(e0 + u) * kPoolPlanes * nsubs + s0 + g * kSelThreads + threadIdx.x;
                     const bool have = e0 + u < c[g];
+                    const uint4* rec = base + (int64_t)(have ? pool_entry_of(e0 + u, cw[g]) : 0) * kPoolPlanes * nsubs + s0 + g * kSelThreads + threadIdx.x;
                     v[g][u][0] = have ? rec[0] : make_uint4(0u, 0u, 0u, 0u);
                     v[g][u][1] = have ? rec[nsubs] : make_uint4(0u, 0u, 0u, 0u);
                     rb[g][u] = have ? (int32_t)rec[2 * nsubs].x : row_end;

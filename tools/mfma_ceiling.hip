@@ -794,7 +794,7 @@ static void run_w1(K k, int lds_bytes, int slab_multiple, const char* name, cons
 // single-buffered and refilled IN PLACE during the last row block (b[j] right after its last MFMA: seven MFMAs = 112 cycles before its first
 // use in the next slab); A fragments in a ring of three as before.  The slab barrier sits before row block 3, where the first fragment of
 // the next stage is read.  FEED 1: fragment stream only, 2: + slab-load burst, 5: loads spread.
-template <int FEED>
+template <int FEED, int ARING = 3>
 __global__ __launch_bounds__(512, 2) void ceiling16b_kernel(const char* __restrict__ src, int64_t src_region, int nslab,
                                                             float* __restrict__ sink, uint64_t* __restrict__ ticks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -832,11 +832,11 @@ __global__ __launch_bounds__(512, 2) void ceiling16b_kernel(const char* __restri
     for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8_t a[3], b[8];
+    bf16x8_t a[ARING], b[8];
     const char* a_w0 = smem + wm * (96 * 64) + foff;
     const char* b_w0 = smem + kAOp + wn * (128 * 64) + foff;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) a[i] = *(const bf16x8_t*)(a_w0 + i * 1024);
+    for (int i = 0; i < ARING; ++i) a[i] = *(const bf16x8_t*)(a_w0 + i * 1024);
 #pragma unroll
     for (int j = 0; j < 8; ++j) b[j] = *(const bf16x8_t*)(b_w0 + j * 1024);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" ::: "memory");
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(512, 2) void ceiling16b_kernel(const char* __restri
         const char* b_nxt = st1 + kAOp + wn * (128 * 64) + foff;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            if (i == 3) {   // every fragment of this stage is in registers; the next stage's first fragment is read below
+            if (i == 6 - ARING) {   // every fragment of this stage is in registers; the next stage's first fragment is read below
                 __builtin_amdgcn_sched_barrier(0);
                 if (FEED == 2 || FEED == 5) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -857,10 +857,10 @@ __global__ __launch_bounds__(512, 2) void ceiling16b_kernel(const char* __restri
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i % 3], b[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i % ARING], b[j], acc[i][j], 0, 0, 0);
                 if (i == 5) b[j] = *(const bf16x8_t*)(b_nxt + j * 1024);
             }
-            a[i % 3] = *(const bf16x8_t*)((i + 3 < 6 ? a_cur + (i + 3) * 1024 : a_nxt + (i + 3 - 6) * 1024));
+            a[i % ARING] = *(const bf16x8_t*)((i + ARING < 6 ? a_cur + (i + ARING) * 1024 : a_nxt + (i + ARING - 6) * 1024));
             if (FEED == 5) {   // the slab that goes into the stage vacated at the barrier: pieces after row blocks 3, 4, 5 and 0, 1 of the next slab
                 if (i >= 3) issue_piece(i - 3);
                 if (i <= 1) issue_piece(3 + i);
@@ -890,9 +890,9 @@ __global__ __launch_bounds__(512, 2) void ceiling16b_kernel(const char* __restri
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int FEED>
+template <int FEED, int ARING = 3>
 static void run16b(const char* name, const char* src, int64_t region, float* sink, uint64_t* ticks, double target_ms) {
-    auto k = ceiling16b_kernel<FEED>;
+    auto k = ceiling16b_kernel<FEED, ARING>;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kStage));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -944,6 +944,8 @@ int main(int argc, char** argv) {
         run16b<1>("T16B (4x2 waves) mfma+ds_read  random", src, region, sink, ticks, target_ms);
         run16b<2>("T16B mfma+ds_read+lds-dma     random", src, region, sink, ticks, target_ms);
         run16b<5>("T16B full, dma interleaved    random", src, region, sink, ticks, target_ms);
+        run16b<2, 2>("T16B burst, A ring of TWO     random", src, region, sink, ticks, target_ms);
+        run16b<1, 2>("T16B ds_read only, A ring 2   random", src, region, sink, ticks, target_ms);
         run_w1(ceiling16w1_kernel<1>, 4 * kStage, 2, "T16W1 mfma+ds_read         random", src, region, sink, ticks, target_ms);
         run_w1(ceiling16w1_kernel<2>, 4 * kStage, 2, "T16W1 mfma+ds_read+lds-dma random", src, region, sink, ticks, target_ms);
         run_w1(ceiling16w1_kernel<5>, 4 * kStage, 2, "T16W1 full, dma interleaved random", src, region, sink, ticks, target_ms);
