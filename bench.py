@@ -59,6 +59,7 @@ def main():
     ap.add_argument('--force-sharded', action='store_true', help='run the sharded code path even with one rank')
     ap.add_argument('--split-bf16', action='store_true',
                     help='LDOT_OPT_PRECISION=1: split-bf16 candidate pass (3 MFMA products per element); not the headline')
+    ap.add_argument('--no-optimistic', action='store_true', help='LDOT_OPT_OPTIMISTIC = 0: guaranteed thresholds only (measurement aid; not the headline)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary workloads measured after the timed region')
     ap.add_argument('--no-kernel-events', action='store_true',
@@ -140,6 +141,8 @@ def main():
         ix.index.set_option(L.OPT_PROFILE, 0 if args.no_kernel_events else 1)
         if args.split_bf16:
             ix.index.set_option(L.OPT_PRECISION, 1)
+        if args.no_optimistic:
+            ix.index.set_option(L.OPT_OPTIMISTIC, 0)
         if args.growth:
             ix.index.set_option(L.OPT_GROWTH_PCT, args.growth)
         if args.warm:
