@@ -170,15 +170,16 @@ static void sgemm_dispatch(bool ak, bool bk, dim3 grid, hipStream_t st, const fl
 // ---- small problems (the in-batch loss itself: <= 512 x 1536 x 768): direct-operand GEMM ---------------------------------------------
 // The shapes of the loss are latency class (0.4 - 1.2 GFLOP): the 64 x 64 LDS-staged kernel above runs 64 - 192 workgroups through 24
 // barrier-separated slabs and takes 30 - 46 us where the flops are worth 3 - 8.  Here a workgroup owns ONE 32 x 32 output tile (256 - 768
-// workgroups for the forward shapes) and its four waves split K between them; every wave feeds v_mfma_f32_32x32x2_f32 straight from
+// workgroups for the forward shapes) and its KS (4 or 8) waves split K between them; every wave feeds v_mfma_f32_32x32x2_f32 straight from
 // global memory — no LDS staging, no barrier inside the K loop:
 //   * lane (r = l & 31, h = l >> 5) of the MFMA holds A[m0 + r][k] and B[n0 + r][k] for k = k0 + h of a K pair; a chunk of 32 k is
 //     consumed as 16 MFMAs in the order k = kc + 16 h + t, t = 0..15 (both operands use the same permutation of K inside a chunk, so
 //     every product pairs the right elements), which lets a lane fetch its 16 values of a K-contiguous operand as four float4
 //     (a full 128-B line per row and lane pair), or 16 coalesced dwords of an operand stored K-major;
-//   * chunks are dealt round-robin to the waves (wave w: chunks w, w + 4, ...), three chunk buffers per wave = two chunks in flight
+//   * chunks are dealt round-robin to the waves (wave w: chunks w, w + KS, ...), NB chunk buffers per wave = NB - 1 chunks in flight
 //     behind the one being multiplied;
-//   * the four partial tiles meet in LDS once, are summed in a fixed order ((w0 + w1) + (w2 + w3)) and leave coalesced.
+//   * the KS partial tiles meet in LDS once, are summed in a fixed order (((w0 + w1) + (w2 + w3)) [+ ((w4 + w5) + (w6 + w7))]) and
+//     leave coalesced.
 // The sum over K is a different (still fixed) order than the fmaf chain of the big kernel; both are exact-product fp32 sums.
 template <int N, typename F, int I = 0>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -254,15 +255,15 @@ struct NllFused {   // forward epilogue of the loss (EPI = 1): per (row, column 
 };
 
 // EPI 0: C = alpha * acc (+ C).  EPI 1 (forward of the loss): C = mix, + the softmax statistics of the tile's rows over its 32 columns.
-template <bool AKF, bool BKF, bool MIX, int EPI>
-__global__ __launch_bounds__(256) void sgemm_direct_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+template <bool AKF, bool BKF, bool MIX, int EPI, int KS>
+__global__ __launch_bounds__(64 * KS) void sgemm_direct_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
                                                            int64_t ldb, const float* __restrict__ B2, float* __restrict__ C, int64_t ldc,
                                                            int64_t M, int64_t N, int64_t K, float alpha, float w2, int accumulate,
                                                            NllFused nll) {
     // LDS: the waves' transposition areas (A, B, B2) during the K loop, the four partial tiles afterwards
     constexpr int kTrOps = MIX ? 3 : 2;
-    __shared__ __attribute__((aligned(16))) float smem[4 * kTrOps * kTrFloats];
-    static_assert(4 * 32 * 33 <= 4 * 2 * kTrFloats, "partial tiles alias the transposition areas");
+    __shared__ __attribute__((aligned(16))) float smem[KS * kTrOps * kTrFloats];
+    static_assert(KS * 32 * 33 <= KS * 2 * kTrFloats, "partial tiles alias the transposition areas");
     float (*red)[32][33] = (float (*)[32][33])smem;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: scalar chunk addresses)
     const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
@@ -272,7 +273,8 @@ __global__ __launch_bounds__(256) void sgemm_direct_kernel(const float* __restri
     for (int r = 0; r < 16; ++r) acc1[r] = acc2[r] = 0.f;
     // chunk buffers per wave: all six chunks of a wave's K quarter in flight at K = 768 (one memory round trip in front of the MFMAs
     // instead of three: the problem is latency class); the mix carries a second B operand and keeps four
-    constexpr int NB = MIX ? 4 : 6;
+    // (KS = 8: eight waves split K — three chunks each at K = 768 — and run two per SIMD: three buffers)
+    constexpr int NB = KS == 8 ? 3 : MIX ? 4 : 6;
     DirectChunk<AKF> a[NB];
     DirectChunk<BKF> b[NB], b2[MIX ? NB : 1];
     auto fetch = [&](auto bi_tag, int64_t c) {
@@ -293,38 +295,40 @@ __global__ __launch_bounds__(256) void sgemm_direct_kernel(const float* __restri
             if (MIX) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[bi].v[t], b2[MIX ? bi : 0].v[t], acc2, 0, 0, 0);
         }
     };
-    // wave w multiplies the chunks w, w + 4, ...; chunk number j of a wave lives in buffer j % NB and is fetched NB - 1 chunks ahead
+    // wave w multiplies the chunks w, w + KS, ...; chunk number j of a wave lives in buffer j % NB and is fetched NB - 1 chunks ahead
     static_for<NB - 1>([&](auto j) {
-        if (wave + 4 * (int64_t)decltype(j)::value < nch) fetch(j, wave + 4 * (int64_t)decltype(j)::value);
+        if (wave + KS * (int64_t)decltype(j)::value < nch) fetch(j, wave + KS * (int64_t)decltype(j)::value);
     });
-    for (int64_t c = wave; c < nch; c += 4 * NB) {
+    for (int64_t c = wave; c < nch; c += KS * NB) {
         static_for<NB>([&](auto j) {
             constexpr int jj = decltype(j)::value;
-            const int64_t cc = c + 4 * jj;
+            const int64_t cc = c + KS * jj;
             if (cc < nch) {
-                if (cc + 4 * (NB - 1) < nch) fetch(std::integral_constant<int, (jj + NB - 1) % NB>{}, cc + 4 * (NB - 1));
+                if (cc + KS * (NB - 1) < nch) fetch(std::integral_constant<int, (jj + NB - 1) % NB>{}, cc + KS * (NB - 1));
                 mult(j);
             }
         });
     }
     // partial tiles -> LDS (MFMA layout: lane holds column lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
-    float fin[4];
+    constexpr int ITER = 1024 / (64 * KS);      // outputs per thread
+    float fin[ITER];
     for (int pass = 0; pass < (MIX ? 2 : 1); ++pass) {
         __syncthreads();   // (every wave is done with its transposition area / with the previous pass)
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][lane & 31] = pass ? acc2[r] : acc1[r];
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = (threadIdx.x >> 5) + 8 * i, n = threadIdx.x & 31;
-            const float sum = (red[0][m][n] + red[1][m][n]) + (red[2][m][n] + red[3][m][n]);
+        for (int i = 0; i < ITER; ++i) {
+            const int m = (threadIdx.x >> 5) + 2 * KS * i, n = threadIdx.x & 31;
+            float sum = (red[0][m][n] + red[1][m][n]) + (red[2][m][n] + red[3][m][n]);
+            if (KS == 8) sum += (red[4][m][n] + red[5][m][n]) + (red[6][m][n] + red[7][m][n]);
             // (1 - w) q.ctx + w q.cap exactly like the reference: two rounded products, one rounded add
             fin[i] = pass ? __fadd_rn(fin[i], __fmul_rn(w2, sum)) : __fmul_rn(alpha, sum);
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t m = m0 + (threadIdx.x >> 5) + 8 * i, n = n0 + (threadIdx.x & 31);
+    for (int i = 0; i < ITER; ++i) {
+        const int64_t m = m0 + (threadIdx.x >> 5) + 2 * KS * i, n = n0 + (threadIdx.x & 31);
         if (m < M && n < N) {
             float* cp = C + m * ldc + n;
             if (accumulate) fin[i] = __fadd_rn(*cp, fin[i]);
@@ -336,8 +340,8 @@ __global__ __launch_bounds__(256) void sgemm_direct_kernel(const float* __restri
     // ---- fused NLL forward: statistics of this tile's 32 columns for each of its rows (a row = the 32 lanes t & 31 of a half wave)
     const int ntn = gridDim.x;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t m = m0 + (threadIdx.x >> 5) + 8 * i, n = n0 + (threadIdx.x & 31);
+    for (int i = 0; i < ITER; ++i) {
+        const int64_t m = m0 + (threadIdx.x >> 5) + 2 * KS * i, n = n0 + (threadIdx.x & 31);
         const float v = n < N ? fin[i] : -INFINITY;
         float mx = v;
         int64_t am = n < N ? n : 0x7fffffffffffffffll;
@@ -449,10 +453,14 @@ static int launch_sgemm_direct(const float* A, int64_t sam, int64_t sak, const f
                                const NllFused& nll, hipStream_t st) {
     const bool ak = (sak == 1), bk = (sbk == 1);
     const int64_t lda = ak ? sam : sak, ldb = bk ? sbn : sbk;
-    const dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32)), block(256);
-#define LDOT_SGD(AK_, BK_, MIX_)                                                                                              \
-    hipLaunchKernelGGL((sgemm_direct_kernel<AK_, BK_, MIX_, EPI>), grid, block, 0, st, A, lda, B, ldb, B2, C, ldc, M, N, K, alpha, \
-                       w2, accumulate, nll)
+    // both operands K-contiguous (the score GEMMs, K = 768): eight waves split K (measured 10-15 % shorter than four:
+    // profiles/r04_loss_kernel_trace_ks8.txt); the others (K = the batch: 512 / 1536) are up to 2.5x SLOWER that way and keep four
+#define LDOT_SGD(AK_, BK_, MIX_)                                                                                                 \
+    do {                                                                                                                         \
+        constexpr int KS_ = (AK_ && BK_) ? 8 : 4;                                                                                \
+        hipLaunchKernelGGL((sgemm_direct_kernel<AK_, BK_, MIX_, EPI, KS_>), dim3((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32)), \
+                           dim3(64 * KS_), 0, st, A, lda, B, ldb, B2, C, ldc, M, N, K, alpha, w2, accumulate, nll);              \
+    } while (0)
     if (B2) {
         if (ak && bk) LDOT_SGD(true, true, true);
         else if (ak && !bk) LDOT_SGD(true, false, true);
