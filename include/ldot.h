@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDOT_ABI_VERSION 3
+#define LDOT_ABI_VERSION 4
 
 /* status codes */
 #define LDOT_OK 0
@@ -141,6 +141,29 @@ int ldot_index_search_finish(ldot_index_t* ix, const float* floor, float* out_sc
 int ldot_index_search_warmup(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k, int parts,
                              float* stat_out, void* stream);
 int ldot_index_search_scan(ldot_index_t* ix, const float* stat_in, float* tau_out, void* stream);
+/* _begin for ONE SHARD of a row-sharded index of `parts` shards, with the statistics its ranks exchange afterwards (the default
+ * exchange of lightningdot_amd/sharded.py; same call sites being sharded as above).  stat_out [3*nq] (device):
+ *   stat_out[q]        the k'-th best candidate score of this shard (as tau_out of _begin),
+ *   stat_out[nq+q]     MINUS its ceil(k'/parts)-th best (+inf when the shard has fewer candidates),
+ *   stat_out[2*nq+q]   the LEVEL above which the shard's list is complete (-inf: a complete top-k' list).
+ * total_rows = 0: the candidate pass of _begin, level = -inf.  total_rows > 0 (the rows of ALL shards together): large batches
+ * scan on order statistics taken against the whole index — the m-th best of the shard's first r rows with
+ * P(Poisson(k' r / total_rows) >= m) <= 1e-7 / parts lies below the GLOBAL k'-th best w.h.p. when rows are spread over the shards
+ * and stored in no order that correlates with the queries —, which admits ~1/parts of the records of the shard's own thresholds
+ * in ONE launch after the warm-up; the level is then that threshold, and the shard alone cannot tell whether it was safe.
+ * The caller all-reduces stat_out with MAX over the shards and calls ldot_shard_floor on the result (stat, floor_out [nq],
+ * unproven_out [1] int32: DEVICE memory):
+ *   floor_out[q] = max(stat[q], -stat[nq+q]) <= the global k'-th best (some shard has k' rows at or above the first term, every shard
+ *   ceil(k'/parts) at or above the second) — the second term is what makes the floor tight: the largest k'-th best of a shard still
+ *   lets ~0.9 k' rows PER SHARD through, the smallest ceil(k'/parts)-th best ~1.4 k'/parts;
+ *   *unproven_out = the number of queries with floor < level on some shard: rows between the two may be missing from that shard's
+ *   list.  0 (always, with total_rows = 0): _finish(floor_out) on every shard + the merge of the partial lists are the exact global
+ *   top-k.  > 0: EVERY rank repeats the search with total_rows = 0 (all ranks see the same number).
+ * Both calls enqueue on `stream`; _begin_shard synchronises it once like _begin (candidate-pool overflows are handled by the shard
+ * itself, as in _begin: the queries concerned are searched again and report a complete list). */
+int ldot_index_search_begin_shard(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k, int parts,
+                                  int64_t total_rows, float* stat_out, void* stream);
+int ldot_shard_floor(const float* stat, int64_t nq, float* floor_out, int32_t* unproven_out, void* stream);
 /* _finish writing the shard's partial lists straight into the send buffer of the all-to-all that follows (device memory, 16-byte
  * aligned): block b — one per destination rank, block_bytes apart — holds the lists of the queries [b*block_rows, (b+1)*block_rows):
  * scores float [block_rows][k] at byte 0, labels int64 [block_rows][k] at byte LDOT_BLOCK_LABELS_OFFSET(block_rows, k); labels are

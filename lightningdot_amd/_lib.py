@@ -16,7 +16,7 @@ MODE_AUTO, MODE_DENSE, MODE_FUSED = 0, 1, 2
 OPT_MODE, OPT_RESCORE, OPT_CHUNK_ROWS, OPT_MARGIN, OPT_PROFILE, OPT_WARM_ROWS, OPT_GROWTH_PCT, OPT_PRECISION, OPT_RESERVE_ROWS = 1, 2, 3, 4, 5, 6, 7, 8, 9
 OPT_OPTIMISTIC = 11
 OPT_VERIFY = 10
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_MARGIN = 1024
 PAD_LABEL = -1
 PAD_SCORE = -3.4028234663852886e+38
@@ -41,6 +41,8 @@ SYMBOLS = {
     'ldot_index_search_finish': (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     'ldot_index_search_warmup': (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
     'ldot_index_search_scan': (_i, [_vp, _vp, _vp, _vp]),
+    'ldot_index_search_begin_shard': (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _i64, _vp, _vp]),
+    'ldot_shard_floor': (_i, [_vp, _i64, _vp, _vp, _vp]),
     'ldot_index_search_finish_blocked': (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     'ldot_merge_topk_blocked': (_i, [_vp, _i, _i64, _i64, _i64, _i, _i, _vp, _vp, _vp]),
     'ldot_index_search_lists': (_i, [_vp, _vp, _i64, _i, _i, _vp, _i, _i64, _vp, _i, _i, _vp, _vp, _i, _vp]),

@@ -84,6 +84,7 @@ struct ldot_index {
     DevBuf w_q16b;
     DevBuf w_stage, w_q32, w_ls, w_li, w_S, w_outs, w_outl, w_tau, w_pool, w_pool_cnt, w_over;
     DevBuf w_part_s, w_part_l, w_mrg_s, w_mrg_l;
+    DevBuf w_redone;   // flags of the queries the recovery searched again (kept for a shard's end-of-scan statistics)
     int64_t stats[4] = {0, 0, 0, 0};
     // the sub-pool counters and overflow flags are all-zero between searches (the pool select resets the counters it
     // reads); they are cleared only after a (re)allocation or an aborted / overflowed search
@@ -142,6 +143,11 @@ struct ldot_index {
     bool opt_used = false;           // the scan in progress filtered with optimistic thresholds
     int64_t opt_nq = 0;
     int cur_parts = 1;   // shards of the search in progress (1 = plain search): sizes the warm-up of a fused scan, fused_warm_rows
+    // a shard scanning on POOLED statistics (ldot_index_search_begin_shard): rows of the whole sharded index (0 = off) and its number of
+    // shards; pooled_used = the scan in progress filtered with thresholds only the ranks together can verify (w_tau_opt = their level)
+    int64_t pool_total = 0;
+    int pool_parts = 1;
+    bool pooled_used = false;
 };
 
 static int index_reserve(ldot_index* ix, int64_t rows, hipStream_t st) {
@@ -223,6 +229,7 @@ int ldot_index_destroy(ldot_index_t* ix) {
     ix->w_over_sum.release();
     ix->w_qcnt.release();
     ix->w_tau_opt.release();
+    ix->w_redone.release();
     ix->w_unproven.release();
     ix->w_norm.release();
     ix->w_nmax.release();
@@ -814,13 +821,22 @@ static int fused_rest_chunk_optimistic(ldot_index* ix, int64_t q0, int64_t nq, i
     const int64_t nslices = 256 / qg, nsubs = kPoolSubsPerSlice * nslices, unit = bm * nslices;
     const int64_t warm = fused_warm_rows(ix, nq, nq_pad, kp), N = ix->ntotal;
     if (warm >= N) return LDOT_OK;
+    // A shard of a sharded search (pool_total > 0) takes its order statistics against the WHOLE index: of the global k' best rows
+    // Poisson(k' r / N_global) lie among this shard's first r rows, so its m(r)-th best is below the GLOBAL k'-th best w.h.p. — a
+    // threshold 1 / parts as selective as the shard's own k'-th best, ~k' / parts + a margin admitted rows per query instead of k'
+    // ln(..), and ONE launch after the warm-up.  This shard alone cannot check it (its list need not hold k' rows above the threshold):
+    // the last select does not verify, the threshold is published as the level above which the list is complete and the ranks decide
+    // together (ldot_shard_floor).
+    const bool pooled = ix->pool_total > 0;
+    const int64_t Ng = pooled ? std::max(ix->pool_total, N) : N;
+    ix->pooled_used = pooled;
     if ((rc = fused_pools(ix, nq_pad, st))) return rc;
     float* tau = (float*)ix->w_tau.p + q0;
     float* tau_opt = (float*)ix->w_tau_opt.p + q0;
     const float* ls = (const float*)ix->w_ls.p + q0 * kp;
     const int32_t* li = (const int32_t*)ix->w_li.p + q0 * kp;
-    double eps = kOptEps;
-    int64_t growth_x = kOptGrowthX, max_rows = kOptMaxLaunchRows;
+    double eps = pooled ? kOptEps / ix->pool_parts : kOptEps;   // (the floor check fails if ANY shard aimed too high)
+    int64_t growth_x = pooled ? (int64_t)1 << 20 : kOptGrowthX, max_rows = kOptMaxLaunchRows;
 #ifdef LDOT_ABLATION
     if (const char* e = getenv("LDOT_DEBUG_OPT_EPS")) eps = atof(e);
     if (const char* e = getenv("LDOT_DEBUG_OPT_GROWTHX")) growth_x = atoll(e);
@@ -828,15 +844,17 @@ static int fused_rest_chunk_optimistic(ldot_index* ix, int64_t q0, int64_t nq, i
 #endif
     int64_t r = warm;
     // the first thresholds come from the warm-up's list; every pool select then leaves the next launch's behind (and the last one checks)
-    if ((rc = launch_tau_opt(ls, li, kp, nq, optimistic_m(kp, r, N, eps), tau, tau_opt, st))) return rc;
+    if ((rc = launch_tau_opt(ls, li, kp, nq, optimistic_m(kp, r, Ng, eps), tau, tau_opt, st))) return rc;
     while (r < N) {
-        const int m = optimistic_m(kp, r, N, eps);
+        const int m = optimistic_m(kp, r, Ng, eps);
         // expected records per query of a launch over len rows: len m / r, kept <= kFill per sub-pool like the guaranteed schedule's bound
-        int64_t len = std::min<int64_t>(std::min<int64_t>(r * growth_x, max_rows), r * kFill * nsubs / m);
+        // (pooled statistics run AT this bound, and the m-th best of a few thousand rows is a noisy quantile — some queries admit
+        // 1.5x the expectation —: half the fill there)
+        int64_t len = std::min<int64_t>(std::min<int64_t>(r * growth_x, max_rows), r * (pooled ? kFill / 2 : kFill) * nsubs / m);
         len = std::max<int64_t>(len / unit * unit, unit);
         len = std::min(len, N - r);
         if (N - r - len < len / 4 && N - r <= max_rows + unit) len = N - r;   // no short tail launch
-        const int m_next = r + len < N ? optimistic_m(kp, r + len, N, eps) : 0;   // (0: the last select verifies)
+        const int m_next = r + len < N ? optimistic_m(kp, r + len, Ng, eps) : pooled ? -1 : 0;   // (0: the last select verifies)
         if ((rc = fused_launch_and_select(ix, q0, nq, nq_pad, kp, r, len, st, tau_opt, m_next))) return rc;
         ix->stats[3] += len * nq;
         r += len;
@@ -915,6 +933,7 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
         if ((rc = ix->w_qcnt.ensure((size_t)nq_pad * 4))) return rc;
         if ((rc = ix->w_tau_opt.ensure((size_t)nq_pad * 4))) return rc;
         ix->opt_used = false;
+        ix->pooled_used = false;
         ix->opt_nq = nq;
         if (ix->opt_backoff > 0 && nq > kFewSelectMaxQueries) --ix->opt_backoff;   // (counted in large-batch searches, the ones it applies to)
         if ((rc = launch_init_fused_scan((float*)ix->w_tau_opt.p, (int32_t*)ix->w_qcnt.p, (int32_t*)ix->w_over_sum.p, nq, nq_pad, st))) return rc;
@@ -999,6 +1018,10 @@ static int redo_flagged(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipS
     const int64_t nf = (int64_t)fidx.size(), nf_pad = round_up(std::max<int64_t>(nf, 1), kBM);
     if (nf == 0) return LDOT_OK;
     if (level == 0) ix->redone += nf;
+    if (level == 0 && ix->pooled_used) {   // (their lists will be complete: the shard statistics must not report the pooled level for them)
+        if ((rc = ix->w_redone.ensure((size_t)nq * 4))) return rc;
+        LDOT_HIP_CHECK(hipMemcpyAsync(ix->w_redone.p, ix->w_over.p, (size_t)nq * 4, hipMemcpyDeviceToDevice, st));
+    }
     ldot_index::Compact& c = ix->compact[level];
     if ((rc = c.fidx.ensure((size_t)nf * 4))) return rc;
     if ((rc = c.q32.ensure((size_t)nf_pad * ix->dpad * 4))) return rc;
@@ -1060,7 +1083,7 @@ static int stage_unstaged_queries(ldot_index* ix, int64_t nq, hipStream_t st) {
 // stat_out (2 * nq floats) and remember the path in split_path; ldot_index_search_scan continues from there
 static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k,
                              float* tau_out, bool defer_check, hipStream_t st, const DirectOut* direct = nullptr,
-                             bool warm_only = false, int parts = 1, float* stat_out = nullptr) {
+                             bool warm_only = false, int parts = 1, float* stat_out = nullptr, int64_t shard_total = -1) {
     LDOT_REQUIRE(ix != nullptr, LDOT_EINVAL, "index is NULL");
     LDOT_REQUIRE(nq >= 0, LDOT_EINVAL, "negative query count");
     LDOT_REQUIRE(k >= 1 && k <= kMaxK, LDOT_EINVAL, "k must be in [1, %d] (got %d)", kMaxK, k);
@@ -1074,6 +1097,10 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
     ix->unproven_n = 0;
     ix->split_path = 0;
     ix->cur_parts = warm_only ? parts : 1;
+    // shard_total >= 0: ldot_index_search_begin_shard (one shard of `parts`; > 0: scan on pooled statistics, the whole index has that many rows)
+    ix->pool_total = (!warm_only && shard_total > 0 && parts > 1) ? shard_total : 0;
+    ix->pool_parts = parts;
+    ix->pooled_used = false;
     if (nq == 0) return LDOT_OK;
     LDOT_REQUIRE(queries != nullptr, LDOT_EINVAL, "NULL buffer");
     DeviceGuard guard(ix->device);
@@ -1171,6 +1198,17 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
         }
     }
     if (tau_out) LDOT_HIP_CHECK(hipMemcpyAsync(tau_out, tau, (size_t)nq * 4, hipMemcpyDeviceToDevice, st));
+    if (!warm_only && shard_total >= 0 && stat_out) {
+        // what the ranks exchange: the k'-th best, -(the ceil(k'/parts)-th best) and the level above which this list is complete
+        // (pooled statistics: the last threshold the rows were filtered with; a query whose candidate pools overflowed was searched
+        // again by redo_flagged and has a complete list)
+        const bool pooled = ix->pooled_used;
+        if ((rc = launch_list_stats((const float*)ix->w_ls.p, (const int32_t*)ix->w_li.p, kp, nq, (kp + parts - 1) / parts, tau, stat_out, st, 3,
+                                    pooled ? (const float*)ix->w_tau_opt.p : nullptr,
+                                    pooled && ix->redone > 0 ? (const int32_t*)ix->w_redone.p : nullptr)))
+            return rc;
+    }
+    ix->pool_total = 0;
     if (mem == LDOT_HOST) LDOT_HIP_CHECK(hipStreamSynchronize(st));   // the staging buffer is reused by the next call
     ix->pend_nq = nq;
     ix->pend_k = k;
@@ -1181,6 +1219,24 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
 int ldot_index_search_begin(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k,
                             float* tau_out, void* stream) {
     return search_begin_impl(ix, queries, nq, dtype, mem, normalize, k, tau_out, false, (hipStream_t)stream);
+}
+
+// One shard's candidate pass of a sharded search + the three numbers per query its ranks all-reduce (MAX) afterwards (ldot.h).
+// total_rows > 0: large batches scan on statistics pooled over the whole index (fused_rest_chunk_optimistic).
+int ldot_index_search_begin_shard(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k, int parts,
+                                  int64_t total_rows, float* stat_out, void* stream) {
+    LDOT_REQUIRE(parts >= 1 && parts <= 65536, LDOT_EINVAL, "bad number of parts %d", parts);
+    LDOT_REQUIRE(total_rows >= 0, LDOT_EINVAL, "negative row count");
+    if (nq > 0) LDOT_REQUIRE(stat_out != nullptr, LDOT_EINVAL, "NULL buffer");
+    return search_begin_impl(ix, queries, nq, dtype, mem, normalize, k, nullptr, false, (hipStream_t)stream, nullptr, false, parts, stat_out,
+                             total_rows);
+}
+
+int ldot_shard_floor(const float* stat, int64_t nq, float* floor_out, int32_t* unproven_out, void* stream) {
+    LDOT_REQUIRE(nq >= 0, LDOT_EINVAL, "negative query count");
+    LDOT_REQUIRE(unproven_out != nullptr, LDOT_EINVAL, "NULL buffer");
+    if (nq > 0) LDOT_REQUIRE(stat != nullptr && floor_out != nullptr, LDOT_EINVAL, "NULL buffer");
+    return launch_shard_floor(stat, nq, floor_out, unproven_out, (hipStream_t)stream);
 }
 
 // A sharded search in three steps (lightningdot_amd/sharded.py): every rank warms up on its own shard and publishes two numbers per

@@ -889,9 +889,9 @@ __global__ __launch_bounds__(kPoolSelThreads * QPW) void select_pools_kernel(con
         if (opt_m > 0) {
             const float tm = opt_m >= kp ? t_guar : sel.mth_best(opt_m);
             if (lane == 0) tau_opt[q] = fmaxf(tau_opt[q], tm);
-        } else {
+        } else if (opt_m == 0) {
             unproven = !(t_guar >= tau_opt[q]);
-        }
+        }   // (opt_m < 0: a shard on pooled statistics — the ranks check together, ldot_shard_floor)
     }
     if (qcnt) {
 #pragma unroll
@@ -1354,7 +1354,8 @@ int launch_select_pools_parts(const uint4* pool, const int32_t* pool_cnt, int ns
 // second (parts * m >= k').  One wave per query; the list is a set of <= 64 * R keys held in registers, the m-th best by bit search.
 template <int R>
 __global__ __launch_bounds__(256) void list_stats_kernel(const float* __restrict__ ls, const int32_t* __restrict__ li, int kp, int64_t nq,
-                                                         int m, const float* __restrict__ tau, float* __restrict__ stat) {
+                                                         int m, const float* __restrict__ tau, float* __restrict__ stat, int slots,
+                                                         const float* __restrict__ level, const int32_t* __restrict__ redone) {
     const int lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nq) return;
@@ -1382,20 +1383,48 @@ __global__ __launch_bounds__(256) void list_stats_kernel(const float* __restrict
     if (lane == 0) {
         stat[q] = tau[q];
         stat[nq + q] = -tm;
+        // third slot (end of a shard's scan): the list holds every row of the shard at or above this score.  A complete top-k' list
+        // (no level, or a query the recovery searched again) reports -inf: the floor is never below its k'-th best anyway
+        if (slots > 2) stat[2 * nq + q] = (level && !(redone && redone[q])) ? level[q] : -INFINITY;
     }
 }
 
-int launch_list_stats(const float* list_s, const int32_t* list_i, int kp, int64_t nq, int m, const float* tau, float* stat, hipStream_t st) {
+int launch_list_stats(const float* list_s, const int32_t* list_i, int kp, int64_t nq, int m, const float* tau, float* stat, hipStream_t st,
+                      int slots, const float* level, const int32_t* redone) {
     if (nq <= 0) return LDOT_OK;
     const dim3 grid((unsigned)((nq + 3) / 4)), block(256);
     if (kp <= 128)
-        hipLaunchKernelGGL(list_stats_kernel<2>, grid, block, 0, st, list_s, list_i, kp, nq, m, tau, stat);
+        hipLaunchKernelGGL(list_stats_kernel<2>, grid, block, 0, st, list_s, list_i, kp, nq, m, tau, stat, slots, level, redone);
     else if (kp <= 256)
-        hipLaunchKernelGGL(list_stats_kernel<4>, grid, block, 0, st, list_s, list_i, kp, nq, m, tau, stat);
+        hipLaunchKernelGGL(list_stats_kernel<4>, grid, block, 0, st, list_s, list_i, kp, nq, m, tau, stat, slots, level, redone);
     else if (kp <= 1024)
-        hipLaunchKernelGGL(list_stats_kernel<16>, grid, block, 0, st, list_s, list_i, kp, nq, m, tau, stat);
+        hipLaunchKernelGGL(list_stats_kernel<16>, grid, block, 0, st, list_s, list_i, kp, nq, m, tau, stat, slots, level, redone);
     else
-        hipLaunchKernelGGL(list_stats_kernel<48>, grid, block, 0, st, list_s, list_i, kp, nq, m, tau, stat);
+        hipLaunchKernelGGL(list_stats_kernel<48>, grid, block, 0, st, list_s, list_i, kp, nq, m, tau, stat, slots, level, redone);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+// the floor of a sharded search from the all-reduced (MAX) end-of-scan statistics of its ranks (3 x nq floats, ldot.h):
+// floor = max(largest k'-th best of a rank, smallest ceil(k'/parts)-th best of a rank) <= the global k'-th best; a query is UNPROVEN when
+// some rank's list is only complete above a score higher than that floor (a shard scanned on pooled statistics that aimed too high)
+__global__ __launch_bounds__(256) void shard_floor_kernel(const float* __restrict__ stat, int64_t nq, float* __restrict__ floor_out,
+                                                          int32_t* __restrict__ unproven) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool bad = false;
+    if (q < nq) {
+        const float fl = fmaxf(stat[q], -stat[nq + q]);
+        floor_out[q] = fl;
+        bad = !(fl >= stat[2 * nq + q]);
+    }
+    const int nbad = __popcll(__ballot(bad));
+    if ((threadIdx.x & 63) == 0 && nbad) atomicAdd(unproven, nbad);
+}
+
+int launch_shard_floor(const float* stat, int64_t nq, float* floor_out, int32_t* unproven, hipStream_t st) {
+    LDOT_HIP_CHECK(hipMemsetAsync(unproven, 0, 4, st));
+    if (nq <= 0) return LDOT_OK;
+    hipLaunchKernelGGL(shard_floor_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, stat, nq, floor_out, unproven);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

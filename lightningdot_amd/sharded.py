@@ -57,7 +57,7 @@ def _hip_merge(scores: torch.Tensor, labels: torch.Tensor, k: int, out=None):
 class ShardedFlatIndexer:
     def __init__(self, vector_sz: int, group=None, local_search: Optional[Callable] = None,
                  merge: Optional[Callable] = None, normalize: bool = False, exchange: str = 'all_to_all',
-                 exchange_warmup: bool = False, equal_query_counts: bool = False):
+                 exchange_warmup: bool = False, equal_query_counts: bool = False, pooled_statistics: bool = True):
         if exchange not in ('all_to_all', 'all_gather'):
             raise ValueError("exchange must be 'all_to_all' or 'all_gather'")
         self.group = group
@@ -72,6 +72,16 @@ class ShardedFlatIndexer:
         # the caller promises that every rank passes the same number of queries to every search: the per-search exchange of the
         # query counts (a small all-gather + a host synchronisation) is skipped
         self.equal_query_counts = equal_query_counts
+        # True (default): large batches scan every shard on order statistics taken against the WHOLE index
+        # (ldot_index_search_begin_shard, total_rows > 0): ~1/world of the admitted records and one launch after the warm-up.  It assumes
+        # rows spread over the shards (and stored) in no order that correlates with the queries; the ranks check the result together
+        # (ldot_shard_floor) and a search that fails the check is repeated on every rank with each shard's own thresholds, after which
+        # the pooled statistics are skipped for `_pooled_backoff` searches (16, doubling up to 1024 while searches keep failing).
+        # Every rank sees the same all-reduced numbers, so all of them take the same decisions.
+        self.pooled_statistics = pooled_statistics
+        self._pooled_backoff, self._pooled_penalty = 0, 16
+        self.last_search = {}                    # diagnostics of the last search (pooled / repeated)
+        self._bad_host = None                    # pinned int32: the check's verdict, copied behind the kernels that produce it
         self._blocks = {}                        # send buffers of the blocked exchange, by size
         self._custom = local_search is not None
         self.local = None if self._custom else DenseFlatIndexer(vector_sz, normalize=normalize)
@@ -259,6 +269,25 @@ class ShardedFlatIndexer:
         """-> (scores [nq_local, k] fp32, GLOBAL row labels [nq_local, k] int64) for the local queries.  ``out`` = (scores, labels)
         pinned host tensors: the merge writes the final lists there directly and the call returns them after a stream
         synchronisation (HIP merge only)."""
+        pooled = (not self._custom and self.world > 1 and self.pooled_statistics and not self.exchange_warmup
+                  and local_queries.is_cuda)
+        if pooled and self._pooled_backoff > 0:
+            self._pooled_backoff -= 1
+            pooled = False
+        self.last_search = {'pooled': pooled, 'repeated': False}
+        res = self._search(local_queries, k, out, pooled)
+        if pooled:
+            # the verdict was copied to pinned memory behind the kernels that produced it
+            torch.cuda.current_stream().synchronize()
+            if int(self._bad_host[0]) > 0:       # the same number on every rank: all of them repeat the search
+                self.last_search['repeated'] = True
+                self._pooled_backoff = self._pooled_penalty
+                self._pooled_penalty = min(2 * self._pooled_penalty, 1024)
+                return self._search(local_queries, k, out, False)
+            self._pooled_penalty = 16
+        return res
+
+    def _search(self, local_queries: torch.Tensor, k: int, out, pooled: bool):
         q_all, counts = self._gather_queries(local_queries.float())
         if self._custom:
             s, l = self._local_search(q_all, k)
@@ -269,15 +298,28 @@ class ShardedFlatIndexer:
             # exchange_warmup (option): the shards agree on thresholds BEFORE the candidate pass as well — every shard warms up on its
             # first few thousand rows and one all-reduce(MAX) of two numbers per query turns the warm-ups into a bound worth ~0.7 x world
             # x as many rows (one or two fused launches per shard).  Default: each shard's own optimistic thresholds (see __init__).
+            # Default exchange (round 4): ONE all-reduce(MAX) of three numbers per query after the candidate pass — the k'-th best, minus
+            # the ceil(k'/world)-th best, the level above which the shard's list is complete (ldot_index_search_begin_shard).  The
+            # second number is what makes the floor tight: the largest k'-th best of a shard still lets ~0.9 k' rows PER SHARD through
+            # to the re-score gather, the smallest ceil(k'/world)-th best ~1.4 k'/world.
             ix = self.local.index
             if self.world > 1 and self.exchange_warmup:
                 stat = ix.search_warmup(q_all, k, self.world)
                 self._all_reduce_max(stat)
                 tau = ix.search_scan(stat)
+                self._all_reduce_max(tau)
+            elif self.world > 1 and q_all.is_cuda:
+                stat = ix.search_begin_shard(q_all, k, self.world, self.ntotal if pooled else 0)
+                self._all_reduce_max(stat)
+                tau, bad = ix.shard_floor(stat)
+                if pooled:
+                    if self._bad_host is None:
+                        self._bad_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                    self._bad_host.copy_(bad, non_blocking=True)
             else:
                 tau = ix.search_begin(q_all, k)
-            if self.world > 1:
-                self._all_reduce_max(tau)
+                if self.world > 1:
+                    self._all_reduce_max(tau)
             mx = max(counts)
             if (self.exchange == 'all_to_all' and self._merge is _hip_merge and min(counts) == mx and mx > 0 and q_all.is_cuda):
                 return self._finish_blocked(ix, tau, mx, k, out)

@@ -73,7 +73,22 @@ _CASES = {
     # equal query slices (the bench's shape): the blocked exchange — re-score kernel -> send buffer -> ONE all-to-all -> merge kernel —
     # with the per-search query-count exchange switched off
     'equal': dict(bounds=[0, 40000, 80000, 120000, 160000], counts=[320, 320, 320, 320], d=256, k=100, equal=True),
+    # rows that are NOT exchangeable between the shards: the first 30 000 rows of shard 1 are three times as long as all others, so
+    # every query's best rows sit there and that shard's pooled statistics (taken from its first 4096 rows) aim above the global k'-th
+    # best.  The ranks notice together (ldot_shard_floor), repeat the search on their own thresholds and back off
+    'skewed': dict(bounds=[0, 40000, 80000, 120000, 160000], counts=[320, 320, 320, 320], d=128, k=100, equal=True,
+                   scale=(40000, 70000, 3.0)),
 }
+
+
+def _case_rows(c, lo, hi, seed):
+    rows = _gen_rows(lo, hi, c['d'], seed)
+    if 'scale' in c:
+        a, b, f = c['scale']
+        a, b = max(a, lo), min(b, hi)
+        if a < b:
+            rows[a - lo:b - lo] *= f
+    return rows
 
 
 def _gen_rows(lo, hi, d, seed):
@@ -107,21 +122,32 @@ def _worker4(rank, world, port, out_dir):
         lo, hi = c['bounds'][rank], c['bounds'][rank + 1]
         qs = np.cumsum([0] + c['counts'])
         sh = ShardedFlatIndexer(c['d'], equal_query_counts=bool(c.get('equal')))
-        sh.index_local_shard(list(range(lo, hi)), _gen_rows(lo, hi, c['d'], 11 + ci))
+        sh.index_local_shard(list(range(lo, hi)), _case_rows(c, lo, hi, 11 + ci))
         q = _gen_queries(int(qs[-1]), c['d'], 500 + ci, c['bounds'][-1])[qs[rank]:qs[rank + 1]].contiguous()
         from lightningdot_amd import _lib as L
         sh.local.index.set_option(L.OPT_PROFILE, 1)
-        assert sh.exchange_warmup is False    # default: every shard scans on its own (optimistic) thresholds, one exchange after the pass
+        # default: every shard scans on statistics pooled over the whole index, ONE exchange (three numbers per query) after the pass
+        assert sh.exchange_warmup is False and sh.pooled_statistics is True
         s, l = sh.search(q, c['k'])
         st, n1 = sh.local.index.last_stats(), sh.local.index.last_profile()['launches']
+        info = dict(sh.last_search)
+        s9, l9 = sh.search(q, c['k'])         # (after a repeated search the pooled statistics are skipped for a while)
+        info9 = dict(sh.last_search)
+        sh.pooled_statistics = False          # option: every shard on its own (optimistic) thresholds, the same exchange
+        s1, l1 = sh.search(q, c['k'])
+        st1, n1b = sh.local.index.last_stats(), sh.local.index.last_profile()['launches']
         sh.exchange_warmup = True             # option: thresholds agreed after the warm-ups (ldot_index_search_warmup / _scan)
         s0, l0 = sh.search(q, c['k'])
         st0, n0 = sh.local.index.last_stats(), sh.local.index.last_profile()['launches']
         sh.exchange_warmup = False
         assert torch.equal(s, s0) and torch.equal(l, l0)
+        assert torch.equal(s, s1) and torch.equal(l, l1)
+        assert torch.equal(s, s9) and torch.equal(l, l9)
         np.savez(os.path.join(out_dir, f'{name}_r{rank}.npz'), s=s.cpu().numpy(), l=l.cpu().numpy(),
                  fused_pairs=st['fused_pairs'], fused_candidates=st['fused_candidates'], overflowed=st['overflowed_queries'],
-                 fused_candidates_agreed=st0['fused_candidates'], launches=n1, launches_agreed=n0)
+                 fused_candidates_own=st1['fused_candidates'], launches_own=n1b,
+                 fused_candidates_agreed=st0['fused_candidates'], launches=n1, launches_agreed=n0,
+                 pooled=int(info['pooled']), repeated=int(info['repeated']), pooled_next=int(info9['pooled']))
         del sh
         torch.cuda.empty_cache()
         dist.barrier()
@@ -139,7 +165,7 @@ def test_sharded_search_four_ranks_fused_path_baseline_shapes(tmp_path):
     for ci, (name, c) in enumerate(_CASES.items()):
         n = c['bounds'][-1]
         ix = FlatIPIndex(c['d'])
-        ix.add(_gen_rows(0, n, c['d'], 11 + ci))
+        ix.add(_case_rows(c, 0, n, 11 + ci))
         qs = np.cumsum([0] + c['counts'])
         q = _gen_queries(int(qs[-1]), c['d'], 500 + ci, n)
         es, el = ix.search_tensors(q, c['k'])
@@ -151,17 +177,24 @@ def test_sharded_search_four_ranks_fused_path_baseline_shapes(tmp_path):
             # the same rows in the same order with bit-identical fp32 scores as the unsharded search of the whole index
             np.testing.assert_array_equal(a['l'], el[qs[r]:qs[r + 1]])
             np.testing.assert_array_equal(a['s'], es[qs[r]:qs[r + 1]])
+            assert int(a['pooled']) == 1
+            if name == 'skewed':
+                # the pooled statistics of shard 1 aimed too high: noticed by all ranks, searched again, skipped in the next search
+                assert int(a['repeated']) == 1 and int(a['pooled_next']) == 0
+                continue
+            assert int(a['repeated']) == 0 and int(a['pooled_next']) == 1
             assert int(a['overflowed']) == 0
             if name == 'shard125k':   # every rank scanned its shard with the fused filter (all queries x its rows beyond the warm-up)
                 assert int(a['fused_pairs']) > 0.9 * int(qs[-1]) * 125000
-                cand.append((int(a['fused_candidates']), int(a['fused_candidates_agreed']), int(a['launches']), int(a['launches_agreed'])))
+                cand.append((int(a['fused_candidates']), int(a['fused_candidates_own']), int(a['fused_candidates_agreed']),
+                             int(a['launches']), int(a['launches_own']), int(a['launches_agreed'])))
             elif name == 'equal':
                 assert int(a['fused_pairs']) > 0.8 * int(qs[-1]) * 40000
             else:
                 assert int(a['fused_pairs']) == 0
         if name == 'shard125k':
-            # both schedules give the same lists (asserted in the workers); the default (optimistic local thresholds) admits fewer
-            # records than the agreed-threshold option in no more launches — which is why it is the default (tools/shard_floor.py)
-            assert all(a < b and la <= lb for a, b, la, lb in cand), cand
+            # all three schedules give the same lists (asserted in the workers); pooled statistics admit the fewest records in no
+            # more launches, a shard's own optimistic thresholds fewer than the agreed-threshold option (tools/shard_floor.py)
+            assert all(a < b < c_ and la <= lb <= lc for a, b, c_, la, lb, lc in cand), cand
         del ix
         torch.cuda.empty_cache()

@@ -1,5 +1,5 @@
 """One rank of an 8-way sharded search on one GPU, for a kernel timeline (tools/shard_timeline.sh): 125 000-row shard, 10 000 queries.
-argv[1] = rows, argv[2] = 'local' (thresholds exchanged only after the candidate pass) | 'agreed' (after the warm-up too; the other
+argv[1] = rows, argv[2] = 'local' (thresholds exchanged only after the candidate pass) | 'pooled' | 'own3' | 'agreed' (after the warm-up too; the other
 seven ranks' warm-up statistics come from seven small indexes, reduced with MAX like the all-reduce would)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,6 +24,13 @@ for _ in range(6):
         stat = torch.maximum(ix.search_warmup(q, K, G), stat_o)
         tau = ix.search_scan(stat)
         ix.search_finish(torch.maximum(tau, floor))
+    elif mode in ('pooled', 'own3'):
+        # the round-4 default: one exchange of three numbers per query; the all-reduce is played by this shard's own statistics with
+        # the floor term replaced by one that keeps ~22 rows (what eight real shards give, tools/shard_floor.py)
+        stat = ix.search_begin_shard(q, K, G, G * n if mode == 'pooled' else 0)
+        stat[0] = torch.maximum(stat[0], s[:, 21])
+        fl, bad = ix.shard_floor(stat)
+        ix.search_finish(fl)
     else:
         ix.search_begin(q, K); ix.search_finish(floor)
 torch.cuda.synchronize()
