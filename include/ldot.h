@@ -144,26 +144,33 @@ int ldot_index_search_scan(ldot_index_t* ix, const float* stat_in, float* tau_ou
 /* _begin for ONE SHARD of a row-sharded index of `parts` shards, with the statistics its ranks exchange afterwards (the default
  * exchange of lightningdot_amd/sharded.py; same call sites being sharded as above).  stat_out [3*nq] (device):
  *   stat_out[q]        the k'-th best candidate score of this shard (as tau_out of _begin),
- *   stat_out[nq+q]     MINUS its ceil(k'/parts)-th best (+inf when the shard has fewer candidates),
+ *   stat_out[nq+q]     MINUS its j-th best, j = ceil(k' x share) (+inf when the shard has fewer candidates; -inf for share = 0),
  *   stat_out[2*nq+q]   the LEVEL above which the shard's list is complete (-inf: a complete top-k' list).
+ * `share` in [0, 1] is the part of the k' rows this shard vouches for; the shares of all shards must add up to at least 1 (equal
+ * shards: 1/parts each; unequal ones: in proportion to their rows, 0 for shards too small to matter — a tiny shard's j-th best
+ * would otherwise drag the floor far below the global k'-th best).
  * total_rows = 0: the candidate pass of _begin, level = -inf.  total_rows > 0 (the rows of ALL shards together): large batches
  * scan on order statistics taken against the whole index — the m-th best of the shard's first r rows with
  * P(Poisson(k' r / total_rows) >= m) <= 1e-7 / parts lies below the GLOBAL k'-th best w.h.p. when rows are spread over the shards
  * and stored in no order that correlates with the queries —, which admits ~1/parts of the records of the shard's own thresholds
  * in ONE launch after the warm-up; the level is then that threshold, and the shard alone cannot tell whether it was safe.
- * The caller all-reduces stat_out with MAX over the shards and calls ldot_shard_floor on the result (stat, floor_out [nq],
- * unproven_out [1] int32: DEVICE memory):
+ * The caller all-reduces stat_out with MAX over the shards and hands the result to ldot_index_shard_floor (between _begin_shard and
+ * _finish; stat [3*nq], floor_out [nq] float, count_out [nq] int32: DEVICE memory; *k_prime_out, host, receives k'):
  *   floor_out[q] = max(stat[q], -stat[nq+q]) <= the global k'-th best (some shard has k' rows at or above the first term, every shard
- *   ceil(k'/parts) at or above the second) — the second term is what makes the floor tight: the largest k'-th best of a shard still
- *   lets ~0.9 k' rows PER SHARD through, the smallest ceil(k'/parts)-th best ~1.4 k'/parts;
- *   *unproven_out = the number of queries with floor < level on some shard: rows between the two may be missing from that shard's
- *   list.  0 (always, with total_rows = 0): _finish(floor_out) on every shard + the merge of the partial lists are the exact global
- *   top-k.  > 0: EVERY rank repeats the search with total_rows = 0 (all ranks see the same number).
- * Both calls enqueue on `stream`; _begin_shard synchronises it once like _begin (candidate-pool overflows are handled by the shard
+ *   its ceil(k' x share) at or above the second, k' or more together) — the second term is what makes the floor tight: the largest k'-th
+ *   best of a shard still lets ~0.9 k' rows PER SHARD through, the smallest ceil(k'/parts)-th best of equal shards ~1.4 k'/parts.
+ *   _finish(floor_out) on every shard + the merge of the partial lists follow as before.
+ *   count_out[q] = the rows of THIS shard at or above the LARGEST level of any shard (all of them are in its list; k' when no shard
+ *   reported a level).  The caller all-reduces count_out with SUM (off the critical path: only the verdict needs it): a query whose sum
+ *   reaches k' has k' rows at or above every level, i.e. no shard dropped one of its global k' best; the merged lists are then exact.
+ *   Queries below k' are UNPROVEN (never, with total_rows = 0): EVERY rank repeats the search with total_rows = 0 (all ranks see the
+ *   same sums).  Comparing the floor with the levels instead would fail far more often than the thresholds do: the floor is a noisy
+ *   lower bound of the global k'-th best, the count is exact.
+ * All calls enqueue on `stream`; _begin_shard synchronises it once like _begin (candidate-pool overflows are handled by the shard
  * itself, as in _begin: the queries concerned are searched again and report a complete list). */
 int ldot_index_search_begin_shard(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k, int parts,
-                                  int64_t total_rows, float* stat_out, void* stream);
-int ldot_shard_floor(const float* stat, int64_t nq, float* floor_out, int32_t* unproven_out, void* stream);
+                                  double share, int64_t total_rows, float* stat_out, void* stream);
+int ldot_index_shard_floor(ldot_index_t* ix, const float* stat, float* floor_out, int32_t* count_out, int* k_prime_out, void* stream);
 /* _finish writing the shard's partial lists straight into the send buffer of the all-to-all that follows (device memory, 16-byte
  * aligned): block b — one per destination rank, block_bytes apart — holds the lists of the queries [b*block_rows, (b+1)*block_rows):
  * scores float [block_rows][k] at byte 0, labels int64 [block_rows][k] at byte LDOT_BLOCK_LABELS_OFFSET(block_rows, k); labels are

@@ -41,8 +41,8 @@ SYMBOLS = {
     'ldot_index_search_finish': (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     'ldot_index_search_warmup': (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
     'ldot_index_search_scan': (_i, [_vp, _vp, _vp, _vp]),
-    'ldot_index_search_begin_shard': (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _i64, _vp, _vp]),
-    'ldot_shard_floor': (_i, [_vp, _i64, _vp, _vp, _vp]),
+    'ldot_index_search_begin_shard': (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, ctypes.c_double, _i64, _vp, _vp]),
+    'ldot_index_shard_floor': (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     'ldot_index_search_finish_blocked': (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     'ldot_merge_topk_blocked': (_i, [_vp, _i, _i64, _i64, _i64, _i, _i, _vp, _vp, _vp]),
     'ldot_index_search_lists': (_i, [_vp, _vp, _i64, _i, _i, _vp, _i, _i64, _vp, _i, _i, _vp, _vp, _i, _vp]),

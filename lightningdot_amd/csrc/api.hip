@@ -1083,7 +1083,8 @@ static int stage_unstaged_queries(ldot_index* ix, int64_t nq, hipStream_t st) {
 // stat_out (2 * nq floats) and remember the path in split_path; ldot_index_search_scan continues from there
 static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k,
                              float* tau_out, bool defer_check, hipStream_t st, const DirectOut* direct = nullptr,
-                             bool warm_only = false, int parts = 1, float* stat_out = nullptr, int64_t shard_total = -1) {
+                             bool warm_only = false, int parts = 1, float* stat_out = nullptr, int64_t shard_total = -1,
+                             double shard_share = 0.0) {
     LDOT_REQUIRE(ix != nullptr, LDOT_EINVAL, "index is NULL");
     LDOT_REQUIRE(nq >= 0, LDOT_EINVAL, "negative query count");
     LDOT_REQUIRE(k >= 1 && k <= kMaxK, LDOT_EINVAL, "k must be in [1, %d] (got %d)", kMaxK, k);
@@ -1203,7 +1204,9 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
         // (pooled statistics: the last threshold the rows were filtered with; a query whose candidate pools overflowed was searched
         // again by redo_flagged and has a complete list)
         const bool pooled = ix->pooled_used;
-        if ((rc = launch_list_stats((const float*)ix->w_ls.p, (const int32_t*)ix->w_li.p, kp, nq, (kp + parts - 1) / parts, tau, stat_out, st, 3,
+        // the rank of the second statistic: this shard vouches for ceil(k' x share) of the k' rows (0: for none)
+        const int j = shard_share > 0.0 ? std::min(kp, std::max(1, (int)ceil((double)kp * shard_share - 1e-9))) : 0;
+        if ((rc = launch_list_stats((const float*)ix->w_ls.p, (const int32_t*)ix->w_li.p, kp, nq, j, tau, stat_out, st, 3,
                                     pooled ? (const float*)ix->w_tau_opt.p : nullptr,
                                     pooled && ix->redone > 0 ? (const int32_t*)ix->w_redone.p : nullptr)))
             return rc;
@@ -1224,19 +1227,24 @@ int ldot_index_search_begin(ldot_index_t* ix, const void* queries, int64_t nq, i
 // One shard's candidate pass of a sharded search + the three numbers per query its ranks all-reduce (MAX) afterwards (ldot.h).
 // total_rows > 0: large batches scan on statistics pooled over the whole index (fused_rest_chunk_optimistic).
 int ldot_index_search_begin_shard(ldot_index_t* ix, const void* queries, int64_t nq, int dtype, int mem, int normalize, int k, int parts,
-                                  int64_t total_rows, float* stat_out, void* stream) {
+                                  double share, int64_t total_rows, float* stat_out, void* stream) {
     LDOT_REQUIRE(parts >= 1 && parts <= 65536, LDOT_EINVAL, "bad number of parts %d", parts);
+    LDOT_REQUIRE(share >= 0.0 && share <= 1.0, LDOT_EINVAL, "share must be in [0, 1]");
     LDOT_REQUIRE(total_rows >= 0, LDOT_EINVAL, "negative row count");
     if (nq > 0) LDOT_REQUIRE(stat_out != nullptr, LDOT_EINVAL, "NULL buffer");
     return search_begin_impl(ix, queries, nq, dtype, mem, normalize, k, nullptr, false, (hipStream_t)stream, nullptr, false, parts, stat_out,
-                             total_rows);
+                             total_rows, share);
 }
 
-int ldot_shard_floor(const float* stat, int64_t nq, float* floor_out, int32_t* unproven_out, void* stream) {
-    LDOT_REQUIRE(nq >= 0, LDOT_EINVAL, "negative query count");
-    LDOT_REQUIRE(unproven_out != nullptr, LDOT_EINVAL, "NULL buffer");
-    if (nq > 0) LDOT_REQUIRE(stat != nullptr && floor_out != nullptr, LDOT_EINVAL, "NULL buffer");
-    return launch_shard_floor(stat, nq, floor_out, unproven_out, (hipStream_t)stream);
+int ldot_index_shard_floor(ldot_index_t* ix, const float* stat, float* floor_out, int32_t* count_out, int* k_prime_out, void* stream) {
+    LDOT_REQUIRE(ix != nullptr, LDOT_EINVAL, "index is NULL");
+    if (k_prime_out) *k_prime_out = ix->pend_kp;
+    const int64_t nq = ix->pend_nq;
+    if (nq == 0) return LDOT_OK;
+    LDOT_REQUIRE(stat != nullptr && floor_out != nullptr && count_out != nullptr, LDOT_EINVAL, "NULL buffer");
+    DeviceGuard guard(ix->device);
+    return launch_shard_floor(stat, nq, (const float*)ix->w_ls.p, (const int32_t*)ix->w_li.p, ix->pend_kp, floor_out, count_out,
+                              (hipStream_t)stream);
 }
 
 // A sharded search in three steps (lightningdot_amd/sharded.py): every rank warms up on its own shard and publishes two numbers per

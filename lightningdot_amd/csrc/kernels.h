@@ -136,8 +136,9 @@ int launch_select_pools_parts(const uint4* pool, const int32_t* pool_cnt, int ns
 // sharded search: warm-up statistics (stat[q] = threshold, stat[nq + q] = -(m-th best)), their neutral element, and the agreed floor
 int launch_list_stats(const float* list_s, const int32_t* list_i, int kp, int64_t nq, int m, const float* tau, float* stat, hipStream_t st,
                       int slots = 2, const float* level = nullptr, const int32_t* redone = nullptr);
-// end-of-scan statistics of all ranks (3 x nq, all-reduced with MAX) -> floor[q] + the number of queries some rank cannot vouch for
-int launch_shard_floor(const float* stat, int64_t nq, float* floor_out, int32_t* unproven, hipStream_t st);
+// end-of-scan statistics of all ranks (3 x nq, all-reduced with MAX) -> floor[q] + this shard's list entries at or above the largest level
+int launch_shard_floor(const float* stat, int64_t nq, const float* list_s, const int32_t* list_i, int kp, float* floor_out,
+                       int32_t* count_out, hipStream_t st);
 int launch_neutral_stats(int64_t nq, float* stat, hipStream_t st);
 int launch_apply_stats(int64_t nq, const float* stat, float* tau, hipStream_t st);
 // optimistic thresholds of the fused scan: tau_opt = max(tau_opt, m-th best of the list); initial values; end-of-scan verification

@@ -1368,8 +1368,8 @@ __global__ __launch_bounds__(256) void list_stats_kernel(const float* __restrict
         key[r] = valid ? desc_key(ls[q * kp + e]) : 0xffffffffu;
         nvalid += __popcll(__ballot(valid));
     }
-    float tm = -INFINITY;
-    if (nvalid >= m) {
+    float tm = m > 0 ? -INFINITY : INFINITY;   // (m = 0: this list vouches for no row — the neutral element of the reduction)
+    if (m > 0 && nvalid >= m) {
         uint32_t T = 0;   // smallest key with #(keys <= T) >= m  (descending keys: the m-th best score)
         for (int b = 31; b >= 0; --b) {
             const uint32_t trial = T | ((1u << b) - 1u);
@@ -1406,25 +1406,32 @@ int launch_list_stats(const float* list_s, const int32_t* list_i, int kp, int64_
 }
 
 // the floor of a sharded search from the all-reduced (MAX) end-of-scan statistics of its ranks (3 x nq floats, ldot.h):
-// floor = max(largest k'-th best of a rank, smallest ceil(k'/parts)-th best of a rank) <= the global k'-th best; a query is UNPROVEN when
-// some rank's list is only complete above a score higher than that floor (a shard scanned on pooled statistics that aimed too high)
-__global__ __launch_bounds__(256) void shard_floor_kernel(const float* __restrict__ stat, int64_t nq, float* __restrict__ floor_out,
-                                                          int32_t* __restrict__ unproven) {
-    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    bool bad = false;
-    if (q < nq) {
-        const float fl = fmaxf(stat[q], -stat[nq + q]);
-        floor_out[q] = fl;
-        bad = !(fl >= stat[2 * nq + q]);
+// floor = max(largest k'-th best of a rank, smallest vouched-for order statistic of the ranks) <= the global k'-th best, and — for the
+// check of the pooled statistics — the number of THIS shard's list entries at or above the largest level of any shard (all of its rows
+// up there are in the list): the ranks add these up, k' or more of them prove that no shard lost a row of the global top k'.
+// One wave per query.  (No pooled level anywhere: nothing to prove, the count reports k'.)
+__global__ __launch_bounds__(256) void shard_floor_kernel(const float* __restrict__ stat, int64_t nq, const float* __restrict__ ls,
+                                                          const int32_t* __restrict__ li, int kp, float* __restrict__ floor_out,
+                                                          int32_t* __restrict__ count_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const float level = stat[2 * nq + q];
+    int c = 0;
+    if (level > -INFINITY)
+        for (int e = lane; e < kp; e += 64) c += (li[q * kp + e] >= 0 && ls[q * kp + e] >= level) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (lane == 0) {
+        floor_out[q] = fmaxf(stat[q], -stat[nq + q]);
+        count_out[q] = level > -INFINITY ? c : kp;
     }
-    const int nbad = __popcll(__ballot(bad));
-    if ((threadIdx.x & 63) == 0 && nbad) atomicAdd(unproven, nbad);
 }
 
-int launch_shard_floor(const float* stat, int64_t nq, float* floor_out, int32_t* unproven, hipStream_t st) {
-    LDOT_HIP_CHECK(hipMemsetAsync(unproven, 0, 4, st));
+int launch_shard_floor(const float* stat, int64_t nq, const float* list_s, const int32_t* list_i, int kp, float* floor_out,
+                       int32_t* count_out, hipStream_t st) {
     if (nq <= 0) return LDOT_OK;
-    hipLaunchKernelGGL(shard_floor_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, stat, nq, floor_out, unproven);
+    hipLaunchKernelGGL(shard_floor_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, stat, nq, list_s, list_i, kp, floor_out, count_out);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

@@ -212,34 +212,39 @@ class FlatIPIndex:
         self._pending = (nq, int(k), keep.device)
         return tau
 
-    def search_begin_shard(self, queries, k: int, parts: int, total_rows: int = 0):
+    def search_begin_shard(self, queries, k: int, parts: int, total_rows: int = 0, share: float = None):
         """First half of a sharded search for ONE of ``parts`` shards (CUDA tensors): the candidate pass + the statistics the ranks
         all-reduce with MAX, a float32 CUDA tensor [3, nq] (ldot.h: the k'-th best, minus the ceil(k'/parts)-th best, the level above
         which this shard's list is complete).  ``total_rows`` > 0 = the rows of all shards: large batches scan on statistics pooled
-        over the whole index (fewer admitted records, one launch); ``shard_floor`` then tells whether that was safe."""
+        over the whole index (fewer admitted records, one launch); ``shard_floor`` then tells whether that was safe.  ``share`` = the
+        part of the k' rows this shard vouches for (default 1/parts; the shares of all shards must add up to at least 1)."""
         import torch
         keep, ptr, nq, dt, mem = _describe(queries, self.d, self.device)
         if mem != L.DEVICE:
             raise ValueError('search_begin_shard expects a CUDA tensor')
         stat = torch.empty((3, nq), dtype=torch.float32, device=keep.device)
-        L.check(self._lib.ldot_index_search_begin_shard(self._h, ptr, nq, dt, mem, int(self.normalize), int(k), int(parts),
+        share = 1.0 / parts if share is None else float(share)
+        L.check(self._lib.ldot_index_search_begin_shard(self._h, ptr, nq, dt, mem, int(self.normalize), int(k), int(parts), share,
                                                         int(total_rows), ctypes.c_void_p(stat.data_ptr()), _stream_ptr(self.device)))
         self._pending = (nq, int(k), keep.device)
         return stat
 
     def shard_floor(self, stat):
-        """All-reduced (MAX) statistics of ``search_begin_shard`` -> (floor [nq] float32, unproven [1] int32), CUDA tensors: the floor
-        for ``search_finish`` and the number of queries some shard's pooled thresholds lost rows for (0 = the merged lists are exact;
-        otherwise every rank searches again with total_rows = 0)."""
+        """All-reduced (MAX) statistics of ``search_begin_shard`` -> (floor [nq] float32, count [nq] int32, k'): the floor for
+        ``search_finish`` and this shard's number of list entries at or above the largest level of any shard — the ranks add the counts
+        up (all-reduce SUM); a query whose sum is below k' is unproven and every rank searches again with total_rows = 0."""
         import torch
+        if self._pending is None:
+            raise L.LdotError(-5, 'shard_floor without a pending search_begin_shard')
+        nq, _, dev = self._pending
         stat = stat.contiguous()
-        nq = stat.shape[1]
         assert stat.shape == (3, nq) and stat.dtype == torch.float32 and stat.is_cuda
-        floor = torch.empty((nq,), dtype=torch.float32, device=stat.device)
-        bad = torch.empty((1,), dtype=torch.int32, device=stat.device)
-        L.check(self._lib.ldot_shard_floor(ctypes.c_void_p(stat.data_ptr()), nq, ctypes.c_void_p(floor.data_ptr()),
-                                           ctypes.c_void_p(bad.data_ptr()), _stream_ptr(self.device)))
-        return floor, bad
+        floor = torch.empty((nq,), dtype=torch.float32, device=dev)
+        count = torch.empty((nq,), dtype=torch.int32, device=dev)
+        kp = ctypes.c_int(0)
+        L.check(self._lib.ldot_index_shard_floor(self._h, ctypes.c_void_p(stat.data_ptr()), ctypes.c_void_p(floor.data_ptr()),
+                                                 ctypes.c_void_p(count.data_ptr()), ctypes.byref(kp), _stream_ptr(self.device)))
+        return floor, count, int(kp.value)
 
     def search_warmup(self, queries, k: int, parts: int):
         """First step of a sharded search over ``parts`` shards (CUDA tensors): ingests the queries, warms up on this shard and returns

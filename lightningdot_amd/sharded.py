@@ -75,7 +75,7 @@ class ShardedFlatIndexer:
         # True (default): large batches scan every shard on order statistics taken against the WHOLE index
         # (ldot_index_search_begin_shard, total_rows > 0): ~1/world of the admitted records and one launch after the warm-up.  It assumes
         # rows spread over the shards (and stored) in no order that correlates with the queries; the ranks check the result together
-        # (ldot_shard_floor) and a search that fails the check is repeated on every rank with each shard's own thresholds, after which
+        # (ldot_index_shard_floor) and a search that fails the check is repeated on every rank with each shard's own thresholds, after which
         # the pooled statistics are skipped for `_pooled_backoff` searches (16, doubling up to 1024 while searches keep failing).
         # Every rank sees the same all-reduced numbers, so all of them take the same decisions.
         self.pooled_statistics = pooled_statistics
@@ -253,6 +253,14 @@ class ShardedFlatIndexer:
         else:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
 
+    def _all_reduce_sum(self, t: torch.Tensor) -> None:
+        if t.is_cuda and dist.get_backend(self.group) != 'nccl':
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
     def _all_to_all(self, send: torch.Tensor) -> torch.Tensor:
         """send[r] goes to rank r; returns recv with recv[r] = what rank r sent here.  RCCL moves device tensors over xGMI; a
         backend without device all-to-all (gloo, the one-GPU test rig) exchanges host copies."""
@@ -309,13 +317,15 @@ class ShardedFlatIndexer:
                 tau = ix.search_scan(stat)
                 self._all_reduce_max(tau)
             elif self.world > 1 and q_all.is_cuda:
-                stat = ix.search_begin_shard(q_all, k, self.world, self.ntotal if pooled else 0)
+                stat = ix.search_begin_shard(q_all, k, self.world, self.ntotal if pooled else 0, share=self._share())
                 self._all_reduce_max(stat)
-                tau, bad = ix.shard_floor(stat)
+                tau, count, kp = ix.shard_floor(stat)
                 if pooled:
+                    # the verdict (off the critical path): k' rows at or above the largest level of any shard, all ranks together
+                    self._all_reduce_sum(count)
                     if self._bad_host is None:
                         self._bad_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-                    self._bad_host.copy_(bad, non_blocking=True)
+                    self._bad_host.copy_((count < kp).sum(dtype=torch.int32).reshape(1), non_blocking=True)
             else:
                 tau = ix.search_begin(q_all, k)
                 if self.world > 1:
@@ -386,6 +396,15 @@ class ShardedFlatIndexer:
         if out is not None:
             torch.cuda.current_stream().synchronize()
         return out_s, out_l
+
+    def _share(self) -> float:
+        """The part of the k' rows this shard vouches for in the floor statistic: in proportion to its rows among the shards that hold at
+        least 1 / (4 world) of the index, 0 for smaller ones (every rank computes the same shares from the same offsets; they add up
+        to 1)."""
+        sizes = [self.offsets[r + 1] - self.offsets[r] for r in range(self.world)]
+        big = [s for s in sizes if s > 0 and s * 4 * self.world >= self.ntotal]
+        mine = sizes[self.rank]
+        return mine / sum(big) if big and mine > 0 and mine * 4 * self.world >= self.ntotal else 0.0
 
     def search_knn(self, local_queries, top_docs: int):
         """DenseIndexer-style result for the local queries: [(ids, scores ndarray)]."""

@@ -75,7 +75,7 @@ _CASES = {
     'equal': dict(bounds=[0, 40000, 80000, 120000, 160000], counts=[320, 320, 320, 320], d=256, k=100, equal=True),
     # rows that are NOT exchangeable between the shards: the first 30 000 rows of shard 1 are three times as long as all others, so
     # every query's best rows sit there and that shard's pooled statistics (taken from its first 4096 rows) aim above the global k'-th
-    # best.  The ranks notice together (ldot_shard_floor), repeat the search on their own thresholds and back off
+    # best.  The ranks notice together (ldot_index_shard_floor: fewer than k' rows at or above the largest level), repeat the search on their own thresholds and back off
     'skewed': dict(bounds=[0, 40000, 80000, 120000, 160000], counts=[320, 320, 320, 320], d=128, k=100, equal=True,
                    scale=(40000, 70000, 3.0)),
 }

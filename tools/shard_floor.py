@@ -49,8 +49,8 @@ def stats(total):
 stat_b = stats(0)
 def run_b():
     ix0.search_begin_shard(q, K, G, 0)
-    floor, bad = ix0.shard_floor(stat_b)
-    return ix0.search_finish(floor), bad
+    floor, cnt, kp = ix0.shard_floor(stat_b)
+    return ix0.search_finish(floor), (cnt, kp)
 print('(b) own thresholds, three-number floor:                 %.3f ms' % t(run_b), ' admitted/query %.0f' % (ix0.last_stats()['fused_candidates'] / NQ),
       ' survivors/query %.1f' % survivors(run_b()[0][1]))
 
@@ -58,12 +58,18 @@ print('(b) own thresholds, three-number floor:                 %.3f ms' % t(run_
 stat_c = stats(G * PER)
 def run_c():
     ix0.search_begin_shard(q, K, G, G * PER)
-    floor, bad = ix0.shard_floor(stat_c)
-    return ix0.search_finish(floor), bad
+    floor, cnt, kp = ix0.shard_floor(stat_c)
+    return ix0.search_finish(floor), (cnt, kp)
 print('(c) pooled statistics, three-number floor:              %.3f ms' % t(run_c), ' admitted/query %.0f' % (ix0.last_stats()['fused_candidates'] / NQ),
       ' survivors/query %.1f' % survivors(run_c()[0][1]))
-(_, _), bad = run_c()
-print('    queries the ranks cannot vouch for: %d' % int(bad.item()))
+total = 0
+for ix in shards:          # the all-reduce(SUM) of the counts at or above the largest level
+    ix.search_begin_shard(q, K, G, G * PER)
+    _, cnt, kp = ix.shard_floor(stat_c)
+    total = total + cnt
+    ix.search_finish(None)
+print('    queries the ranks cannot vouch for (fewer than k\' = %d rows at or above the largest level): %d;  rows up there per query: %.0f'
+      % (kp, int((total < kp).sum()), float(total.float().mean())))
 
 # (d) agreed thresholds after the warm-ups
 stat_w = torch.stack([ix.search_warmup(q, K, G) for ix in shards], 0).amax(0)
@@ -77,9 +83,9 @@ print('(d) thresholds agreed after the warm-ups, floor of (a): %.3f ms' % t(run_
 
 # exactness of (c): merge of the eight partial lists == plain search of the whole index
 parts_s, parts_l = [], []
-floor_c, _ = ix0.shard_floor(stat_c)
 for r, ix in enumerate(shards):
     ix.search_begin_shard(q, K, G, G * PER)
+    floor_c, _, _ = ix.shard_floor(stat_c)
     s, l = ix.search_finish(floor_c)
     parts_s.append(s); parts_l.append(torch.where(l >= 0, l + r * PER, l))
 S = torch.cat(parts_s, 1); Lb = torch.cat(parts_l, 1)

@@ -29,7 +29,8 @@ for _ in range(6):
         # the floor term replaced by one that keeps ~22 rows (what eight real shards give, tools/shard_floor.py)
         stat = ix.search_begin_shard(q, K, G, G * n if mode == 'pooled' else 0)
         stat[0] = torch.maximum(stat[0], s[:, 21])
-        fl, bad = ix.shard_floor(stat)
+        fl, cnt, kp = ix.shard_floor(stat)
+        bad = (cnt < kp).sum()     # (what follows the all-reduce(SUM) of the counts)
         ix.search_finish(fl)
     else:
         ix.search_begin(q, K); ix.search_finish(floor)
