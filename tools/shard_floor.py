@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-rank cost of the 8-GPU case on one GPU: 8 shards of 125 000 rows (all resident here, 4.7 GB), 10 000 queries, top-100.
+"""Per-rank cost of the G-GPU case (default 8) on one GPU: G shards of 1M / G rows (all resident here, 4.7 GB), 10 000 queries, top-100.
 The eight ranks are played one after the other; what the all-reduce(MAX) would deliver is computed from all eight shards'
 statistics, so the floor every variant re-scores against is the REAL one (round 3's tool assumed a floor that keeps ~16 rows).
   (a) round 3 exchange: every shard on its own thresholds, floor = the largest k'-th best of a shard;
@@ -12,7 +12,8 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lightningdot_amd import _lib as L
 from lightningdot_amd.indexer import FlatIPIndex
-G, K, PER, D, NQ = 8, 100, 125000, 768, 10000
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 8           # usage: tools/shard_floor.py [ranks]  (1M rows / ranks per shard)
+K, PER, D, NQ = 100, 1000000 // G, 768, 10000
 g = torch.Generator(device='cuda').manual_seed(0)
 q = torch.randn(NQ, D, device='cuda', generator=g)
 shards = []
