@@ -81,7 +81,8 @@ class ShardedFlatIndexer:
         self.pooled_statistics = pooled_statistics
         self._pooled_backoff, self._pooled_penalty = 0, 16
         self.last_search = {}                    # diagnostics of the last search (pooled / repeated)
-        self._bad_host = None                    # pinned int32: the check's verdict, copied behind the kernels that produce it
+        self._bad_host = None                    # pinned int32: the check's verdict
+        self._verdict = None                     # (work handle, counts, k') of the search in progress
         self._blocks = {}                        # send buffers of the blocked exchange, by size
         self._custom = local_search is not None
         self.local = None if self._custom else DenseFlatIndexer(vector_sz, normalize=normalize)
@@ -253,13 +254,15 @@ class ShardedFlatIndexer:
         else:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
 
-    def _all_reduce_sum(self, t: torch.Tensor) -> None:
+    def _all_reduce_sum_async(self, t: torch.Tensor):
+        """in-place SUM over the ranks, not waited for: returns the work handle (RCCL: the collective runs on the communicator's stream
+        while this stream goes on) or None when it has completed (a backend without device collectives reduces a host copy)."""
         if t.is_cuda and dist.get_backend(self.group) != 'nccl':
             h = t.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
             t.copy_(h)
-        else:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            return None
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _all_to_all(self, send: torch.Tensor) -> torch.Tensor:
         """send[r] goes to rank r; returns recv with recv[r] = what rank r sent here.  RCCL moves device tensors over xGMI; a
@@ -283,14 +286,22 @@ class ShardedFlatIndexer:
             self._pooled_backoff -= 1
             pooled = False
         self.last_search = {'pooled': pooled, 'repeated': False}
+        self._verdict = None
         res = self._search(local_queries, k, out, pooled)
-        if pooled:
-            # the verdict was copied to pinned memory behind the kernels that produced it
+        if pooled and self._verdict is not None:
+            # the counts were all-reduced (SUM) while the re-score, the list exchange and the merge ran
+            work, count, kp = self._verdict
+            if work is not None:
+                work.wait()
+            if self._bad_host is None:
+                self._bad_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._bad_host.copy_((count < kp).sum(dtype=torch.int32).reshape(1), non_blocking=True)
             torch.cuda.current_stream().synchronize()
             if int(self._bad_host[0]) > 0:       # the same number on every rank: all of them repeat the search
                 self.last_search['repeated'] = True
                 self._pooled_backoff = self._pooled_penalty
                 self._pooled_penalty = min(2 * self._pooled_penalty, 1024)
+                self._verdict = None
                 return self._search(local_queries, k, out, False)
             self._pooled_penalty = 16
         return res
@@ -322,10 +333,7 @@ class ShardedFlatIndexer:
                 tau, count, kp = ix.shard_floor(stat)
                 if pooled:
                     # the verdict (off the critical path): k' rows at or above the largest level of any shard, all ranks together
-                    self._all_reduce_sum(count)
-                    if self._bad_host is None:
-                        self._bad_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-                    self._bad_host.copy_((count < kp).sum(dtype=torch.int32).reshape(1), non_blocking=True)
+                    self._verdict = (self._all_reduce_sum_async(count), count, kp)
             else:
                 tau = ix.search_begin(q_all, k)
                 if self.world > 1:
@@ -364,7 +372,8 @@ class ShardedFlatIndexer:
             return s.new_empty((0, k)), l.new_empty((0, k))
         if out is not None:
             res = self._merge(part_s.contiguous(), part_l.contiguous(), k, out=out)
-            torch.cuda.current_stream().synchronize()
+            if self._verdict is None:            # (a pooled search synchronises once, after its verdict)
+                torch.cuda.current_stream().synchronize()
             return res
         return self._merge(part_s.contiguous(), part_l.contiguous(), k)
 
@@ -393,7 +402,7 @@ class ShardedFlatIndexer:
         L.check(lib.ldot_merge_topk_blocked(ctypes.c_void_p(recv.data_ptr()), self.world, mx, block_bytes, mx, k, k,
                                             ctypes.c_void_p(out_s.data_ptr()), ctypes.c_void_p(out_l.data_ptr()),
                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        if out is not None:
+        if out is not None and self._verdict is None:   # (a pooled search synchronises once, after its verdict)
             torch.cuda.current_stream().synchronize()
         return out_s, out_l
 
