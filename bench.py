@@ -60,6 +60,7 @@ def main():
     ap.add_argument('--split-bf16', action='store_true',
                     help='LDOT_OPT_PRECISION=1: split-bf16 candidate pass (3 MFMA products per element); not the headline')
     ap.add_argument('--no-optimistic', action='store_true', help='LDOT_OPT_OPTIMISTIC = 0: guaranteed thresholds only (measurement aid; not the headline)')
+    ap.add_argument('--scan-order', type=int, default=0, help='LDOT_OPT_SCAN_ORDER: 0 auto (the headline), 1 storage order, 2 scrambled (measurement aid)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary workloads measured after the timed region')
     ap.add_argument('--no-kernel-events', action='store_true',
@@ -143,6 +144,8 @@ def main():
             ix.index.set_option(L.OPT_PRECISION, 1)
         if args.no_optimistic:
             ix.index.set_option(L.OPT_OPTIMISTIC, 0)
+        if args.scan_order:
+            ix.index.set_option(L.OPT_SCAN_ORDER, args.scan_order)
         if args.growth:
             ix.index.set_option(L.OPT_GROWTH_PCT, args.growth)
         if args.warm:

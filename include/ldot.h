@@ -75,6 +75,14 @@ extern "C" {
                                  * verify every query's list afterwards (queries that fail are searched again on guaranteed thresholds):
                                  * a third of the admitted candidates, four launches instead of six per 1M rows; results are identical.
                                  * 0: guaranteed thresholds only (the k'-th best score seen so far) */
+#define LDOT_OPT_SCAN_ORDER 12  /* the order in which large batches scan the index rows.  1: storage order.  2: scrambled — the 384-row tiles of the
+                                 * whole index in a fixed pseudo-random order and a warm-up on a spread sample, so that the rows seen so far
+                                 * are a fair sample of the index when it is stored in long runs of similar rows (sorted by class, source,
+                                 * coarse cluster: runs of thousands of rows; runs about as long as a tile stay together and keep failing
+                                 * the check — shuffle such rows before adding them): what the optimistic thresholds and the candidate
+                                 * pools assume; +1 % on rows stored in random order.  0 (default):
+                                 * storage order until one query in a thousand of a search fails the optimistic check, scrambled from then
+                                 * on.  Results are identical in every order */
 #define LDOT_OPT_VERIFY 10      /* 1: after every search flag the queries whose top-k cannot be vouched for: the k-th exact score is not above
                                  * the candidate threshold by E = 4 * 2^-8 * |q| * max|x| / sqrt(d), a STATISTICAL bound of the bf16
                                  * rounding error of a d-term inner product (4 standard deviations for independent rounding errors;

@@ -15,6 +15,7 @@ HOST, DEVICE = 0, 1
 MODE_AUTO, MODE_DENSE, MODE_FUSED = 0, 1, 2
 OPT_MODE, OPT_RESCORE, OPT_CHUNK_ROWS, OPT_MARGIN, OPT_PROFILE, OPT_WARM_ROWS, OPT_GROWTH_PCT, OPT_PRECISION, OPT_RESERVE_ROWS = 1, 2, 3, 4, 5, 6, 7, 8, 9
 OPT_OPTIMISTIC = 11
+OPT_SCAN_ORDER = 12
 OPT_VERIFY = 10
 ABI_VERSION = 4
 MAX_MARGIN = 1024

@@ -140,6 +140,11 @@ struct ldot_index {
     // flagged more than 1 / 64 of its queries the optimistic schedule is skipped for `opt_backoff` searches, twice as many after every
     // further failure (reset by a search that passes)
     int opt_backoff = 0, opt_penalty = 16;
+    // LDOT_OPT_SCAN_ORDER: 0 auto (sequential until the optimistic check fails for more than 1 / 64 of a search's queries, then scrambled
+    // for the rest of the index's life), 1 sequential, 2 scrambled.  scrambled_now: the optimistic scan in progress visits the row tiles
+    // in the pseudo-random order (fused_rest_chunk_optimistic)
+    int scan_order = 0;
+    bool scrambled_auto = false, scrambled_now = false;
     bool opt_used = false;           // the scan in progress filtered with optimistic thresholds
     int64_t opt_nq = 0;
     int cur_parts = 1;   // shards of the search in progress (1 = plain search): sizes the warm-up of a fused scan, fused_warm_rows
@@ -337,6 +342,11 @@ int ldot_index_set_option(ldot_index_t* ix, int option, int64_t value) {
         case LDOT_OPT_OPTIMISTIC:
             LDOT_REQUIRE(value == 0 || value == 1, LDOT_EINVAL, "LDOT_OPT_OPTIMISTIC is 0 or 1");
             ix->optimistic = (int)value;
+            return LDOT_OK;
+        case LDOT_OPT_SCAN_ORDER:
+            LDOT_REQUIRE(value >= 0 && value <= 2, LDOT_EINVAL, "LDOT_OPT_SCAN_ORDER is 0 (auto), 1 (sequential) or 2 (scrambled)");
+            ix->scan_order = (int)value;
+            ix->scrambled_auto = false;
             return LDOT_OK;
         case LDOT_OPT_GROWTH_PCT:
             LDOT_REQUIRE(value >= 5 && value <= 10000, LDOT_EINVAL, "growth_pct must be in [5, 10000]");
@@ -693,7 +703,7 @@ constexpr int64_t kFewBlockGrowthPct = 1600;   // launch growth with ONE query b
 // one fused-filter launch over index rows [r, r + len) for the queries [q0, q0 + nq) + the pool select that folds its records into
 // the running lists and raises the thresholds
 static int fused_launch_and_select(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_pad, int kp, int64_t r, int64_t len,
-                                   hipStream_t st, float* tau_opt = nullptr, int opt_m_next = 0) {
+                                   hipStream_t st, float* tau_opt = nullptr, int opt_m_next = 0, int64_t scramble_tiles = 0) {
     float* tau = (float*)ix->w_tau.p + q0;
     // (the optimistic scan filters with w_tau_opt; the selects keep the guaranteed w_tau and refresh w_tau_opt for the next launch)
     const float* filter_tau = tau_opt ? tau_opt : tau;
@@ -705,8 +715,9 @@ static int fused_launch_and_select(ldot_index* ix, int64_t q0, int64_t nq, int64
     const int64_t nslices = 256 / qg, nsubs = kPoolSubsPerSlice * nslices;
     int rc;
     prof_begin(ix, st, 2.0 * nq * len * ix->d, (double)len * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * kp * 8);
-    rc = launch_score_filter(ix->x16b, ix->ld16(), r, len, q16, ix->ld16(), nq_pad, (int)ix->ld16(), filter_tau, (uint4*)ix->w_pool.p,
-                             (int32_t*)ix->w_pool_cnt.p, st);
+    // (scrambled scan: rows [r, r + len) of the pseudo-random tile order of the whole index)
+    rc = launch_score_filter(ix->x16b, ix->ld16(), scramble_tiles ? 0 : r, len, q16, ix->ld16(), nq_pad, (int)ix->ld16(), filter_tau,
+                             (uint4*)ix->w_pool.p, (int32_t*)ix->w_pool_cnt.p, st, scramble_tiles, scramble_tiles ? r / fused_tile_rows() : 0);
     prof_end(ix, st);
     if (rc) return rc;
     if (nq <= kFewSelectMaxQueries && nsubs >= 128 * kPoolSubsPerSlice && kp + 512 + 32 <= 1024) {
@@ -777,10 +788,45 @@ static int64_t fused_warm_rows(const ldot_index* ix, int64_t nq, int64_t nq_pad,
     return std::min(ix->ntotal, warm);
 }
 
-static int fused_warm_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_pad, int kp, hipStream_t st) {
+// large batches of a plain search (and shards on pooled statistics) filter with optimistic thresholds; few-query searches have their
+// own launch schedule, shards of the agreed-threshold exchange their agreed thresholds
+static bool optimistic_scan(const ldot_index* ix, int64_t nq, int parts) {
+    bool opt_on = ix->optimistic && ix->opt_backoff == 0;
+#ifdef LDOT_ABLATION
+    if (getenv("LDOT_DEBUG_NOOPT")) opt_on = false;   // (the kernel ablation variants produce no candidates: the end-of-scan check would redo every query)
+#endif
+    return opt_on && parts == 1 && ix->cur_parts == 1 && nq > kFewSelectMaxQueries;
+}
+
+// Scrambled scan order (LDOT_OPT_SCAN_ORDER).  The optimistic thresholds assume that the rows scanned so far are a fair sample of the
+// index.  Rows stored in an order that correlates with the queries (sorted by cluster, by class, by source) break that — and the pool
+// bound of the guaranteed thresholds with it: a query's best rows arrive together.  The remedy is to scan in an order that does not
+// follow the storage order: the fused launches visit the 384-row tiles of the WHOLE index in a fixed pseudo-random order (tile j of the
+// order = tile (j x mul) mod T, score_filter.hip) and the warm-up scores a SPREAD sample (every T/16-th 256-row tile) that only yields
+// the first thresholds: its rows are scanned again with everybody else, the lists start empty.
+static bool scrambled_scan(const ldot_index* ix, int64_t nq, int parts, int kp) {
+    return optimistic_scan(ix, nq, parts) && (ix->scan_order == 2 || (ix->scan_order == 0 && ix->scrambled_auto)) &&
+           ix->ntotal >= 8 * fused_warm_rows(ix, nq, round_up(nq, kBM), kp);
+}
+
+static int fused_warm_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_pad, int kp, int parts, hipStream_t st) {
     // (q0 is a multiple of 256: whole 16-row blocks of the query shadow)
     const int64_t warm = fused_warm_rows(ix, nq, nq_pad, kp);
-    return dense_scan_all(ix, nq, 0, warm, kp, (float*)ix->w_tau.p, nq <= 64, st, q0);
+    if (!scrambled_scan(ix, nq, parts, kp)) return dense_scan_all(ix, nq, 0, warm, kp, (float*)ix->w_tau.p, nq <= 64, st, q0);
+    // spread sample: `warm` rows in 256-row tiles at equal distances over the index, scored and selected like a contiguous chunk (the
+    // labels the select writes are column numbers: the list is only read by the first tau_opt and then cleared)
+    const int64_t wpad = round_up(warm, kBN), tiles = wpad / kBN;
+    const int64_t stride = tiles > 1 ? (ix->ntotal - kBN) / (tiles - 1) / 16 * 16 : kBN;
+    const uint16_t* q16 = (const uint16_t*)ix->w_q16b.p + q0 * ix->ld16();
+    int rc = ix->w_S.ensure((size_t)nq_pad * wpad * sizeof(float));
+    if (rc) return rc;
+    prof_begin(ix, st, 2.0 * nq * wpad * ix->d, (double)wpad * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * wpad * 4);
+    rc = launch_score_dense(q16, ix->ld16(), nq_pad, ix->x16b, ix->ld16(), 0, wpad, (int)ix->ld16(), (float*)ix->w_S.p, wpad, nq, st, stride);
+    prof_end(ix, st);
+    if (rc) return rc;
+    ix->stats[2] += wpad * nq;
+    return launch_select_dense((const float*)ix->w_S.p, wpad, nq, wpad, 0, (float*)ix->w_ls.p + q0 * kp, (int32_t*)ix->w_li.p + q0 * kp, kp,
+                               (float*)ix->w_tau.p + q0, st);
 }
 
 // ---- optimistic thresholds (round 4) ---------------------------------------------------------------------------------------------------
@@ -830,6 +876,9 @@ static int fused_rest_chunk_optimistic(ldot_index* ix, int64_t q0, int64_t nq, i
     const bool pooled = ix->pool_total > 0;
     const int64_t Ng = pooled ? std::max(ix->pool_total, N) : N;
     ix->pooled_used = pooled;
+    const bool scr = scrambled_scan(ix, nq, 1, kp);
+    ix->scrambled_now = scr;
+    const int64_t T = (N + bm - 1) / bm, Nscan = scr ? T * bm : N;   // (scrambled: every tile of the index, the warm-up's rows included)
     if ((rc = fused_pools(ix, nq_pad, st))) return rc;
     float* tau = (float*)ix->w_tau.p + q0;
     float* tau_opt = (float*)ix->w_tau_opt.p + q0;
@@ -842,21 +891,24 @@ static int fused_rest_chunk_optimistic(ldot_index* ix, int64_t q0, int64_t nq, i
     if (const char* e = getenv("LDOT_DEBUG_OPT_GROWTHX")) growth_x = atoll(e);
     if (const char* e = getenv("LDOT_DEBUG_OPT_MAXROWS")) max_rows = atoll(e);
 #endif
-    int64_t r = warm;
+    int64_t r = scr ? 0 : warm;   // rows scanned by the fused launches so far (scrambled: in the pseudo-random tile order, from its start)
     // the first thresholds come from the warm-up's list; every pool select then leaves the next launch's behind (and the last one checks)
-    if ((rc = launch_tau_opt(ls, li, kp, nq, optimistic_m(kp, r, Ng, eps), tau, tau_opt, st))) return rc;
-    while (r < N) {
-        const int m = optimistic_m(kp, r, Ng, eps);
+    if ((rc = launch_tau_opt(ls, li, kp, nq, optimistic_m(kp, warm, Ng, eps), tau, tau_opt, st))) return rc;
+    if (scr && (rc = launch_init_lists((float*)ix->w_ls.p + q0 * kp, (int32_t*)ix->w_li.p + q0 * kp, nq_pad * kp, tau, nq, nq_pad, st)))
+        return rc;   // (the spread sample's rows come again with the scan: the lists start empty)
+    while (r < Nscan) {
+        const int64_t seen = std::max(r, warm);   // the rows the thresholds in force were drawn from
+        const int m = optimistic_m(kp, seen, Ng, eps);
         // expected records per query of a launch over len rows: len m / r, kept <= kFill per sub-pool like the guaranteed schedule's bound
         // (pooled statistics run AT this bound, and the m-th best of a few thousand rows is a noisy quantile — some queries admit
         // 1.5x the expectation —: half the fill there)
-        int64_t len = std::min<int64_t>(std::min<int64_t>(r * growth_x, max_rows), r * (pooled ? kFill / 2 : kFill) * nsubs / m);
+        int64_t len = std::min<int64_t>(std::min<int64_t>(seen * growth_x, max_rows), seen * (pooled ? kFill / 2 : kFill) * nsubs / m);
         len = std::max<int64_t>(len / unit * unit, unit);
-        len = std::min(len, N - r);
-        if (N - r - len < len / 4 && N - r <= max_rows + unit) len = N - r;   // no short tail launch
-        const int m_next = r + len < N ? optimistic_m(kp, r + len, Ng, eps) : pooled ? -1 : 0;   // (0: the last select verifies)
-        if ((rc = fused_launch_and_select(ix, q0, nq, nq_pad, kp, r, len, st, tau_opt, m_next))) return rc;
-        ix->stats[3] += len * nq;
+        len = std::min(len, Nscan - r);
+        if (Nscan - r - len < len / 4 && Nscan - r <= max_rows + 2 * unit) len = Nscan - r;   // no short tail launch
+        const int m_next = r + len < Nscan ? optimistic_m(kp, r + len, Ng, eps) : pooled ? -1 : 0;   // (0: the last select verifies)
+        if ((rc = fused_launch_and_select(ix, q0, nq, nq_pad, kp, r, len, st, tau_opt, m_next, scr ? T : 0))) return rc;
+        ix->stats[3] += std::min(len, N - std::min(r, N)) * nq;
         r += len;
     }
     ix->pools_clean = true;
@@ -869,11 +921,7 @@ static int fused_rest_chunk_optimistic(ldot_index* ix, int64_t q0, int64_t nq, i
 static int fused_rest_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_pad, int kp, int parts, hipStream_t st) {
     // large batches of a plain search: optimistic thresholds (few-query searches have their own launch schedule, sharded searches
     // their agreed thresholds)
-    bool opt_on = ix->optimistic && ix->opt_backoff == 0;
-#ifdef LDOT_ABLATION
-    if (getenv("LDOT_DEBUG_NOOPT")) opt_on = false;   // (the kernel ablation variants produce no candidates: the end-of-scan check would redo every query)
-#endif
-    if (opt_on && parts == 1 && ix->cur_parts == 1 && nq > kFewSelectMaxQueries) {
+    if (optimistic_scan(ix, nq, parts)) {
         ix->opt_used = true;
         return fused_rest_chunk_optimistic(ix, q0, nq, nq_pad, kp, st);
     }
@@ -934,6 +982,7 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
         if ((rc = ix->w_tau_opt.ensure((size_t)nq_pad * 4))) return rc;
         ix->opt_used = false;
         ix->pooled_used = false;
+        ix->scrambled_now = false;
         ix->opt_nq = nq;
         if (ix->opt_backoff > 0 && nq > kFewSelectMaxQueries) --ix->opt_backoff;   // (counted in large-batch searches, the ones it applies to)
         if ((rc = launch_init_fused_scan((float*)ix->w_tau_opt.p, (int32_t*)ix->w_qcnt.p, (int32_t*)ix->w_over_sum.p, nq, nq_pad, st))) return rc;
@@ -944,7 +993,7 @@ static int fused_scan(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStr
     }
     for (int64_t q0 = 0; q0 < nq; q0 += kFusedQueryChunk) {
         const int64_t nqc = std::min(kFusedQueryChunk, nq - q0);
-        if (phase != 2 && (rc = fused_warm_chunk(ix, q0, nqc, round_up(nqc, kBM), kp, st))) return rc;
+        if (phase != 2 && (rc = fused_warm_chunk(ix, q0, nqc, round_up(nqc, kBM), kp, phase == 0 ? 1 : 0, st))) return rc;
         if (phase == 0 && (rc = fused_rest_chunk(ix, q0, nqc, round_up(nqc, kBM), kp, 1, st))) return rc;
     }
     if (phase == 1) return LDOT_OK;
@@ -982,7 +1031,13 @@ static bool fused_overflow_check(ldot_index* ix) {
     ix->flags_clean = n_over == 0;
     if (ix->opt_used) {
         ix->opt_used = false;
-        if (n_over * 64 > ix->opt_nq) {
+        // With rows in a fair order a query fails the check once in ~1e7 launches: a search in which one query in a thousand fails says
+        // that the storage order is not a fair sample order — the index scans in the scrambled order from then on.  Failures that
+        // persist (or come with the scrambled order: scores that bf16 cannot tell apart, thousands of equal rows) at more than 1 / 64
+        // of the queries cost more than the optimistic thresholds save: back off to the guaranteed ones for a while.
+        if (ix->scan_order == 0 && !ix->scrambled_auto && !ix->scrambled_now && n_over >= 4 && n_over * 1024 > ix->opt_nq) {
+            ix->scrambled_auto = true;
+        } else if (n_over * 64 > ix->opt_nq) {
             ix->opt_backoff = ix->opt_penalty;
             ix->opt_penalty = std::min(2 * ix->opt_penalty, 1024);
         } else if (n_over == 0) {

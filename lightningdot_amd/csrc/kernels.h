@@ -55,7 +55,7 @@ int launch_scatter_lists(const float* cs, const int32_t* ci, const float* ctau, 
 // q16 / x16 are the BLOCKED shadows (launch_convert_rows dst16b), nq_pad a multiple of 256, xrow0 a multiple of 16
 int launch_score_dense(const void* q16, int64_t ldq_elems, int64_t nq_pad, const void* x16, int64_t ldx_elems,
                        int64_t xrow0, int64_t nrows_pad, int dpad, float* S, int64_t lds_elems, int64_t nq_valid,
-                       hipStream_t st);
+                       hipStream_t st, int64_t tile_stride = 256);   // (tile_stride: rows between the starts of consecutive 256-row tiles)
 
 // <= 64 queries (serving): wave-per-16-row-group scan straight from global memory (score_narrow.hip)
 constexpr int kNarrowMaxQueries = 64;    // 1, 2 or 4 groups of 16 queries per scan
@@ -179,11 +179,19 @@ int launch_translate_cols(int64_t* labels, int64_t nq, int k, const int64_t* lis
 int fused_tile_rows();
 int fused_query_group(int64_t nq_pad);   // 8 / 4 / 2 / 1 -> 1024 / qg sub-pools per query, 256 / qg row slices
 
+// the order in which a fused launch visits its row tiles: tile t sits at physical tile ((base + t) * mul) mod `mod` of the panel
+// (da = nslices * mul mod `mod`, dn = ntiles * mul mod `mod`: the cursors' increments); sequential = {1, 0, 2^30, nslices, ntiles}
+struct ScanOrder {
+    int mul, base, mod, da, dn;
+};
+int scan_order_multiplier(int64_t mod);
+
 // fused MFMA score + threshold filter over index rows [row0, row0 + nrows) (row0 multiple of 16); x16 / q16 are the BLOCKED
-// shadows (launch_convert_rows dst16b)
+// shadows (launch_convert_rows dst16b).  scramble_tiles > 0 (= the 384-row tiles of the WHOLE index, row0 = 0): the launch covers the
+// tiles [scramble_base, scramble_base + ceil(nrows / 384)) of a fixed pseudo-random order of all tiles instead of a contiguous range
 int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_t nrows, const void* q16,
                         int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, uint4* pool, int32_t* pool_cnt,
-                        hipStream_t st);
+                        hipStream_t st, int64_t scramble_tiles = 0, int64_t scramble_base = 0);
 
 // loss path (fp32-input MFMA)
 int launch_sgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* B2, float w, float* C,

@@ -24,7 +24,7 @@ __device__ __forceinline__ void dense_wait_vmcnt() {
 
 __global__ __launch_bounds__(kRingThreads, 2) void score_dense_kernel(
     const char* __restrict__ Q16, int64_t ld_b, int tiles_m, int64_t q_rows, const char* __restrict__ X16, int64_t xrow0,
-    int tiles_n, int nk, float* __restrict__ S, int64_t lds_elems, int64_t m_valid) {
+    int tiles_n, int nk, float* __restrict__ S, int64_t lds_elems, int64_t m_valid, int64_t tile_stride) {
     constexpr int MR = 6;
     using Geo = RingGeom<MR>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_dense_kernel(
         // the last query tile may be short: the buffer bound makes its missing rows read as zero
         const int64_t qrows = q_rows - (int64_t)tm * Geo::kBM;
         sa.rsrc = ring_make_rsrc_n(Q16 + (int64_t)tm * Geo::kBM * ld_b, (qrows < Geo::kBM ? qrows : Geo::kBM) * ld_b);
-        sb.rsrc = ring_make_rsrc_n(X16 + (xrow0 + (int64_t)tn * kRBN) * ld_b, kRBN * ld_b);
+        sb.rsrc = ring_make_rsrc_n(X16 + (xrow0 + (int64_t)tn * tile_stride) * ld_b, kRBN * ld_b);   // (tile_stride > 256: a spread sample)
     };
     set_src(l_u);
     int64_t issued = 0;
@@ -139,10 +139,11 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_dense_kernel(
 // q16 / x16 are the BLOCKED shadows; q_rows = rows of the query shadow (multiple of 256, zero padded)
 int launch_score_dense(const void* q16, int64_t ldq_elems, int64_t nq_pad, const void* x16, int64_t ldx_elems,
                        int64_t xrow0, int64_t nrows_pad, int dpad, float* S, int64_t lds_elems, int64_t nq_valid,
-                       hipStream_t st) {
+                       hipStream_t st, int64_t tile_stride) {
     if (nq_pad <= 0 || nrows_pad <= 0) return LDOT_OK;
     LDOT_REQUIRE(ldq_elems == ldx_elems, LDOT_EINVAL, "index and query shadows must have the same row stride");
-    LDOT_REQUIRE(xrow0 % 16 == 0 && nrows_pad % kRBN == 0 && nq_pad % 256 == 0, LDOT_EINVAL, "unaligned dense chunk");
+    LDOT_REQUIRE(xrow0 % 16 == 0 && nrows_pad % kRBN == 0 && nq_pad % 256 == 0 && tile_stride % 16 == 0 && tile_stride >= kRBN, LDOT_EINVAL,
+                 "unaligned dense chunk");
     using Geo = RingGeom<6>;
     const int tiles_m = (int)((nq_pad + Geo::kBM - 1) / Geo::kBM), tiles_n = (int)(nrows_pad / kRBN);
     const int nunits = tiles_m * tiles_n;
@@ -150,7 +151,7 @@ int launch_score_dense(const void* q16, int64_t ldq_elems, int64_t nq_pad, const
     LDOT_HIP_CHECK(set_max_dynamic_lds_once((const void*)score_dense_kernel, Geo::kLds, attr_set));
     hipLaunchKernelGGL(score_dense_kernel, dim3(nunits < 256 ? nunits : 256), dim3(kRingThreads), Geo::kLds, st,
                        (const char*)q16, ldq_elems * 2, tiles_m, nq_pad, (const char*)x16, xrow0, tiles_n, dpad / kRBK, S,
-                       lds_elems, nq_valid);
+                       lds_elems, nq_valid, tile_stride);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

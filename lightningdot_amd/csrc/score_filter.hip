@@ -165,7 +165,7 @@ template <int VAR>
 __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
     const char* __restrict__ X16, int64_t ldx_b, int64_t row0, int64_t nrows, const char* __restrict__ Q16,
     int64_t ldq_b, int nqb, int nk, const float* __restrict__ tau_g, uint4* __restrict__ pool,
-    int32_t* __restrict__ pool_cnt, int qg_log2) {
+    int32_t* __restrict__ pool_cnt, int qg_log2, ScanOrder so) {
     using Geo = RingGeom<6>;   // 384-row A slab + 256-row B slab per stage, 5 direct-to-LDS pieces per wave and slab
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -194,9 +194,15 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
     const int st_col = ((lane & 3) ^ ((lane >> 3) & 3)) << 4;
     const int vo = wave * 16 * (int)ldx_b + (lane >> 2) * 64 + st_col;
     const int jstep = 8 * 16 * (int)ldx_b;
-    int l_q = g0, l_t = t0, l_k = 0;
+    // Row tile t of the launch sits at physical tile p(t) = ((so.base + t) * so.mul) mod so.mod of the panel that starts at row0
+    // (kernels.h: ScanOrder).  Sequential scan: mul = 1, mod = 2^30, p(t) = t.  Scrambled scan (api.hip): the launch covers tiles
+    // [base, base + ntiles) of a pseudo-random order of ALL row tiles of the index, so that the rows seen so far are a fair sample of
+    // the index whatever order it is stored in.  Both cursors carry p along with t: t advances by nslices (p by da = nslices * mul mod
+    // m) and wraps at ntiles (p by dn = ntiles * mul mod m) — two scalar additions per unit.
+    const int p0 = (int)(((int64_t)(so.base + t0) * so.mul) % so.mod);
+    int l_q = g0, l_t = t0, l_p = p0, l_k = 0;
     RingSrc sa, sb;
-    sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)l_t * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
+    sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)l_p * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
     sb.rsrc = ring_make_rsrc_n(Q16 + (int64_t)(qsub + l_q * qg) * kRBN * ldq_b, kRBN * ldq_b);
     int64_t issued = 0;
     // one slab = kLoads pieces per wave (3 of the row panel, 2 of the query panel); issue() sends them into the stage of slab
@@ -217,14 +223,18 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
             if (++l_k == nk) {   // next unit of this stream
                 l_k = 0;
                 l_t += nslices;
+                l_p += so.da;
+                if (l_p >= so.mod) l_p -= so.mod;
                 if (l_t >= ntiles) {
                     do {
                         l_t -= ntiles;
+                        l_p -= so.dn;
+                        if (l_p < 0) l_p += so.mod;
                         ++l_q;
                     } while (l_t >= ntiles);
                     sb.rsrc = ring_make_rsrc_n(Q16 + (int64_t)(qsub + l_q * qg) * kRBN * ldq_b, kRBN * ldq_b);
                 }
-                sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)l_t * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
+                sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)l_p * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
             }
         }
     };
@@ -324,7 +334,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
         pbase_u = (uint32_t)(((int64_t)(qsub + g * qg) * kRBN + wn * 128) * kPoolCap * kPoolPlanes * nsubs + slice * kPoolSubsPerSlice + wm);
         curp[0] = curp[1] = 0;
     };
-    int c_q = g0, c_t = t0, cur_q = g0;
+    int c_q = g0, c_t = t0, c_p = p0, cur_q = g0;
     setup_group(c_q);
     slab(M1{});
 #pragma unroll 1
@@ -333,11 +343,15 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
         for (int kk = 1; kk + 1 < nk; ++kk) slab(M0{});
         slab(M2{});    // (nk >= 2: the row stride is a multiple of 64 elements)
         // tile jt is complete in acc
-        const int64_t trow = row0 + (int64_t)c_t * Geo::kBM;
+        const int64_t trow = row0 + (int64_t)c_p * Geo::kBM;
         const int32_t row_w = (int32_t)trow + wm * 96;    // (uniform) first row of the wave's block of the tile
         c_t += nslices;
+        c_p += so.da;
+        if (c_p >= so.mod) c_p -= so.mod;
         while (c_t >= ntiles) {
             c_t -= ntiles;
+            c_p -= so.dn;
+            if (c_p < 0) c_p += so.mod;
             ++c_q;
         }
         const bool more = jt + 1 < ntile_total;
@@ -395,9 +409,26 @@ int fused_query_group(int64_t nq_pad) {
     return nqb >= 8 ? 8 : nqb >= 4 ? 4 : nqb >= 2 ? 2 : 1;
 }
 
+// mul coprime to mod, close to mod / golden ratio: consecutive tiles of the scan order land far apart
+int scan_order_multiplier(int64_t mod) {
+    if (mod <= 2) return 1;
+    auto gcd = [](int64_t a, int64_t b) {
+        while (b) {
+            const int64_t t = a % b;
+            a = b;
+            b = t;
+        }
+        return a;
+    };
+    int64_t a = (int64_t)((double)mod * 0.6180339887498949);
+    if (a < 1) a = 1;
+    while (gcd(a, mod) != 1) ++a;
+    return (int)(a % mod);
+}
+
 int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_t nrows, const void* q16,
                         int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, uint4* pool, int32_t* pool_cnt,
-                        hipStream_t st) {
+                        hipStream_t st, int64_t scramble_tiles, int64_t scramble_base) {
     if (nrows <= 0 || nq_pad <= 0) return LDOT_OK;
     LDOT_REQUIRE(ldx_elems == ldq_elems, LDOT_EINVAL, "index and query shadows must have the same row stride");
     auto rk = score_filter_t16_kernel<0>;
@@ -421,9 +452,29 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
 #endif
     const int qg = fused_query_group(nq_pad);
     const int qg_log2 = qg == 8 ? 3 : qg == 4 ? 2 : qg == 2 ? 1 : 0;
+    // sequential: tile t of the launch = tile t of [row0, row0 + nrows); scrambled (scramble_tiles = the row tiles of the whole
+    // index, row0 = 0): tile t of the launch = tile ((scramble_base + t) * mul) mod scramble_tiles of the index
+    const int64_t ntiles = (nrows + RingGeom<6>::kBM - 1) / RingGeom<6>::kBM, nslices = 256 / qg;
+    ScanOrder so;
+    if (scramble_tiles > 0) {
+        LDOT_REQUIRE(row0 == 0 && scramble_tiles < ((int64_t)1 << 30) && scramble_base + ntiles <= scramble_tiles, LDOT_EINVAL,
+                     "bad scrambled launch");
+        so.mul = scan_order_multiplier(scramble_tiles);
+        so.mod = (int)scramble_tiles;
+        so.base = (int)scramble_base;
+        so.da = (int)((nslices * (int64_t)so.mul) % scramble_tiles);
+        so.dn = (int)((ntiles * (int64_t)so.mul) % scramble_tiles);
+    } else {
+        LDOT_REQUIRE(ntiles + 256 < ((int64_t)1 << 30), LDOT_EINVAL, "too many rows for one launch");
+        so.mul = 1;
+        so.mod = 1 << 30;
+        so.base = 0;
+        so.da = (int)nslices;
+        so.dn = (int)ntiles;
+    }
     hipLaunchKernelGGL(rk, dim3(256), dim3(kRingThreads), RingGeom<6>::kLds, st, (const char*)x16, ldx_elems * 2, row0,
                        nrows, (const char*)q16, ldq_elems * 2, (int)(nq_pad / kRBN), dpad / kRBK, tau, pool, pool_cnt,
-                       qg_log2);
+                       qg_log2, so);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

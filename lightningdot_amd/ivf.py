@@ -105,7 +105,8 @@ class DenseIVFFlatIndexer(DenseIndexer):
         self.d = vector_sz
         self.index = FlatIPIndex(vector_sz)              # the rows, sorted by list
         # (cluster-sorted rows are the order the optimistic thresholds of the exact scan must not assume away: a query's best rows
-        # sit together, often early — the scan would flag and redo most queries; the library also backs off by itself)
+        # sit together, often early — the scan would flag and redo most queries; the library also backs off by itself.  The scrambled
+        # scan order does not help here: it permutes 384-row tiles, and a list of ~250 rows IS a tile)
         self.index.set_option(L.OPT_OPTIMISTIC, 0)
         self.nlist, self.nprobe = nlist, nprobe
         self.train_iters, self.train_rows_per_list, self.seed = train_iters, train_rows_per_list, seed

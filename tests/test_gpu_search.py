@@ -201,8 +201,9 @@ def test_optimistic_thresholds_are_verified_and_front_loaded_rows_are_redone(L):
     s, l = ix.search(q, 100)
     st = ix.last_stats()
     assert 256 <= st['overflowed_queries'] < 300, st        # the front-loaded queries failed the check and were searched again
-    # an index whose searches keep failing the check stops trying for a while (16 searches, then 32, ...): the next search runs on
-    # guaranteed thresholds, flags nothing and returns the same lists
+    # an index whose search fails the check for many queries switches to the scrambled scan order (LDOT_OPT_SCAN_ORDER, auto): the next
+    # search sees the front-loaded rows spread over the scan like everybody else's, flags nothing and returns the same lists
+    # (an index that keeps failing even then stops trying for a while: 16 searches on guaranteed thresholds, then 32, ...)
     sb, lb = ix.search(q, 100)
     assert ix.last_stats()['overflowed_queries'] == 0
     np.testing.assert_array_equal(lb, l)
@@ -233,6 +234,54 @@ def test_optimistic_thresholds_are_verified_and_front_loaded_rows_are_redone(L):
     uniq[:, 1:] &= s[:, 1:] != s[:, :-1]
     uniq[:, :-1] &= s[:, :-1] != s[:, 1:]
     np.testing.assert_array_equal(perm[l2][uniq], l[uniq])
+
+
+def test_scrambled_scan_order_on_cluster_sorted_rows(L):
+    """LDOT_OPT_SCAN_ORDER.  Rows stored SORTED BY CLUSTER are not a fair sample of the index in storage order: a query's best rows
+    arrive together, its optimistic thresholds aim too high or too low and candidate pools overflow.  The scrambled scan (row tiles of the
+    whole index in a pseudo-random order + a warm-up on a spread sample) makes the scan order independent of the storage order: nothing
+    is flagged, far fewer records are admitted, and the lists equal those of the storage-order scan and of the dense path bit for bit.
+    Default (auto): storage order until one query in a thousand of a search fails the check, scrambled from then on."""
+    rng = np.random.default_rng(5)
+    n, d, nq, k = 160000, 64, 600, 50
+    cent = rng.standard_normal((40, d)).astype(np.float32)
+    assign = np.sort(rng.integers(0, 40, n))                       # 40 contiguous clusters of ~4000 rows
+    x = (cent[assign] + 0.5 * rng.standard_normal((n, d))).astype(np.float32)
+    q = (x[rng.integers(0, n, nq)] + 0.3 * rng.standard_normal((nq, d))).astype(np.float32)
+    ref = _index(x, mode=L.MODE_DENSE)
+    sd, ld = ref.search(q, k)
+    seq = _index(x, mode=L.MODE_FUSED, scan_order=1)
+    s1, l1 = seq.search(q, k)
+    st1 = seq.last_stats()
+    scr = _index(x, mode=L.MODE_FUSED, scan_order=2)
+    s2, l2 = scr.search(q, k)
+    st2 = scr.last_stats()
+    for s_, l_ in ((s1, l1), (s2, l2)):
+        np.testing.assert_array_equal(l_, ld)
+        np.testing.assert_array_equal(s_, sd)
+    assert_topk_matches(q, x, s2, l2, k)
+    assert st1['overflowed_queries'] > nq // 64, st1              # storage order: the check fails for many queries
+    assert st2['overflowed_queries'] == 0, st2                    # scrambled order: for none
+    assert st2['fused_candidates'] < 0.5 * st1['fused_candidates'], (st1, st2)
+    assert st2['fused_pairs'] >= nq * n                           # every row went through the filter (the sample's rows again)
+    auto = _index(x, mode=L.MODE_FUSED)
+    sa, la = auto.search(q, k)
+    assert auto.last_stats()['overflowed_queries'] > nq // 64
+    sb, lb = auto.search(q, k)                                     # ... which switched the index to the scrambled order
+    stb = auto.last_stats()
+    assert stb['overflowed_queries'] == 0 and stb['fused_candidates'] == st2['fused_candidates'], stb
+    for s_, l_ in ((sa, la), (sb, lb)):
+        np.testing.assert_array_equal(l_, ld)
+        np.testing.assert_array_equal(s_, sd)
+    # rows in random order: both orders flag nothing and return the same lists
+    perm = rng.permutation(n)
+    a = _index(x[perm], mode=L.MODE_FUSED, scan_order=1)
+    b = _index(x[perm], mode=L.MODE_FUSED, scan_order=2)
+    sa, la = a.search(q, k)
+    sb, lb = b.search(q, k)
+    np.testing.assert_array_equal(la, lb)
+    np.testing.assert_array_equal(sa, sb)
+    assert a.last_stats()['overflowed_queries'] == 0 and b.last_stats()['overflowed_queries'] == 0
 
 
 def test_no_rescore_reports_bf16_input_scores(L):
