@@ -42,6 +42,7 @@ for it in range(cases):
     try:
         ix = FlatIPIndex(d, normalize=normalize)
         ix.set_option(L.OPT_MODE, mode)
+        if rng.integers(0, 3) == 0: ix.set_option(L.OPT_SCAN_ORDER, 2)   # scrambled tile order (large batches of the fused scan)
         parts = int(rng.integers(1, 4))
         cuts = sorted(set([0, n] + [int(v) for v in rng.integers(0, n + 1, parts - 1)]))
         for a, b in zip(cuts[:-1], cuts[1:]):

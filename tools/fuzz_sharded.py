@@ -36,13 +36,15 @@ for it in range(cases):
         if order == 3: a = torch.sort(a).values
         x = c[a] + 0.3 * x
     q = x[torch.randint(0, n, (nq,), device='cuda', generator=g)] + 0.5 * torch.randn(nq, d, device='cuda', generator=g)
-    desc = f'G={G} sizes={sizes} nq={nq} d={d} k={k} order={order}'
+    scan = int(rng.choice([0, 0, 2]))   # LDOT_OPT_SCAN_ORDER of the shards: auto, or the scrambled tile order from the first search on
+    desc = f'G={G} sizes={sizes} nq={nq} d={d} k={k} order={order} scan={scan}'
     try:
         whole = FlatIPIndex(d); whole.add(x)
         es, el = whole.search_tensors(q, k)
         shards, off = [], [0]
         for sz in sizes:
             ix = FlatIPIndex(d)
+            if scan: ix.set_option(L.OPT_SCAN_ORDER, scan)
             if sz: ix.add(x[off[-1]:off[-1] + sz])
             shards.append(ix); off.append(off[-1] + sz)
 
