@@ -327,7 +327,7 @@ class ShardedFlatIndexer:
                 self._all_reduce_max(stat)
                 tau = ix.search_scan(stat)
                 self._all_reduce_max(tau)
-            elif self.world > 1 and q_all.is_cuda:
+            elif q_all.is_cuda:   # (also with ONE rank: the same calls and collectives, which is how RCCL gets exercised on a one-GPU box)
                 stat = ix.search_begin_shard(q_all, k, self.world, self.ntotal if pooled else 0, share=self._share())
                 self._all_reduce_max(stat)
                 tau, count, kp = ix.shard_floor(stat)

@@ -51,3 +51,13 @@ def test_serving_line_reports_an_hbm_roofline():
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and 0.0 < r['frac'] < 1.0
     assert d['config']['workload'] and d['ms_per_step'] > 0
+
+
+def test_sharded_path_on_rccl_with_one_rank():
+    """`--force-sharded` at world size 1: ShardedFlatIndexer on the nccl (= RCCL) backend — all-gather of the queries, all-reduce(MAX) of
+    the shard statistics, the blocked all-to-all of the partial lists, the merge into pinned host buffers — with the one rank a GPU box
+    offers.  (More ranks: gloo tests on one GPU, tests/test_gpu_sharded.py; the driver's multi-GPU runs.)"""
+    d = _run('--rows', '131072', '--queries', '1024', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-secondary',
+             '--force-sharded', '--backend', 'nccl')
+    assert d['n_gpus'] == 1 and d['ranks_seen'] == 1 and d['recall@1'] == 1.0 and d['results_sorted'] is True
+    assert d['overflowed_queries'] == 0 and d['roofline']['kernel_ms_per_step'] <= d['ms_per_step']
