@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Byte offsets beyond 2^31 / 2^32: an index whose bf16 shadow (rows x 1536 B) and fp32 master (rows x 3072 B) are several GiB, searched
+through every regime (one query: narrow search; 64 queries; 300 and 3000 queries: fused scan on optimistic thresholds, sequential and
+scrambled tile order; dense mode on a few queries) and compared with an fp64 brute-force scan on the GPU.
+usage: tools/big_index_check.py [rows = 3000000] [d = 768]"""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lightningdot_amd import _lib as L
+from lightningdot_amd.indexer import FlatIPIndex
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 3_000_000
+D = int(sys.argv[2]) if len(sys.argv) > 2 else 768
+K = 100
+g = torch.Generator(device='cuda').manual_seed(3)
+ix = FlatIPIndex(D)
+chunk = 500_000
+rows = []
+for r0 in range(0, N, chunk):
+    x = torch.randn(min(chunk, N - r0), D, device='cuda', generator=g)
+    ix.add(x)
+    rows.append(x)
+X = torch.cat(rows, 0)
+del rows
+assert ix.ntotal == N
+print(f'{N} x {D}: bf16 shadow {N * D * 2 / 2**30:.1f} GiB, fp32 master {N * D * 4 / 2**30:.1f} GiB', flush=True)
+# planted queries near rows spread over the whole index (the last rows included)
+gt = torch.linspace(0, N - 1, 3000, device='cuda').long()
+Q = X[gt] + 0.5 * torch.randn(3000, D, device='cuda', generator=g)
+
+
+def truth(q):
+    best_s, best_l = None, None
+    for r0 in range(0, N, 250_000):
+        s = q.double() @ X[r0:r0 + 250_000].double().T
+        ts, tl = s.topk(K, dim=1)
+        tl = tl + r0
+        if best_s is None:
+            best_s, best_l = ts, tl
+        else:
+            cs, cl = torch.cat([best_s, ts], 1), torch.cat([best_l, tl], 1)
+            o = cs.topk(K, dim=1).indices
+            best_s, best_l = torch.gather(cs, 1, o), torch.gather(cl, 1, o)
+    return best_s, best_l
+
+
+bad = 0
+ts_all, tl_all = truth(Q[:300])
+for name, nq, opts in (('1 query (narrow)', 1, {}), ('64 queries', 64, {}), ('300 queries (fused)', 300, {}),
+                       ('300 queries, scrambled tile order', 300, {L.OPT_SCAN_ORDER: 2}),
+                       ('3000 queries (fused)', 3000, {}), ('8 queries, dense mode', 8, {L.OPT_MODE: L.MODE_DENSE})):
+    for o, v in opts.items():
+        ix.set_option(o, v)
+    t0 = time.perf_counter()
+    s, l = ix.search_tensors(Q[:nq], K)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for o in opts:
+        ix.set_option(o, 1 if o == L.OPT_SCAN_ORDER else L.MODE_AUTO)
+    n = min(nq, 300)
+    rank1 = bool((l[:, 0] == gt[:nq]).all())
+    # the same rows as the fp64 scan, up to the order of rows whose fp64 scores differ by less than the fp32 rounding of a 768-term sum:
+    # every reported row's fp64 score must reach the true k-th best score, reported scores must be the rows' true scores
+    mine64 = torch.stack([(Q[i].double() * X[l[i]].double()).sum(1) for i in range(n)], 0)
+    tol = 1e-6 * float(ts_all.abs().max()) * 10
+    same_rows = bool((mine64 >= ts_all[:n, -1:] - tol).all()) and bool(((mine64 - ts_all[:n]).abs() < tol).all())
+    swaps = int((l[:n] != tl_all[:n]).sum())
+    missing = sum(len(set(tl_all[i].tolist()) - set(l[i].tolist())) for i in range(n))
+    dscore = float((s[:n].double() - mine64).abs().max())
+    st = ix.last_stats()
+    ok = rank1 and same_rows and dscore < 2e-3 and st['overflowed_queries'] == 0
+    bad += 0 if ok else 1
+    print(f'{"ok  " if ok else "FAIL"} {name}: {dt * 1e3:.2f} ms  rank-1 = planted row: {rank1}  top-{K} == fp64 truth up to near-ties (first {n}): {same_rows} ({swaps} positions differ, {missing} rows of the truth missing)  '
+          f'max |dscore| {dscore:.2e}  stats {st}', flush=True)
+sys.exit(1 if bad else 0)
