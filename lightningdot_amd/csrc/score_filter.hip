@@ -406,7 +406,23 @@ int fused_query_group(int64_t nq_pad) {
     }
     if (force == 1 || force == 2 || force == 4 || force == 8) return force;
 #endif
-    return nqb >= 8 ? 8 : nqb >= 4 ? 4 : nqb >= 2 ? 2 : 1;
+    // Every XCD works on qg query blocks at a time, so a batch occupies ceil(nqb / qg) * qg block slots: 12 blocks (3000 queries) in
+    // groups of 8 leave a quarter of the workgroups idle in the second group, in groups of 4 none.  Smaller groups cost a little
+    // themselves (each row tile is shared by fewer workgroups of the XCD: more HBM traffic; more row slices: more sub-pools for the
+    // pool select to walk): 3 / 8.5 / 22 % of a search for 4 / 2 / 1 (tools/qg_penalty.py at 8 and 16 blocks, where every width divides the
+    // batch: profiles/r04_qg_penalty.txt).
+    int best = 1;
+    double best_cost = 1e30;
+    for (int qg = 8; qg >= 1; qg >>= 1) {
+        if (qg > nqb && qg > 1) continue;
+        const double slots = (double)((nqb + qg - 1) / qg * qg);
+        const double cost = slots * (qg == 8 ? 1.0 : qg == 4 ? 1.03 : qg == 2 ? 1.085 : 1.22);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = qg;
+        }
+    }
+    return best;
 }
 
 // mul coprime to mod, close to mod / golden ratio: consecutive tiles of the scan order land far apart
