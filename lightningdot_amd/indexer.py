@@ -14,7 +14,7 @@ L2 variant.  There is no CPU fallback: constructing an index without the HIP lib
 import ctypes
 import logging
 import pickle
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import numpy as np
 
@@ -384,12 +384,24 @@ class DenseIndexer(object):
 class DenseFlatIndexer(DenseIndexer):
     """faiss_indexers.py:63-87"""
 
-    def __init__(self, vector_sz: int, buffer_size: int = 50000, normalize: bool = False):
+    def __init__(self, vector_sz: int, buffer_size: int = 50000, normalize: bool = False, shuffle_seed: Optional[int] = None):
+        """``shuffle_seed`` (not in the reference): the rows of every index_data / index_tensor call are stored in a pseudo-random
+        order, together with their ids — invisible from outside (search_knn reports external ids; only the order of EQUAL scores
+        changes) and free, since the id list is kept next to the rows anyway.  For data that arrives sorted in short runs of similar
+        rows (by class, by k-means list): the scan's thresholds and candidate pools assume that the rows seen so far are a fair sample
+        of the index, long runs are handled by the library's scrambled tile order (LDOT_OPT_SCAN_ORDER), runs about as long as a
+        384-row tile only by a row-granular order like this one."""
         super(DenseFlatIndexer, self).__init__(buffer_size=buffer_size)
         self.index = FlatIPIndex(vector_sz, normalize=normalize)
+        self.shuffle_seed = shuffle_seed
+
+    def _permutation(self, n: int):
+        return np.random.default_rng([int(self.shuffle_seed), len(self.index_id_to_db_id)]).permutation(n)
 
     def index_data(self, data: List[Tuple[object, np.array]]):
         n = len(data)
+        if self.shuffle_seed is not None and n > 1:
+            data = [data[i] for i in self._permutation(n)]
         # same chunking as the reference (:72-77); vectors may be numpy rows or (device) tensors
         for i in range(0, n, self.buffer_size):
             chunk = data[i:i + self.buffer_size]
@@ -408,7 +420,16 @@ class DenseFlatIndexer(DenseIndexer):
         """Device path: ids + one [n, d] tensor, no per-row Python objects."""
         if len(db_ids) != vectors.shape[0]:
             raise ValueError('ids / vectors length mismatch')
-        self._update_id_mapping(list(db_ids))
+        db_ids = list(db_ids)
+        if self.shuffle_seed is not None and len(db_ids) > 1:
+            perm = self._permutation(len(db_ids))
+            db_ids = [db_ids[i] for i in perm]
+            if _is_tensor(vectors):
+                import torch
+                vectors = vectors[torch.as_tensor(perm, device=vectors.device)]
+            else:
+                vectors = np.asarray(vectors)[perm]
+        self._update_id_mapping(db_ids)
         self.index.add(vectors)
 
     def search_knn(self, query_vectors: np.array, top_docs: int) -> List[Tuple[List[object], List[float]]]:

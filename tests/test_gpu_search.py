@@ -284,6 +284,45 @@ def test_scrambled_scan_order_on_cluster_sorted_rows(L):
     assert a.last_stats()['overflowed_queries'] == 0 and b.last_stats()['overflowed_queries'] == 0
 
 
+def test_rows_sorted_in_short_runs_and_the_row_shuffle_of_the_indexer(L):
+    """Rows sorted by a fine clustering (runs of ~250 similar rows: a run IS a 384-row tile) keep a query's whole top k' in one or two
+    tiles whatever the tile order: the optimistic check fails in both scan orders and the index ends on guaranteed thresholds — exact,
+    but with flagged queries.  DenseFlatIndexer(shuffle_seed=) stores the rows (and their ids) in a pseudo-random order: nothing is
+    flagged from the first search on, and search_knn returns the same external ids and scores."""
+    from lightningdot_amd.indexer import DenseFlatIndexer
+    rng = np.random.default_rng(9)
+    n, d, nq, k = 200000, 64, 600, 50
+    cent = rng.standard_normal((800, d)).astype(np.float32)
+    assign = np.sort(rng.integers(0, 800, n))                      # 800 contiguous clusters of ~250 rows
+    x = (cent[assign] + 0.5 * rng.standard_normal((n, d))).astype(np.float32)
+    q = (x[rng.integers(0, n, nq)] + 0.3 * rng.standard_normal((nq, d))).astype(np.float32)
+    ids = [f'row{i}' for i in range(n)]
+    plain = DenseFlatIndexer(d)
+    plain.index.set_option(L.OPT_MODE, L.MODE_FUSED)
+    plain.index_tensor(ids, x)
+    res_plain = plain.search_knn(q, k)
+    assert plain.index.last_stats()['overflowed_queries'] > 0      # storage order: flagged queries (searched again: still exact)
+    shuf = DenseFlatIndexer(d, shuffle_seed=3)
+    shuf.index.set_option(L.OPT_MODE, L.MODE_FUSED)
+    shuf.index_tensor(ids, x)
+    assert shuf.index_id_to_db_id != ids and sorted(shuf.index_id_to_db_id) == sorted(ids)
+    res_shuf = shuf.search_knn(q, k)
+    assert shuf.index.last_stats()['overflowed_queries'] == 0      # a fair order from the first search on
+    for (ia, sa), (ib, sb) in zip(res_plain, res_shuf):
+        np.testing.assert_array_equal(sa, sb)                      # the same fp32 scores
+        uniq = np.ones(k, dtype=bool)
+        uniq[1:] &= sa[1:] != sa[:-1]
+        uniq[:-1] &= sa[:-1] != sa[1:]
+        assert [a for a, u in zip(ia, uniq) if u] == [b for b, u in zip(ib, uniq) if u]   # the same ids wherever a score is unique
+    # index_data (host tuples) shuffles too, with the ids
+    small = DenseFlatIndexer(d, shuffle_seed=3)
+    small.index_data([(ids[i], x[i]) for i in range(3000)])
+    ref = DenseFlatIndexer(d)
+    ref.index_data([(ids[i], x[i]) for i in range(3000)])
+    assert small.index_id_to_db_id != ref.index_id_to_db_id
+    assert [r[0][0] for r in small.search_knn(q[:20], 1)] == [r[0][0] for r in ref.search_knn(q[:20], 1)]
+
+
 def test_no_rescore_reports_bf16_input_scores(L):
     rng = np.random.default_rng(12)
     x = rng.standard_normal((4000, 768)).astype(np.float32)
