@@ -198,3 +198,56 @@ def test_sharded_search_four_ranks_fused_path_baseline_shapes(tmp_path):
             assert all(a < b < c_ and la <= lb for a, b, c_, la, lb, lc in cand), cand
         del ix
         torch.cuda.empty_cache()
+
+
+def test_shard_entry_points_contract_in_one_process():
+    """ldot_index_search_begin_shard / ldot_index_shard_floor without collectives: one shard of one (its statistics are the search's own:
+    level -inf, floor = its k'-th best, every count = k', _finish(floor) = the plain search), two shards played in turn with pooled
+    statistics, and the argument checks of the C entry points."""
+    import ctypes
+    import torch
+    from lightningdot_amd import _lib as L
+    from lightningdot_amd.indexer import FlatIPIndex
+    L.require_gpu()
+    g = torch.Generator(device='cuda').manual_seed(4)
+    x = torch.randn(90000, 128, device='cuda', generator=g)
+    q = torch.randn(700, 128, device='cuda', generator=g)
+    k = 20
+    whole = FlatIPIndex(128)
+    whole.add(x)
+    es, el = whole.search_tensors(q, k)
+    # one shard of one
+    stat = whole.search_begin_shard(q, k, 1, 0)
+    assert stat.shape == (3, 700) and bool((stat[2] == float('-inf')).all()) and bool((stat[1] == -stat[0]).all())
+    floor, count, kp = whole.shard_floor(stat)
+    assert kp >= k and bool((floor == stat[0]).all()) and bool((count == kp).all())
+    s, l = whole.search_finish(floor)
+    assert torch.equal(s, es) and torch.equal(l, el)
+    # two shards, pooled statistics, played in turn; shares in proportion to the rows
+    a, b = FlatIPIndex(128), FlatIPIndex(128)
+    a.add(x[:50000])
+    b.add(x[50000:])
+    st = torch.maximum(a.search_begin_shard(q, k, 2, 90000, share=5 / 9), b.search_begin_shard(q, k, 2, 90000, share=4 / 9))
+    assert bool(torch.isfinite(st[2]).all())                      # both shards scanned on pooled statistics and published their levels
+    fa, ca, kp = a.shard_floor(st)
+    fb, cb, _ = b.shard_floor(st)
+    assert torch.equal(fa, fb) and bool((ca + cb >= kp).all())     # every query proven
+    sa, la = a.search_finish(fa)
+    sb, lb = b.search_finish(fb)
+    S = torch.cat([sa, sb], 1)
+    Lb = torch.cat([la, torch.where(lb >= 0, lb + 50000, lb)], 1)
+    S = torch.where(Lb >= 0, S, torch.full_like(S, float('-inf')))
+    o = torch.sort(S, dim=1, descending=True, stable=True).indices[:, :k]
+    assert torch.equal(torch.gather(S, 1, o), es) and torch.equal(torch.gather(Lb, 1, o), el)
+    # argument checks
+    lib = L.load_library()
+    buf = torch.empty(3 * 700, dtype=torch.float32, device='cuda')
+    qp, bp = ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(buf.data_ptr())
+    for parts, share, total in ((0, 0.5, 0), (2, 1.5, 0), (2, -0.1, 0), (2, 0.5, -1)):
+        rc = lib.ldot_index_search_begin_shard(whole._h, qp, 700, L.F32, L.DEVICE, 0, k, parts, share, total, bp, None)
+        assert rc == -1, (parts, share, total, rc)
+    assert lib.ldot_index_search_begin_shard(whole._h, qp, 700, L.F32, L.DEVICE, 0, k, 2, 0.5, 0, None, None) == -1   # NULL statistics buffer
+    assert lib.ldot_index_shard_floor(None, bp, bp, bp, None, None) == -1
+    fresh = FlatIPIndex(128)
+    with pytest.raises(L.LdotError):
+        fresh.shard_floor(buf.view(3, 700))                       # no pending search_begin_shard
