@@ -233,8 +233,11 @@ def _calc_loss(args, loss_function, local_q_vector, local_ctx_vectors, local_cap
                                              device=local_ctx_vectors.device))
         offset = sum(int(c.item()) for c in counts[:rank])
         positive_idx_per_question = [v + offset for v in local_positive_idxs]
+        # the collate hands over a FLAT list (dvl/data/itm.py:284: list(range(bs, n))); the reference's dead branch iterates nested
+        # per-question lists (dvl/utils.py:147,152, the DPR layout) and would raise on it — both are re-based here
         hard_negatives_per_question = (None if local_hard_negatives_idxs is None else
-                                       [[v + offset for v in l] for l in local_hard_negatives_idxs])
+                                       [[v + offset for v in l] if isinstance(l, (list, tuple)) else l + offset
+                                        for l in local_hard_negatives_idxs])
     else:
         global_q_vector = local_q_vector
         global_ctxs_vector = local_ctx_vectors
@@ -248,10 +251,12 @@ def _calc_loss(args, loss_function, local_q_vector, local_ctx_vectors, local_cap
     return loss, is_correct, scores
 
 
-def train_step_loss(args, txt_vector: T, img_vectors: T, caption_vectors: Optional[T], batch: dict, experiment=None):
+def train_step_loss(args, txt_vector: T, img_vectors: T, caption_vectors: Optional[T], batch: dict, experiment=None,
+                    loss_function=None):
     """The loss composition of one fine-tuning step — train_itm.py:195-222 (both directions, averaged).
-    Returns (loss_nce, is_correct, scores, (loss_nce_txt, loss_nce_img))."""
-    loss_function = BiEncoderNllLoss()
+    Returns (loss_nce, is_correct, scores, (loss_nce_txt, loss_nce_img)).  ``loss_function`` (an object with the reference's
+    ``calc``) defaults to the HIP ``BiEncoderNllLoss``, as train_itm.py:193 constructs it."""
+    loss_function = loss_function or BiEncoderNllLoss()
     bs = batch['sample_size']
     if args.num_hard_negatives > 0:
         loss_nce_txt, is_correct_txt, scores_txt = _calc_loss(args, loss_function, img_vectors[:bs], txt_vector,

@@ -124,21 +124,26 @@ class GradientBucketReducer:
 
     def __init__(self, params: Iterable[nn.Parameter], bucket_bytes: int = 64 << 20, reduce_dtype: Optional[torch.dtype] = None,
                  average: bool = True, group=None):
-        self.group, self.average, self.reduce_dtype = group, average, reduce_dtype
+        self.group, self.average, self.reduce_dtype, self.bucket_bytes = group, average, reduce_dtype, bucket_bytes
         self.params = [p for p in params if p.requires_grad]
-        self.buckets = []            # dict(params, offsets, flat, had, pending, fired, handle)
+        self._layout(list(reversed(self.params)))
+        self.armed = False
+        self._relaid = False
+        self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+
+    def _layout(self, ordered):
+        """flat buckets over `ordered` (the order in which backward is expected to produce the gradients)"""
+        self.buckets = []            # dict(params, offsets, flat, flags, pending, fired, handle)
         self.where = {}              # id(param) -> (bucket index, slot)
         cur, size = [], 0
-        for p in reversed(self.params):
+        for p in ordered:
             cur.append(p)
-            size += p.numel() * (torch.empty((), dtype=reduce_dtype or p.dtype).element_size())
-            if size >= bucket_bytes:
+            size += p.numel() * (torch.empty((), dtype=self.reduce_dtype or p.dtype).element_size())
+            if size >= self.bucket_bytes:
                 self._close(cur)
                 cur, size = [], 0
         if cur:
             self._close(cur)
-        self.armed = False
-        self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
 
     def _close(self, plist):
         dt = self.reduce_dtype or plist[0].dtype
@@ -147,8 +152,11 @@ class GradientBucketReducer:
             offs.append(o)
             o += p.numel()
         # payload + one "some rank had a gradient" element per parameter, reduced in the same collective
-        flat = torch.zeros(o + len(plist), dtype=dt, device=plist[0].device)
-        b = dict(params=plist, offsets=offs, n=o, flat=flat, fired=[False] * len(plist), pending=len(plist), handle=None)
+        dev = plist[0].device
+        flat = torch.zeros(o + len(plist), dtype=dt, device=dev)
+        # the flags are staged in pinned host memory so that the hook's copy does not stall the host behind backward
+        flags = torch.zeros(len(plist), dtype=dt, pin_memory=dev.type == 'cuda')
+        b = dict(params=plist, offsets=offs, n=o, flat=flat, flags=flags, fired=[False] * len(plist), pending=len(plist), handle=None)
         for i, p in enumerate(plist):
             self.where[id(p)] = (len(self.buckets), i)
         self.buckets.append(b)
@@ -165,10 +173,17 @@ class GradientBucketReducer:
         dist = _dist()
         while self._next < len(self.buckets) and self.buckets[self._next]['pending'] == 0:
             b = self.buckets[self._next]
-            # the "had a gradient" flags travel behind the payload (one small copy per bucket, not one fill per parameter)
-            b['flat'][b['n']:].copy_(torch.tensor([1.0 if f else 0.0 for f in b['fired']], dtype=b['flat'].dtype))
+            # the "had a gradient" flags travel behind the payload (one small asynchronous copy per bucket, not one fill per parameter)
+            b['flags'].copy_(torch.tensor([1.0 if f else 0.0 for f in b['fired']], dtype=b['flags'].dtype))
+            b['flat'][b['n']:].copy_(b['flags'], non_blocking=True)
             b['handle'] = dist.all_reduce(b['flat'], group=self.group, async_op=True) if dist is not None else None
             self._next += 1
+
+    def _take(self, b, i, p):
+        o, n = b['offsets'][i], p.numel()
+        b['flat'][o:o + n].copy_(p.grad.reshape(-1))
+        b['fired'][i] = True
+        b['pending'] -= 1
 
     def _hook(self, p):
         if not self.armed:
@@ -177,10 +192,7 @@ class GradientBucketReducer:
         b = self.buckets[bi]
         if b['fired'][i]:
             return
-        o, n = b['offsets'][i], p.numel()
-        b['flat'][o:o + n].copy_(p.grad.reshape(-1))
-        b['fired'][i] = True
-        b['pending'] -= 1
+        self._take(b, i, p)
         if b['pending'] == 0:
             self._launch_ready()
 
@@ -190,9 +202,18 @@ class GradientBucketReducer:
             return
         self.armed = False
         dist = _dist()
-        for b in self.buckets:       # parameters whose hook never fired: zeros (and a zero "had" flag) from this rank
+        for b in self.buckets:
+            if b['handle'] is not None:
+                continue             # launched: every slot was filled by a hook
             for i, p in enumerate(b['params']):
-                if not b['fired'][i] and b['handle'] is None:
+                if b['fired'][i]:
+                    continue
+                if p.grad is not None:
+                    # no hook in the armed backward, but a gradient accumulated by the earlier micro-steps (gradient accumulation
+                    # with a parameter the last micro-step did not use): it takes part like every other gradient, exactly as
+                    # allreduce_gradients decides by `p.grad is None`
+                    self._take(b, i, p)
+                else:                # zeros (and a zero "had" flag) from this rank
                     o, n = b['offsets'][i], p.numel()
                     b['flat'][o:o + n].zero_()
             b['pending'] = 0
@@ -201,9 +222,12 @@ class GradientBucketReducer:
         for b in self.buckets:
             if b['handle'] is not None:
                 b['handle'].wait()
-            had = b['flat'][b['n']:].float().tolist()
+        # ONE device -> host read for the flags of all buckets
+        had_all = torch.cat([b['flat'][b['n']:].float() for b in self.buckets]).tolist()
+        k, never = 0, set()
+        for b in self.buckets:
             for i, p in enumerate(b['params']):
-                if had[i] > 0:
+                if had_all[k + i] > 0:
                     o, n = b['offsets'][i], p.numel()
                     g = b['flat'][o:o + n].view_as(p)
                     if p.grad is None:
@@ -211,7 +235,16 @@ class GradientBucketReducer:
                     p.grad.copy_(g)
                     if self.average and ws > 1:
                         p.grad.div_(ws)
-                # (else: no rank produced a gradient: p.grad stays None)
+                else:                # no rank produced a gradient: p.grad stays None
+                    never.add(id(p))
+            k += len(b['params'])
+        if never and not self._relaid:
+            # parameters without a gradient on ANY rank (an unused pooler) sit somewhere in the bucket order and keep their bucket —
+            # and, because buckets launch in order, every later one — from starting during backward.  The flags are reduced values,
+            # identical on every rank, so all ranks move the same parameters behind the last bucket, once.
+            self._relaid = True
+            order = [p for p in reversed(self.params) if id(p) not in never] + [p for p in reversed(self.params) if id(p) in never]
+            self._layout(order)
 
     def remove(self):
         for h in self._handles:

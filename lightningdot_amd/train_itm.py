@@ -34,6 +34,11 @@ def _is_main() -> bool:
     return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
 
 
+def _loss_dtype(t):
+    """the loss path computes in fp32 (bf16 / fp16 tower outputs are widened; float64 towers — CPU tests with an injected loss — pass)"""
+    return t if t is None or t.dtype == torch.float64 else t.float()
+
+
 def _checkpoint_path(args, epoch: int, offset: int = 0, cp_name: Optional[str] = None) -> str:
     """dvl/trainer.py:44-50"""
     if cp_name is None:
@@ -134,8 +139,8 @@ def TRAIN(args, bi_encoder, train_dataset, val_dataloader, val_img2txt: Dict, *,
             dev_type = 'cuda' if device.type == 'cuda' else 'cpu'
             with torch.autocast(dev_type, dtype=torch.bfloat16, enabled=autocast_bf16):
                 txt_vector, img_vectors, caption_vectors = bi_encoder(batch)
-            loss_nce, is_correct, scores, _ = loss_fn(args, txt_vector.float(), img_vectors.float(),
-                                                      caption_vectors.float() if caption_vectors is not None else None, batch)
+            loss_nce, is_correct, scores, _ = loss_fn(args, _loss_dtype(txt_vector), _loss_dtype(img_vectors),
+                                                      _loss_dtype(caption_vectors), batch)
             loss = loss_nce
             if kd_teacher is not None:                                                                           # :224-241
                 with torch.no_grad():

@@ -82,6 +82,111 @@ def _torch_mine(loaders, args, bi_encoder, img2txt, txt2img):
     return hn_txt, hn_img
 
 
+class _TorchNll:
+    """bi_encoder.py:615-656 in plain torch ops behind the reference's `calc` signature (stand-in for the HIP BiEncoderNllLoss)"""
+
+    def calc(self, q, ctx, cap, positive_idx, hard_neg_idx=None, caption_score_weight=0.1, experiment=None, reduction='mean'):
+        import torch.nn.functional as F
+        scores = q @ ctx.T
+        pos = torch.tensor(positive_idx)
+        return F.nll_loss(F.log_softmax(scores, dim=1), pos, reduction=reduction), (scores.argmax(1) == pos).sum(), scores
+
+
+def _global_negatives_loss(args, txt, img, cap, batch):
+    """the product's own composition (loss.train_step_loss -> loss._calc_loss: with args.distributed_world_size > 1 the contexts of
+    all ranks are all-gathered) around the plain-torch calc"""
+    from lightningdot_amd.loss import train_step_loss
+    return train_step_loss(args, txt, img, cap, batch, loss_function=_TorchNll())
+
+
+def _tiny_setup(nh):
+    from lightningdot_amd.data import itm_fast_collate
+    from lightningdot_amd.synthetic import SyntheticItmDataset
+    from lightningdot_amd.towers import BiEncoder, TowerConfig
+    cfg = TowerConfig(vocab_size=29000, hidden_size=32, num_hidden_layers=1, num_attention_heads=2, intermediate_size=64,
+                      max_position_embeddings=32, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+
+    def model(seed):
+        torch.manual_seed(seed)
+        return BiEncoder(types.SimpleNamespace(img_model_type='uniter-base', txt_model_type='bert-base'), project_dim=16,
+                         txt_config=cfg, img_config=cfg).double()
+
+    # float64 throughout: AdamW turns rounding noise on near-zero gradients (the last projection's bias) into steps of the size of
+    # the learning rate, which would drown the comparison in fp32
+    def f64(b):
+        return {k: {kk: (vv.double() if torch.is_tensor(vv) and vv.is_floating_point() else vv) for kk, vv in v.items()}
+                if isinstance(v, dict) else (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in b.items()}
+
+    train_ds = SyntheticItmDataset(12, caps_per_img=2, txt_len=8, num_bb=4, img_dim=2048, num_hard_negatives=nh, seed=1)
+    val_ds = SyntheticItmDataset(6, caps_per_img=2, txt_len=8, num_bb=4, img_dim=2048, seed=2)
+    loader_of = lambda ds: [f64(itm_fast_collate([ds[i] for i in range(b, min(b + 6, len(ds)))])) for b in range(0, len(ds), 6)]
+
+    def train_loader(ds, args, epoch, device):
+        from lightningdot_amd.train_itm import default_train_loader
+        for b in default_train_loader(ds, args, epoch, device):
+            yield f64(b)
+    train_loader.steps_per_epoch = lambda ds, args: len(ds) // (args.train_batch_size * args.distributed_world_size)
+
+    def mining_loaders():
+        saved = (train_ds.neg_imgs, train_ds.neg_txts)
+        train_ds.new_epoch()
+        out = loader_of(train_ds)
+        train_ds.neg_imgs, train_ds.neg_txts = saved
+        return [out]
+    return model, train_ds, val_ds, loader_of(val_ds), mining_loaders, train_loader
+
+
+def _args_global(out_dir, world, bs, nh):
+    return types.SimpleNamespace(output_dir=out_dir, learning_rate=2e-3, num_train_epochs=2, train_batch_size=bs,
+                                 gradient_accumulation_steps=1, max_grad_norm=2.0, num_hard_negatives=nh,
+                                 sample_init_hard_negatives=nh > 0, hard_negatives_sampling='none', save_all_epochs=False, seed=5,
+                                 distributed_world_size=world, caption_score_weight=0.0, log_result_step=100)
+
+
+def _run_global(rank, world, port, out_dir, nh):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from lightningdot_amd.train_itm import TRAIN
+    model, train_ds, val_ds, val_loader, mining_loaders, train_loader = _tiny_setup(nh)
+    m = model(100 + rank)                          # different initial weights per rank: rank 0's are broadcast
+    hist = TRAIN(_args_global(os.path.join(out_dir, 'w'), world, 4, nh), m, train_ds, val_loader, val_ds.img2txts,
+                 train_img2txt=train_ds.img2txts, train_txt2img=train_ds.txt2img, mining_loaders=mining_loaders,
+                 make_train_loader=train_loader, loss_fn=_global_negatives_loss, evaluate=_torch_eval, mine=_torch_mine, device=torch.device('cpu'))
+    flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    others = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(others, flat)
+    assert all(torch.equal(o, others[0]) for o in others)
+    losses = torch.tensor([h['loss'] for h in hist], dtype=torch.float64)     # a rank logs the mean loss of ITS queries: average the ranks
+    dist.all_reduce(losses)
+    if rank == 0:
+        torch.save(dict(flat=flat, loss=(losses / world).tolist()), os.path.join(out_dir, 'world.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('nh', [0, 1])
+def test_train_loop_global_negatives_two_ranks_equal_one_process_on_the_global_batch(tmp_path, nh):
+    """TRAIN at world 2 with the loss hook going through loss._calc_loss's distributed branch (cross-rank in-batch negatives: 2 x 4
+    rows per step) ends with the weights of ONE process training on the global batch of 8 — the same items (rank r takes the r-th
+    slice of 4 of every 8 drawn), the same objective (mean of the ranks' mean losses = the global mean at equal sizes; with hard
+    negatives the gathered context order differs from the single-process one, which the softmax does not see), the same clipping,
+    schedule and re-mining."""
+    sys.path.insert(0, ROOT)
+    from lightningdot_amd.train_itm import TRAIN
+    world = 2
+    mp.spawn(_run_global, args=(world, _free_port(), str(tmp_path), nh), nprocs=world, join=True)
+    got = torch.load(os.path.join(str(tmp_path), 'world.pt'))
+    model, train_ds, val_ds, val_loader, mining_loaders, train_loader = _tiny_setup(nh)
+    m = model(100)
+    hist = TRAIN(_args_global(os.path.join(str(tmp_path), 's'), 1, 8, nh), m, train_ds, val_loader, val_ds.img2txts,
+                 train_img2txt=train_ds.img2txts, train_txt2img=train_ds.txt2img, mining_loaders=mining_loaders,
+                 make_train_loader=train_loader, loss_fn=_global_negatives_loss, evaluate=_torch_eval, mine=_torch_mine, device=torch.device('cpu'))
+    flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    assert np.allclose(got['loss'], [h['loss'] for h in hist], rtol=0, atol=1e-9), (got['loss'], [h['loss'] for h in hist])
+    assert torch.allclose(got['flat'], flat, rtol=0, atol=1e-7), float((got['flat'] - flat).abs().max())
+
+
 def _run(rank, world, port, out_dir, nh):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
@@ -172,9 +277,13 @@ def _run_reducer(rank, world, port):
             self.sometimes = nn.Linear(16, 3)       # used on rank 0 only
             self.c = nn.Linear(16, 2)
 
-        def forward(self, x, use_extra):
+            self.early = nn.Linear(16, 5)           # used by the first micro-steps only, never by the armed (last) one
+
+        def forward(self, x, use_extra, use_early=False):
             h = torch.tanh(self.b(torch.tanh(self.a(x))))
             out = self.c(h).sum()
+            if use_early:
+                out = out + self.early(h).sum()
             return out + self.sometimes(h).sum() if use_extra else out
 
     def fresh():
@@ -184,27 +293,35 @@ def _run_reducer(rank, world, port):
     torch.manual_seed(10 + rank)
     xs = [torch.randn(5, 8) for _ in range(3)]
     # reference: gradients accumulated over 3 micro-steps, exchanged after backward
+    # `early` takes part in micro-step 0 on both ranks and in micro-step 1 on rank 1 only: its hook does not fire in the armed backward,
+    # its accumulated gradient must be exchanged all the same (allreduce_gradients decides by `p.grad is None`)
+    early = lambda i: i == 0 or (i == 1 and rank == 1)
     ref = fresh()
-    for x in xs:
-        ref(x, rank == 0).backward()
+    for i, x in enumerate(xs):
+        ref(x, rank == 0, early(i)).backward()
     allreduce_gradients(ref.parameters())
+    assert ref.early.weight.grad is not None
     for dtype, tol in ((None, 0.0), (torch.bfloat16, 2e-2)):
         net = fresh()
         red = GradientBucketReducer(net.parameters(), bucket_bytes=200, reduce_dtype=dtype)      # several small buckets
         assert len(red.buckets) > 2
-        for i, x in enumerate(xs):
-            if i == len(xs) - 1:
-                red.arm()                          # only the last micro-step's backward exchanges (the accumulated gradients)
-            net(x, rank == 0).backward()
-        red.finish()
-        for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
-            assert (p.grad is None) == (q.grad is None), n
-            if p.grad is not None:
-                if tol == 0.0:
-                    assert torch.equal(p.grad, q.grad), n         # same sums, same order of ranks: bit-identical to the one-pass exchange
-                else:
-                    assert torch.allclose(p.grad, q.grad, rtol=tol, atol=tol), n
-        assert net.unused.weight.grad is None and net.sometimes.weight.grad is not None
+        for step in range(2):                      # the second step runs on the re-laid buckets (never-used parameters moved last)
+            for i, x in enumerate(xs):
+                if i == len(xs) - 1:
+                    red.arm()                      # only the last micro-step's backward exchanges (the accumulated gradients)
+                net(x, rank == 0, early(i)).backward()
+            red.finish()
+            for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+                assert (p.grad is None) == (q.grad is None), n
+                if p.grad is not None:
+                    if tol == 0.0:
+                        assert torch.equal(p.grad, q.grad), n     # same sums, same order of ranks: bit-identical to the one-pass exchange
+                    else:
+                        assert torch.allclose(p.grad, q.grad, rtol=tol, atol=tol), n
+            assert net.unused.weight.grad is None and net.sometimes.weight.grad is not None
+            assert red._relaid and red.buckets[-1]['params'][-1] in (net.unused.weight, net.unused.bias)
+            if step == 0:
+                net.zero_grad(set_to_none=True)
         # every rank holds the same reduced gradients
         flat = torch.cat([p.grad.reshape(-1) for p in net.parameters() if p.grad is not None])
         others = [torch.empty_like(flat) for _ in range(world)]
