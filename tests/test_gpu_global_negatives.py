@@ -110,15 +110,16 @@ def _worker(rank, world, port, sizes, nh, captions, exchange, seed):
     loss, correct, scores = _calc_loss(args, BiEncoderNllLoss(), q, c, cap, list(range(sizes[rank])), None)
     assert tuple(scores.shape) == (sizes[rank], sum(sizes) * (1 + nh)) and scores.dtype == torch.float32
     np.testing.assert_allclose(scores.detach().cpu().numpy(), ref_scores, rtol=0, atol=5e-5)
-    assert abs(float(loss) - float(ref_loss)) < 5e-5 and int(correct) == ref_correct, (float(loss), float(ref_loss), int(correct), ref_correct)
+    assert abs(float(loss.detach()) - float(ref_loss)) < 5e-5 and int(correct) == ref_correct, (float(loss.detach()), float(ref_loss))
     red = None
     if exchange == 'reducer':
         red = GradientBucketReducer(enc.parameters(), bucket_bytes=100 << 10)      # q and c towers in different buckets
         assert len(red.buckets) >= 2
         red.arm()
     loss.backward()
+    # (db_c is exactly zero in exact arithmetic — the rows of softmax - onehot sum to zero —, hence the absolute floor)
     close = lambda got, want, what: np.testing.assert_allclose(got.detach().cpu().numpy(), want, rtol=2e-4,
-                                                               atol=2e-4 * float(np.abs(want).max()), err_msg=what)
+                                                               atol=2e-4 * max(float(np.abs(want).max()), 1e-3), err_msg=what)
     close(q.grad, ref_dq, 'dq')
     close(c.grad, ref_dc, 'dctx (sum over ranks of this rank\'s slice)')
     if captions:
