@@ -368,10 +368,75 @@ def secondary_metrics(dev, flat_main, D, K):
     q1 = qc[:1].contiguous()
     ms_ivf = _time_ms(lambda: ivf.search_knn_tensors(q1, 10, 32, exact_when_cheaper=False), 50)
     ms_exact = _time_ms(lambda: exact.search_knn_tensors(q1, 10), 50)
+    sec['loss_step'] = loss_step_metrics(dev, D)
     sec['ivf_123k'] = {'nlist': int(ivf.nlist), 'nprobe': 32, 'ms_1_query': ms_ivf, 'ms_1_query_exact_flat': ms_exact,
                        'recall@10_vs_exact': rec, 'build_s': build_s,
                        'data': '123 287 rows = 500 overlapping Gaussian clusters (centroid spread 0.2, noise 0.5), 768-d'}
     return sec
+
+
+def loss_step_metrics(dev, D):
+    """The in-batch contrastive loss of ONE fine-tuning step (BASELINE configs[4]: global batch 512; train_itm.py:195-222 = two
+    BiEncoderNllLoss.calc, bi_encoder.py:615-656, averaged) — forward + backward through autograd, fp32, at 512 x 512 (no hard
+    negatives, the reference's fine-tuning configs) and 512 x 1536 (two hard negatives per item): end-to-end microseconds per step as
+    the caller sees them (host + device, no synchronisation inside the loop), the device time of one step (events around a step issued behind a busy
+    stream, so that host gaps do not count), and the plain torch formulation of the reference on the same GPU beside it."""
+    import types
+    import torch.nn.functional as F
+    from lightningdot_amd.loss import train_step_loss
+    out = {}
+    for name, bs, nh in (('512x512', 512, 0), ('512x1536', 512, 2)):
+        n = bs * (1 + nh)
+        g = torch.Generator(device=dev).manual_seed(99)
+        txt = (0.2 * torch.randn(n, D, device=dev, generator=g)).requires_grad_()
+        img = (0.2 * torch.randn(n, D, device=dev, generator=g) + txt.detach() * (torch.arange(n, device=dev) < bs)[:, None]).requires_grad_()
+        args = types.SimpleNamespace(caption_score_weight=0.0, num_hard_negatives=nh)
+        batch = dict(sample_size=bs, pos_ctx_indices=list(range(bs)), neg_ctx_indices=list(range(bs, n)))
+        pos_t = torch.arange(bs, device=dev)
+
+        def ours():
+            loss, _ic, _sc, _ = train_step_loss(args, txt, img, None, batch)
+            loss.backward()
+
+        def ref():        # the reference's formulation (bi_encoder.py:615-656 twice, train_itm.py:195-222) in torch ops
+            def nll(q, c):
+                s = q @ c.t()
+                ls = F.log_softmax(s, dim=1)
+                loss = F.nll_loss(ls, pos_t, reduction='mean')
+                correct = (ls.max(1)[1] == pos_t).sum()
+                return loss, correct, s
+            lt, ct, st = nll(img[:bs], txt)
+            li, ci, si = nll(txt[:bs], img)
+            loss = 0.5 * lt + 0.5 * li
+            _sc = st * 0.5 + si * 0.5
+            loss.backward()
+
+        def device_us(fn):
+            # device time of one step: events around a step issued behind a long-running kernel, so that host gaps do not count
+            fn()
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda._sleep(2_000_000)
+                e0.record()
+                fn()
+                e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) * 1e3)
+            return best
+        txt.grad = img.grad = None
+        us = _time_ms(ours, 200, warm=20) * 1e3
+        us_dev = device_us(ours)
+        txt.grad = img.grad = None
+        us_ref = _time_ms(ref, 200, warm=20) * 1e3
+        us_ref_dev = device_us(ref)
+        txt.grad = img.grad = None
+        out[name] = {'bs': bs, 'contexts': n, 'dim': D, 'end_to_end_us': us, 'device_us': us_dev, 'torch_end_to_end_us': us_ref,
+                     'torch_device_us': us_ref_dev}
+    out['what'] = ('train_step_loss forward + backward (both directions of train_itm.py:195-222), fp32, through autograd; end_to_end = wall '
+                   'clock per step over 200 back-to-back steps, device = stream time of one step issued behind a busy stream')
+    return out
 
 
 PEAK_HBM_GBPS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured with a float4 copy)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDOT_ABI_VERSION 4
+#define LDOT_ABI_VERSION 5
 
 /* status codes */
 #define LDOT_OK 0
@@ -261,6 +261,26 @@ int ldot_inbatch_nll_bwd(const float* q, const float* ctx, const float* cap, flo
                          int64_t n1, int64_t n2, int64_t d, const float* scores, const float* lse,
                          const float* g_row, const float* g_scores, float* ds_work,
                          float* dq, float* dctx, float* dcap, void* stream);
+
+/* The bidirectional loss of ONE fine-tuning step — train_itm.py:195-222: two _calc_loss calls (dvl/utils.py:114-169) on the same
+ * embeddings, img[:bs] against txt and txt[:bs] against img, positives pos[i] for both, averaged:
+ *     S_txt = img[:bs].txt^T   [bs,n]     loss_txt = mean_i NLL(log_softmax(S_txt)_i, pos_i)       (train_itm.py:198-199 / :205-206)
+ *     S_img = txt[:bs].img^T   [bs,n]     loss_img = mean_i NLL(log_softmax(S_img)_i, pos_i)       (:200-202 / :208-210)
+ *     loss_nce = 0.5 loss_txt + 0.5 loss_img (:212),  is_correct = (#correct_txt + #correct_img) / 2 (:211),
+ *     scores_avg = 0.5 S_txt + 0.5 S_img (:222; s_avg may be NULL)
+ * img, txt: [n,d] fp32 device rows (n = bs + bs * num_hard_negatives, the first bs rows are the in-batch items).  S_img[:, :bs] is
+ * the transpose of S_txt[:, :bs]: ONE GEMM tile pass produces both, with row and column softmax statistics in its epilogue (no caption
+ * mixing on this path: callers with caption_score_weight != 0 use ldot_inbatch_nll_fwd twice).
+ * Outputs: s_txt, s_img [bs,n]; lse, row_loss [2][bs] (direction txt, then img); out[6] = {loss_txt, loss_img, loss_nce, is_correct,
+ * #correct_txt, #correct_img}.  Nothing is read back by the host. */
+int ldot_inbatch_nll_bidir_fwd(const float* img, const float* txt, const int32_t* pos, int64_t bs, int64_t n, int64_t d,
+                               float* s_txt, float* s_img, float* s_avg, float* lse, float* row_loss, float* out, void* stream);
+/* Backward of the above.  g_nce, g_txt, g_img: DEVICE scalars (gradients w.r.t. loss_nce / loss_txt / loss_img; NULL = 0), g_avg [bs,n]
+ * (gradient w.r.t. scores_avg — the KD branch of train_itm.py:224-241; NULL = 0).  ds_work: [bs*n + bs*(n-bs)] fp32 scratch.
+ * dimg, dtxt: [n,d] (either may be NULL). */
+int ldot_inbatch_nll_bidir_bwd(const float* img, const float* txt, const int32_t* pos, int64_t bs, int64_t n, int64_t d,
+                               const float* s_txt, const float* s_img, const float* lse, const float* g_nce, const float* g_txt,
+                               const float* g_img, const float* g_avg, float* ds_work, float* dimg, float* dtxt, void* stream);
 
 /* plain score matrix (dot_product_scores, bi_encoder.py:54-68): out[n1,n2] = q.ctx^T, fp32 exact products */
 int ldot_dot_product_scores(const float* q, const float* ctx, int64_t n1, int64_t n2, int64_t d, float* out,

@@ -17,7 +17,7 @@ OPT_MODE, OPT_RESCORE, OPT_CHUNK_ROWS, OPT_MARGIN, OPT_PROFILE, OPT_WARM_ROWS, O
 OPT_OPTIMISTIC = 11
 OPT_SCAN_ORDER = 12
 OPT_VERIFY = 10
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_MARGIN = 1024
 PAD_LABEL = -1
 PAD_SCORE = -3.4028234663852886e+38
@@ -59,6 +59,8 @@ SYMBOLS = {
     'ldot_inbatch_nll_fwd': (_i, [_vp, _vp, _vp, _f, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     'ldot_inbatch_nll_bwd': (_i, [_vp, _vp, _vp, _f, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'ldot_dot_product_scores': (_i, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    'ldot_inbatch_nll_bidir_fwd': (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'ldot_inbatch_nll_bidir_bwd': (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 

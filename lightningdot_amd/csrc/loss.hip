@@ -6,6 +6,7 @@
 // bound, not MFMA bound, so the 1/16-rate fp32 matrix path costs nothing that matters.
 #include <math.h>
 
+#include <algorithm>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -248,11 +249,38 @@ struct DirectChunk {
     }
 };
 
-struct NllFused {   // forward epilogue of the loss (EPI = 1): per (row, column tile) statistics for nll_finish_kernel
+struct NllFused {   // forward epilogue of the loss (EPI >= 1): per (row, column tile) statistics for the finish kernels
     const int32_t* pos;
-    uint4* stat;         // {max, sum exp(s - max), first arg-max column, -} of a row over one column tile
+    uint4* stat;         // {max, sum exp(s - max), first arg-max column, -} of a row over one column tile: stat[m * ldstat + stat_col0 + tile]
     float* spos;         // the positive's score per row
+    int ldstat, stat_col0;
+    int64_t col_off;     // global column of this GEMM's column 0 (arg-max and positive indices are global)
+    // EPI 2 (the bidirectional train step, train_itm.py:195-222): the OTHER direction's score matrix is the transpose of this one over
+    // the first `nshared` columns — S_img[n][m] = S_txt[m][n] — so the tile also leaves its transpose and the COLUMN statistics
+    float* Ct;           // transposed scores, Ct[n * ldct + m]
+    int64_t ldct, nshared;
+    uint4* stat_t;       // stat_t[n * ldstat_t + row tile]
+    int ldstat_t;
+    float* spos_t;       // Ct[n][pos[n]]
 };
+
+// max / first arg-max / sum of exponentials of 32 values held by the 32 lanes of a half wave (idx = the value's global index)
+__device__ __forceinline__ void half_wave_softmax_stats(float v, bool valid, int64_t idx, float& mx, int64_t& am, float& z) {
+    mx = valid ? v : -INFINITY;
+    am = valid ? idx : 0x7fffffffffffffffll;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(mx, o);
+        const int64_t a2 = __shfl_xor(am, o);
+        if (m2 > mx || (m2 == mx && a2 < am)) {
+            mx = m2;
+            am = a2;
+        }
+    }
+    z = valid ? expf(v - mx) : 0.f;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) z += __shfl_xor(z, o);
+}
 
 // EPI 0: C = alpha * acc (+ C).  EPI 1 (forward of the loss): C = mix, + the softmax statistics of the tile's rows over its 32 columns.
 template <bool AKF, bool BKF, bool MIX, int EPI, int KS>
@@ -338,30 +366,39 @@ __global__ __launch_bounds__(64 * KS) void sgemm_direct_kernel(const float* __re
     if (EPI == 0) return;
 
     // ---- fused NLL forward: statistics of this tile's 32 columns for each of its rows (a row = the 32 lanes t & 31 of a half wave)
-    const int ntn = gridDim.x;
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
         const int64_t m = m0 + (threadIdx.x >> 5) + 2 * KS * i, n = n0 + (threadIdx.x & 31);
-        const float v = n < N ? fin[i] : -INFINITY;
-        float mx = v;
-        int64_t am = n < N ? n : 0x7fffffffffffffffll;
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-            const float m2 = __shfl_xor(mx, o);
-            const int64_t a2 = __shfl_xor(am, o);
-            if (m2 > mx || (m2 == mx && a2 < am)) {
-                mx = m2;
-                am = a2;
-            }
-        }
-        float z = n < N ? expf(v - mx) : 0.f;
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) z += __shfl_xor(z, o);
+        float mx, z;
+        int64_t am;
+        half_wave_softmax_stats(fin[i], n < N, n + nll.col_off, mx, am, z);
         if (m < M) {
-            if ((threadIdx.x & 31) == 0) {
-                nll.stat[m * ntn + blockIdx.x] = make_uint4(__float_as_uint(mx), __float_as_uint(z), (uint32_t)am, 0u);
+            if ((threadIdx.x & 31) == 0)
+                nll.stat[m * nll.ldstat + nll.stat_col0 + blockIdx.x] = make_uint4(__float_as_uint(mx), __float_as_uint(z), (uint32_t)am, 0u);
+            if (n < N && (int64_t)nll.pos[m] == n + nll.col_off) nll.spos[m] = fin[i];
+        }
+    }
+    if (EPI != 2 || n0 >= nll.nshared) return;   // (uniform)
+    // ---- the other direction: the tile transposed through LDS — stored as rows of Ct, and its COLUMN statistics
+    __syncthreads();   // (every thread is done with the partial tiles)
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) red[0][(threadIdx.x >> 5) + 2 * KS * i][threadIdx.x & 31] = fin[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+        const int c = (threadIdx.x >> 5) + 2 * KS * i, r = threadIdx.x & 31;
+        const int64_t n = n0 + c, m = m0 + r;
+        const float v = red[0][r][c];
+        const bool col_ok = n < N && n < nll.nshared;
+        float mx, z;
+        int64_t am;
+        half_wave_softmax_stats(v, m < M, m, mx, am, z);
+        if (col_ok) {
+            if (m < M) {
+                nll.Ct[n * nll.ldct + m] = v;
+                if ((int64_t)nll.pos[n] == m) nll.spos_t[n] = v;
             }
-            if (n < N && (int64_t)nll.pos[m] == n) nll.spos[m] = v;
+            if (r == 0) nll.stat_t[n * nll.ldstat_t + blockIdx.y] = make_uint4(__float_as_uint(mx), __float_as_uint(z), (uint32_t)am, 0u);
         }
     }
 }
@@ -374,7 +411,7 @@ __global__ __launch_bounds__(64 * KS) void sgemm_direct_kernel(const float* __re
 // (Finishing INSIDE the GEMM kernel by "last workgroup to arrive" per row tile was built and measured: with hundreds of workgroups the
 // hand-off chain cost 12 - 18 us on top of a 9 - 24 us GEMM, profiles/r04_loss_kernel_trace_*.txt.)
 __global__ __launch_bounds__(512) void nll_finish_kernel(const uint4* __restrict__ stat, const float* __restrict__ spos,
-                                                         const int32_t* __restrict__ pos, int64_t n1, int ntn,
+                                                         const int32_t* __restrict__ pos, int64_t n1, int64_t n2, int ntn,
                                                          float* __restrict__ row_loss, float* __restrict__ lse_out,
                                                          int32_t* __restrict__ correct, float* __restrict__ loss_sum,
                                                          double* __restrict__ part_sum, int32_t* __restrict__ part_ok,
@@ -409,11 +446,13 @@ __global__ __launch_bounds__(512) void nll_finish_kernel(const uint4* __restrict
     int nok = 0;
     if (m < n1 && sub == 0) {
         const float l = mx + logf(z);
-        const float rl = l - spos[m];
+        const int32_t p = pos[m];
+        // (a positive outside [0, n2) was matched by no tile: spos[m] is stale workspace — the row's loss is NaN, not garbage)
+        const float rl = (p >= 0 && (int64_t)p < n2) ? l - spos[m] : NAN;
         lse_out[m] = l;
         row_loss[m] = rl;
         acc = (double)rl;
-        nok = am == pos[m];
+        nok = am == p;
     }
     sh[threadIdx.x] = acc;
 #pragma unroll
@@ -620,6 +659,162 @@ int launch_nll_dscores(const float* scores, const float* lse, const int32_t* pos
     return LDOT_OK;
 }
 
+// ---- the bidirectional train step (train_itm.py:195-222) in one pass --------------------------------------------------------------
+// Both directions' rows are finished by one launch: blockIdx.y = direction (0: img -> txt, 1: txt -> img), the same merge as
+// nll_finish_kernel per row; the last workgroup to arrive adds the partials of both directions in workgroup order and writes
+//   out = {loss_txt (mean), loss_img (mean), loss_nce = 0.5 loss_txt + 0.5 loss_img, is_correct = (c_txt + c_img) / 2, c_txt, c_img}.
+// blockIdx.y == 2 (optional): scores_avg = 0.5 S_txt + 0.5 S_img elementwise (train_itm.py:222).
+struct NllDir {
+    const uint4* stat;
+    const float* spos;
+    float *row_loss, *lse;
+    int ntn;
+};
+struct NllFinish2 {
+    NllDir dir[2];
+    const int32_t* pos;
+    int64_t n1, n2;
+    float* out;          // [6]
+    double* part_sum;    // [2][gridDim.x]
+    int32_t* part_ok;    // [2][gridDim.x]
+    int32_t* counter;
+    const float *s_txt, *s_img;
+    float* s_avg;        // (NULL: not wanted)
+};
+
+__global__ __launch_bounds__(512) void nll_finish_bidir_kernel(NllFinish2 a) {
+    __shared__ double sh[512];
+    __shared__ int ok_sh[8];
+    __shared__ int last_flag;
+    if (blockIdx.y == 2) {
+        const int64_t tot = a.n1 * a.n2;
+        for (int64_t i = (int64_t)blockIdx.x * 512 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 512)
+            a.s_avg[i] = __fadd_rn(__fmul_rn(a.s_txt[i], 0.5f), __fmul_rn(a.s_img[i], 0.5f));
+        return;
+    }
+    const NllDir d = a.dir[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = threadIdx.x & 7;
+    const int64_t m = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 3);
+    float mx = -INFINITY, z = 0.f;
+    int am = 0x7fffffff;
+    if (m < a.n1)
+        for (int t = sub; t < d.ntn; t += 8) {
+            const uint4 st = d.stat[m * d.ntn + t];
+            const float sx = __uint_as_float(st.x), sz = __uint_as_float(st.y);
+            const int a2 = (int)st.z;
+            if (sx > mx || (sx == mx && a2 < am)) am = a2;
+            const float nm = fmaxf(mx, sx);
+            z = z * expf(mx - nm) + sz * expf(sx - nm);
+            mx = nm;
+        }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(mx, o), z2 = __shfl_xor(z, o);
+        const int a2 = __shfl_xor(am, o);
+        if (m2 > mx || (m2 == mx && a2 < am)) am = a2;
+        const float nm = fmaxf(mx, m2);
+        z = (nm == -INFINITY) ? 0.f : z * expf(mx - nm) + z2 * expf(m2 - nm);
+        mx = nm;
+    }
+    double acc = 0.0;
+    int nok = 0;
+    if (m < a.n1 && sub == 0) {
+        const float l = mx + logf(z);
+        const int32_t p = a.pos[m];
+        const float rl = (p >= 0 && (int64_t)p < a.n2) ? l - d.spos[m] : NAN;
+        d.lse[m] = l;
+        d.row_loss[m] = rl;
+        acc = (double)rl;
+        nok = am == p;
+    }
+    sh[threadIdx.x] = acc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nok += __shfl_xor(nok, o);
+    if (lane == 0) ok_sh[wave] = nok;
+    __syncthreads();
+    for (int o = 256; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < 8; ++w) tot += ok_sh[w];
+        const unsigned slot = blockIdx.y * gridDim.x + blockIdx.x;
+        __hip_atomic_store(&a.part_sum[slot], sh[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.part_ok[slot], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int old = __hip_atomic_fetch_add(a.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = old == 2 * (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last_flag || threadIdx.x != 0) return;
+    double total[2] = {0.0, 0.0};
+    int tot[2] = {0, 0};
+    for (unsigned dd = 0; dd < 2; ++dd)
+        for (unsigned b = 0; b < gridDim.x; ++b) {   // (workgroup order: deterministic)
+            total[dd] += __hip_atomic_load(&a.part_sum[dd * gridDim.x + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tot[dd] += __hip_atomic_load(&a.part_ok[dd * gridDim.x + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    // mean like F.nll_loss(reduction='mean'): the fp32 sum divided by the row count; then 0.5 a + 0.5 b as train_itm.py:212 writes it
+    const float l0 = (float)total[0] / (float)a.n1, l1 = (float)total[1] / (float)a.n1;
+    a.out[0] = l0;
+    a.out[1] = l1;
+    a.out[2] = __fadd_rn(__fmul_rn(0.5f, l0), __fmul_rn(0.5f, l1));
+    a.out[3] = (float)(tot[0] + tot[1]) * 0.5f;
+    a.out[4] = (float)tot[0];
+    a.out[5] = (float)tot[1];
+    __hip_atomic_store(a.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// dS of the bidirectional step from S_txt alone (S_img[n][m] = S_txt[m][n] over the shared block):
+//   dS1[m][n]  = c1 (softmax_row(S_txt)[m][n] - [pos[m] == n]) + 0.5 G[m][n]
+//              + (n < bs:  c2 (exp(S_txt[m][n] - lse_img[n]) - [pos[n] == m]) + 0.5 G[n][m])        (the transposed direction folded in)
+//   dS2b[j][c] = c2 (exp(S_img[j][bs + c] - lse_img[j]) - [pos[j] == bs + c]) + 0.5 G[j][bs + c]      (hard-negative columns of S_img)
+// c1 = (0.5 g_nce + g_txt) / bs, c2 = (0.5 g_nce + g_img) / bs from DEVICE scalars (no host round trip); G = gradient w.r.t. scores_avg.
+struct NllBwd2 {
+    const float *s_txt, *s_img, *lse_txt, *lse_img, *g_nce, *g_txt, *g_img, *g_avg;
+    const int32_t* pos;
+    int64_t bs, n;
+    float *ds1, *ds2b;
+};
+__global__ __launch_bounds__(256) void nll_dscores_bidir_kernel(NllBwd2 a) {
+    const float gn = a.g_nce ? a.g_nce[0] : 0.f;
+    const float inv = 1.f / (float)a.bs;
+    const float c1 = (0.5f * gn + (a.g_txt ? a.g_txt[0] : 0.f)) * inv, c2 = (0.5f * gn + (a.g_img ? a.g_img[0] : 0.f)) * inv;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t tot1 = a.bs * a.n, nb = a.n - a.bs;
+    if (i < tot1) {
+        const int64_t m = i / a.n, n = i % a.n;
+        const float s = a.s_txt[i];
+        float v = c1 * (expf(s - a.lse_txt[m]) - ((int64_t)a.pos[m] == n ? 1.f : 0.f));
+        if (a.g_avg) v += 0.5f * a.g_avg[i];
+        if (n < a.bs) {
+            v += c2 * (expf(s - a.lse_img[n]) - ((int64_t)a.pos[n] == m ? 1.f : 0.f));
+            if (a.g_avg) v += 0.5f * a.g_avg[n * a.n + m];
+        }
+        a.ds1[i] = v;
+    } else if (i < tot1 + a.bs * nb) {
+        const int64_t r = i - tot1, j = r / nb, c = r % nb + a.bs;
+        float v = c2 * (expf(a.s_img[j * a.n + c] - a.lse_img[j]) - ((int64_t)a.pos[j] == c ? 1.f : 0.f));
+        if (a.g_avg) v += 0.5f * a.g_avg[j * a.n + c];
+        a.ds2b[r] = v;
+    }
+}
+
+__global__ void nll_combine_kernel(const float* loss_sum, const int32_t* correct, int64_t n1, float* out) {
+    const float l0 = loss_sum[0] / (float)n1, l1 = loss_sum[1] / (float)n1;
+    out[0] = l0;
+    out[1] = l1;
+    out[2] = __fadd_rn(__fmul_rn(0.5f, l0), __fmul_rn(0.5f, l1));
+    out[3] = (float)(correct[0] + correct[1]) * 0.5f;
+    out[4] = (float)correct[0];
+    out[5] = (float)correct[1];
+}
+__global__ __launch_bounds__(256) void scores_avg_kernel(const float* a, const float* b, int64_t n, float* o) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        o[i] = __fadd_rn(__fmul_rn(a[i], 0.5f), __fmul_rn(b[i], 0.5f));
+}
+
 }  // namespace ldot
 
 using namespace ldot;
@@ -688,12 +883,13 @@ static int launch_nll_fwd_fused(const float* q, const float* ctx, const float* c
     char* ws = nullptr;
     int rc = loss_workspace(st, b_cnt + b_st + b_spos + b_ps + b_po, &ws);
     if (rc) return rc;
-    NllFused nll;
+    NllFused nll{};
     nll.pos = pos;
     nll.stat = (uint4*)(ws + b_cnt);
     nll.spos = (float*)(ws + b_cnt + b_st);
+    nll.ldstat = (int)ntn;
     if ((rc = launch_sgemm_direct<1>(q, d, 1, ctx, d, 1, mix ? cap : nullptr, scores, n2, n1, n2, d, a1, w, 0, nll, st))) return rc;
-    hipLaunchKernelGGL(nll_finish_kernel, dim3((unsigned)nfin), dim3(512), 0, st, nll.stat, nll.spos, pos, n1, (int)ntn, row_loss, lse, correct,
+    hipLaunchKernelGGL(nll_finish_kernel, dim3((unsigned)nfin), dim3(512), 0, st, nll.stat, nll.spos, pos, n1, n2, (int)ntn, row_loss, lse, correct,
                        loss_sum, (double*)(ws + b_cnt + b_st + b_spos), (int32_t*)(ws + b_cnt + b_st + b_spos + b_ps), (int32_t*)ws);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
@@ -710,6 +906,119 @@ int ldot_inbatch_nll_fwd(const float* q, const float* ctx, const float* cap, flo
     int rc = launch_sgemm_nt(q, d, ctx, d, cap, w, scores, n2, n1, n2, d, st);
     if (rc) return rc;
     return launch_nll_rows(scores, n1, n2, pos, row_loss, lse, correct, loss_sum, st);
+}
+
+// ---- the bidirectional train step: ONE score GEMM for the shared block, both directions finished together ---------------------------
+int ldot_inbatch_nll_bidir_fwd(const float* img, const float* txt, const int32_t* pos, int64_t bs, int64_t n, int64_t d, float* s_txt,
+                               float* s_img, float* s_avg, float* lse, float* row_loss, float* out, void* stream) {
+    LDOT_REQUIRE(img && txt && pos && s_txt && s_img && lse && row_loss && out, LDOT_EINVAL, "NULL buffer");
+    LDOT_REQUIRE(bs > 0 && n >= bs && d > 0, LDOT_EINVAL, "bad shape (need 0 < bs <= n)");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nb = n - bs;
+    if (!(sgemm_is_small(bs, n) && sgemm_direct_ok(img, d, 1, d) && sgemm_direct_ok(txt, d, 1, d))) {
+        // shapes beyond the direct kernel (or ragged K): the two directions one after the other on the staged kernels
+        const size_t b_small = 256;
+        char* ws = nullptr;
+        int rc = loss_workspace(st, 256 + b_small, &ws);
+        if (rc) return rc;
+        float* lsum = (float*)(ws + 256);
+        int32_t* corr = (int32_t*)(ws + 256 + 64);
+        if ((rc = launch_sgemm_nt(img, d, txt, d, nullptr, 0.f, s_txt, n, bs, n, d, st))) return rc;
+        if ((rc = launch_nll_rows(s_txt, bs, n, pos, row_loss, lse, corr, lsum, st))) return rc;
+        if ((rc = launch_sgemm_nt(txt, d, img, d, nullptr, 0.f, s_img, n, bs, n, d, st))) return rc;
+        if ((rc = launch_nll_rows(s_img, bs, n, pos, row_loss + bs, lse + bs, corr + 1, lsum + 1, st))) return rc;
+        hipLaunchKernelGGL(nll_combine_kernel, dim3(1), dim3(1), 0, st, lsum, corr, bs, out);
+        if (s_avg) hipLaunchKernelGGL(scores_avg_kernel, dim3((unsigned)std::min<int64_t>((bs * n + 255) / 256, 2048)), dim3(256), 0, st, s_txt, s_img, bs * n, s_avg);
+        LDOT_HIP_CHECK(hipGetLastError());
+        return LDOT_OK;
+    }
+    const int64_t ntn1 = (n + 31) / 32, ntm = (bs + 31) / 32, ntn2b = (nb + 31) / 32, nt2 = ntm + ntn2b;
+    const int64_t nfin = (bs + 63) / 64;
+    const size_t b_cnt = 256, b_st1 = (size_t)round_up(bs * ntn1 * 16, 256), b_st2 = (size_t)round_up(bs * nt2 * 16, 256),
+                 b_spos = (size_t)round_up(bs * 4, 256), b_ps = (size_t)round_up(2 * nfin * 8, 256), b_po = (size_t)round_up(2 * nfin * 4, 256);
+    char* ws = nullptr;
+    int rc = loss_workspace(st, b_cnt + b_st1 + b_st2 + 2 * b_spos + b_ps + b_po, &ws);
+    if (rc) return rc;
+    uint4* stat1 = (uint4*)(ws + b_cnt);
+    uint4* stat2 = (uint4*)(ws + b_cnt + b_st1);
+    float* spos1 = (float*)(ws + b_cnt + b_st1 + b_st2);
+    float* spos2 = (float*)(ws + b_cnt + b_st1 + b_st2 + b_spos);
+    NllFused f{};
+    f.pos = pos;
+    f.stat = stat1;
+    f.ldstat = (int)ntn1;
+    f.spos = spos1;
+    f.Ct = s_img;
+    f.ldct = n;
+    f.nshared = bs;
+    f.stat_t = stat2;
+    f.ldstat_t = (int)nt2;
+    f.spos_t = spos2;
+    // S_txt = img[:bs] . txt^T with the row statistics, its transpose over the first bs columns (= S_img's shared block) and the column statistics
+    hipLaunchKernelGGL((sgemm_direct_kernel<true, true, false, 2, 8>), dim3((unsigned)ntn1, (unsigned)ntm), dim3(512), 0, st, img, d, txt, d,
+                       (const float*)nullptr, s_txt, n, bs, n, d, 1.f, 0.f, 0, f);
+    if (nb > 0) {   // hard-negative columns of S_img: txt[:bs] . img[bs:]^T
+        NllFused g{};
+        g.pos = pos;
+        g.stat = stat2;
+        g.ldstat = (int)nt2;
+        g.stat_col0 = (int)ntm;
+        g.col_off = bs;
+        g.spos = spos2;
+        hipLaunchKernelGGL((sgemm_direct_kernel<true, true, false, 1, 8>), dim3((unsigned)ntn2b, (unsigned)ntm), dim3(512), 0, st, txt, d,
+                           img + bs * d, d, (const float*)nullptr, s_img + bs, n, bs, nb, d, 1.f, 0.f, 0, g);
+    }
+    NllFinish2 a{};
+    a.dir[0] = NllDir{stat1, spos1, row_loss, lse, (int)ntn1};
+    a.dir[1] = NllDir{stat2, spos2, row_loss + bs, lse + bs, (int)nt2};
+    a.pos = pos;
+    a.n1 = bs;
+    a.n2 = n;
+    a.out = out;
+    a.part_sum = (double*)(ws + b_cnt + b_st1 + b_st2 + 2 * b_spos);
+    a.part_ok = (int32_t*)(ws + b_cnt + b_st1 + b_st2 + 2 * b_spos + b_ps);
+    a.counter = (int32_t*)ws;
+    a.s_txt = s_txt;
+    a.s_img = s_img;
+    a.s_avg = s_avg;
+    hipLaunchKernelGGL(nll_finish_bidir_kernel, dim3((unsigned)nfin, s_avg ? 3 : 2), dim3(512), 0, st, a);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+int ldot_inbatch_nll_bidir_bwd(const float* img, const float* txt, const int32_t* pos, int64_t bs, int64_t n, int64_t d,
+                               const float* s_txt, const float* s_img, const float* lse, const float* g_nce, const float* g_txt,
+                               const float* g_img, const float* g_avg, float* ds_work, float* dimg, float* dtxt, void* stream) {
+    LDOT_REQUIRE(img && txt && pos && s_txt && s_img && lse && ds_work, LDOT_EINVAL, "NULL buffer");
+    LDOT_REQUIRE(bs > 0 && n >= bs && d > 0, LDOT_EINVAL, "bad shape (need 0 < bs <= n)");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nb = n - bs;
+    NllBwd2 a{};
+    a.s_txt = s_txt;
+    a.s_img = s_img;
+    a.lse_txt = lse;
+    a.lse_img = lse + bs;
+    a.g_nce = g_nce;
+    a.g_txt = g_txt;
+    a.g_img = g_img;
+    a.g_avg = g_avg;
+    a.pos = pos;
+    a.bs = bs;
+    a.n = n;
+    a.ds1 = ds_work;
+    a.ds2b = ds_work + bs * n;
+    const int64_t tot = bs * n + bs * nb;
+    hipLaunchKernelGGL(nll_dscores_bidir_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, a);
+    LDOT_HIP_CHECK(hipGetLastError());
+    int rc;
+    // S_txt = img[:bs] . txt^T  ->  dimg[:bs] = dS1 . txt,  dtxt = dS1^T . img[:bs]
+    if (dimg && (rc = launch_sgemm_nn(a.ds1, n, txt, d, 1.f, dimg, d, bs, d, n, 0, st))) return rc;
+    if (dtxt && (rc = launch_sgemm_tn(a.ds1, n, img, d, 1.f, dtxt, d, n, d, bs, 0, st))) return rc;
+    if (nb > 0) {   // S_img[:, bs:] = txt[:bs] . img[bs:]^T  ->  dtxt[:bs] += dS2b . img[bs:],  dimg[bs:] = dS2b^T . txt[:bs]
+        if (dtxt && (rc = launch_sgemm_nn(a.ds2b, nb, img + bs * d, d, 1.f, dtxt, d, bs, d, nb, 1, st))) return rc;
+        if (dimg && (rc = launch_sgemm_tn(a.ds2b, nb, txt, d, 1.f, dimg + bs * d, d, nb, d, bs, 0, st))) return rc;
+    }
+    return LDOT_OK;
 }
 
 int ldot_inbatch_nll_bwd(const float* q, const float* ctx, const float* cap, float w, const int32_t* pos, int64_t n1,

@@ -136,6 +136,31 @@ def dot_product_scores(q_vectors: T, ctx_vectors: T, cosine=False) -> T:
     return r
 
 
+_range_lists = {}      # n -> list(range(n))  (the collate's pos_ctx_indices, dvl/data/itm.py:283)
+_pos_cache = {}        # (n, device) -> int32 device tensor arange(n)
+
+
+def _positive_tensor(positive_idx: list, n2: int, device) -> T:
+    """int32 device tensor of the positives.  The reference uploads the list on every call (torch.tensor(list).to(device),
+    bi_encoder.py:651,655: a pageable host-to-device copy, i.e. a synchronisation); the in-batch positives are always range(bs)
+    (dvl/data/itm.py:189,283), so that tensor is built once per (length, device).  Other lists are validated and uploaded."""
+    n = len(positive_idx)
+    rl = _range_lists.get(n)
+    if rl is None:
+        rl = _range_lists[n] = list(range(n))
+    if positive_idx == rl:
+        if n > n2:
+            raise IndexError('Target out of bounds')
+        key = (n, device)
+        t = _pos_cache.get(key)
+        if t is None:
+            t = _pos_cache[key] = torch.arange(n, dtype=torch.int32, device=device)
+        return t
+    if n and (min(positive_idx) < 0 or max(positive_idx) >= n2):
+        raise IndexError('Target out of bounds')      # what F.nll_loss raises in the reference
+    return torch.tensor(positive_idx, dtype=torch.int32).to(device)
+
+
 class BiEncoderNllLoss(object):
     """bi_encoder.py:613-665"""
 
@@ -145,13 +170,10 @@ class BiEncoderNllLoss(object):
         use_cap = caption_vectors is not None and caption_score_weight != 0
         if len(q_vectors.size()) == 1:
             q_vectors = q_vectors.view(1, -1)
-        pos = torch.tensor(positive_idx_per_question, dtype=torch.int32).to(q_vectors.device)
         n2 = ctx_vectors.shape[0]
         if len(positive_idx_per_question) != q_vectors.shape[0]:
             raise ValueError('one positive index per question is required')
-        if len(positive_idx_per_question) and (min(positive_idx_per_question) < 0 or
-                                                max(positive_idx_per_question) >= n2):
-            raise IndexError('Target out of bounds')      # what F.nll_loss raises in the reference
+        pos = _positive_tensor(positive_idx_per_question, n2, q_vectors.device)
         row_loss, scores, correct, loss_sum = _InBatchNll.apply(
             q_vectors, ctx_vectors, caption_vectors if use_cap else None, pos,
             float(caption_score_weight) if use_cap else 0.0)
@@ -179,6 +201,53 @@ class BiEncoderNllLoss(object):
     @staticmethod
     def get_similarity_function():
         return dot_product_scores
+
+
+class _BidirNll(torch.autograd.Function):
+    """The two _calc_loss calls of a fine-tuning step (train_itm.py:195-222) as ONE forward and ONE backward call into the library:
+    S_txt = img[:bs].txt^T and S_img = txt[:bs].img^T share their bs x bs block (transposed), so one GEMM tile pass leaves both with
+    row and column softmax statistics (ldot_inbatch_nll_bidir_fwd); nothing is read back by the host, the upstream gradients are
+    read by the backward kernel from device memory."""
+
+    @staticmethod
+    def forward(ctx, txt, img, pos, bs: int, want_scores: bool):
+        lib = L.load_library()
+        tf, mf = _prep(txt), _prep(img)
+        n, d = tf.shape
+        if mf.shape != tf.shape:
+            raise ValueError('txt and img vectors of a step have the same shape (bs + bs * num_hard_negatives rows)')
+        dev = tf.device
+        big = torch.empty((3 if want_scores else 2, bs, n), dtype=torch.float32, device=dev)        # S_txt | S_img | scores_avg
+        small = torch.empty((4 * bs + 8,), dtype=torch.float32, device=dev)                          # lse [2][bs] | row_loss [2][bs] | out [6]
+        lse, row_loss, out = small[:2 * bs], small[2 * bs:4 * bs], small[4 * bs:]
+        L.check(lib.ldot_inbatch_nll_bidir_fwd(_ptr(mf), _ptr(tf), _ptr(pos), bs, n, d, _ptr(big[0]), _ptr(big[1]),
+                                               _ptr(big[2]) if want_scores else None, _ptr(lse), _ptr(row_loss), _ptr(out), _stream()))
+        ctx.save_for_backward(tf, mf, pos, big, small)
+        ctx.bs = bs
+        ctx.in_dtypes = (txt.dtype, img.dtype)
+        ctx.set_materialize_grads(False)
+        is_correct = out[3]
+        ctx.mark_non_differentiable(is_correct)
+        scores = big[2] if want_scores else None
+        # loss_nce, loss_txt, loss_img, is_correct, scores
+        return out[2], out[0], out[1], is_correct, scores
+
+    @staticmethod
+    def backward(ctx, g_nce, g_txt, g_img, _g_ic, g_scores):
+        lib = L.load_library()
+        tf, mf, pos, big, small = ctx.saved_tensors
+        bs = ctx.bs
+        n, d = tf.shape
+        dev = tf.device
+        need_t, need_i = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dt = torch.empty_like(tf) if need_t else None
+        di = torch.empty_like(mf) if need_i else None
+        work = torch.empty((bs * n + bs * (n - bs),), dtype=torch.float32, device=dev)
+        g = [None if x is None else x.float().contiguous() for x in (g_nce, g_txt, g_img, g_scores)]
+        L.check(lib.ldot_inbatch_nll_bidir_bwd(_ptr(mf), _ptr(tf), _ptr(pos), bs, n, d, _ptr(big[0]), _ptr(big[1]), _ptr(small),
+                                               _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _ptr(work), _ptr(di), _ptr(dt), _stream()))
+        tt, ti = ctx.in_dtypes
+        return (dt.to(tt) if dt is not None else None, di.to(ti) if di is not None else None, None, None, None)
 
 
 class _AllGatherCat(torch.autograd.Function):
@@ -256,8 +325,20 @@ def train_step_loss(args, txt_vector: T, img_vectors: T, caption_vectors: Option
     """The loss composition of one fine-tuning step — train_itm.py:195-222 (both directions, averaged).
     Returns (loss_nce, is_correct, scores, (loss_nce_txt, loss_nce_img)).  ``loss_function`` (an object with the reference's
     ``calc``) defaults to the HIP ``BiEncoderNllLoss``, as train_itm.py:193 constructs it."""
-    loss_function = loss_function or BiEncoderNllLoss()
     bs = batch['sample_size']
+    ws = int(getattr(args, 'distributed_world_size', 1) or 1)
+    w = getattr(args, 'caption_score_weight', 0.0)
+    if (loss_function is None and ws == 1 and experiment is None and (caption_vectors is None or w == 0) and txt_vector.is_cuda
+            and txt_vector.dim() == 2 and txt_vector.shape == img_vectors.shape and 0 < bs <= txt_vector.shape[0]
+            and len(batch['pos_ctx_indices']) == bs
+            and (args.num_hard_negatives > 0 or bs == txt_vector.shape[0])):
+        # both directions in one forward and one backward call (one score GEMM for the shared bs x bs block); same values as the
+        # two-call composition below.  `is_correct` is a 0-dim DEVICE tensor (the reference's .item() calls, train_itm.py:211, would
+        # stall the host in front of backward()); float(is_correct) gives the reference's number.
+        pos = _positive_tensor(batch['pos_ctx_indices'], txt_vector.shape[0], txt_vector.device)
+        loss_nce, loss_nce_txt, loss_nce_img, is_correct, scores = _BidirNll.apply(txt_vector, img_vectors, pos, bs, True)
+        return loss_nce, is_correct, scores, (loss_nce_txt, loss_nce_img)
+    loss_function = loss_function or BiEncoderNllLoss()
     if args.num_hard_negatives > 0:
         loss_nce_txt, is_correct_txt, scores_txt = _calc_loss(args, loss_function, img_vectors[:bs], txt_vector,
                                                               caption_vectors, batch['pos_ctx_indices'],

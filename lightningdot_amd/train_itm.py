@@ -150,8 +150,9 @@ def TRAIN(args, bi_encoder, train_dataset, val_dataloader, val_img2txt: Dict, *,
                 loss = loss_nce + float(args.kd_loss_weight) * loss_kd
             if gas > 1:
                 loss = loss / gas
-            epoch_correct += float(is_correct)
-            epoch_loss += float(loss.item())
+            # (accumulated on the device: a float() / .item() here would stall the host in front of backward(), train_itm.py:211,243)
+            epoch_correct = epoch_correct + (is_correct.detach() if torch.is_tensor(is_correct) else float(is_correct))
+            epoch_loss = epoch_loss + loss.detach()
             n_steps += 1
             last_micro = (step + 1) % gas == 0
             if reducer is not None and last_micro:
@@ -171,7 +172,8 @@ def TRAIN(args, bi_encoder, train_dataset, val_dataloader, val_img2txt: Dict, *,
             if (step + 1) % int(getattr(args, 'log_result_step', 100) or 100) == 0 and _is_main():
                 logger.info('Epoch: %d: Step: %d/%d, loss=%f, lr=%f', epoch, step, steps_per_epoch, loss.item(),
                             optimizer.param_groups[0]['lr'])
-        epoch_loss = epoch_loss / n_steps if n_steps else 0.0
+        epoch_loss = float(epoch_loss) / n_steps if n_steps else 0.0
+        epoch_correct = float(epoch_correct)
         correct_ratio = epoch_correct / max(n_steps * int(args.train_batch_size), 1)
 
         # eval and save (:303-349)

@@ -42,6 +42,9 @@ def test_headline_line_has_the_contract_fields():
     for key in ('1q_x_headline_index', '64q_x_headline_index', '1q_x_123k', '64q_x_123k'):
         e = sec['serving_latency'][key]
         assert e['ms'] > 0 and 0.0 < e['hbm_frac_whole_search'] < 1.0 and e['rank1_ok']
+    for key in ('512x512', '512x1536'):
+        e = sec['loss_step'][key]
+        assert 0 < e['device_us'] <= e['end_to_end_us'] * 1.5 and e['torch_end_to_end_us'] > 0 and e['torch_device_us'] > 0
     iv = sec['ivf_123k']
     assert iv['ms_1_query'] > 0 and iv['recall@10_vs_exact'] > 0.8 and iv['nprobe'] == 32
 

@@ -130,6 +130,96 @@ def test_direct_kernel_edge_shapes_vs_fp64_oracle(n1, n2, d, w):
             np.testing.assert_allclose(tcap.grad.cpu().numpy(), dcap, rtol=2e-4, atol=2e-6)
 
 
+def _bidir_oracle(txt, img, bs, pos, g_nce=1.0, g_txt=0.0, g_img=0.0, g_avg=None):
+    """fp64: the two calc calls of train_itm.py:195-222 and the gradient of  g_nce * loss_nce + g_txt * loss_txt + g_img * loss_img
+    + <g_avg, scores_avg>  w.r.t. txt and img"""
+    l1, c1, s1 = O.biencoder_nll_loss(img[:bs], txt, None, pos, 0.0, 'mean', dtype=np.float64)
+    l2, c2, s2 = O.biencoder_nll_loss(txt[:bs], img, None, pos, 0.0, 'mean', dtype=np.float64)
+    ga = None if g_avg is None else 0.5 * np.asarray(g_avg, np.float64)
+    dq1, dc1, _ = O.biencoder_nll_grads(img[:bs], txt, None, pos, 0.0, 'mean', grad_loss=0.5 * g_nce + g_txt, grad_scores=ga)
+    dq2, dc2, _ = O.biencoder_nll_grads(txt[:bs], img, None, pos, 0.0, 'mean', grad_loss=0.5 * g_nce + g_img, grad_scores=ga)
+    dtxt, dimg = dc1.copy(), dc2.copy()
+    dimg[:bs] += dq1
+    dtxt[:bs] += dq2
+    return (l1, l2, 0.5 * l1 + 0.5 * l2, (c1 + c2) / 2, 0.5 * s1 + 0.5 * s2), dtxt, dimg
+
+
+@pytest.mark.parametrize('bs,nh,d', [(512, 0, 768), (512, 2, 768), (64, 0, 768), (33, 0, 96), (70, 1, 64), (100, 3, 160), (1, 0, 32)])
+def test_bidirectional_step_vs_fp64_oracle_and_the_two_call_composition(bs, nh, d):
+    """loss.train_step_loss on the one-pass path (ldot_inbatch_nll_bidir_fwd / _bwd: one score GEMM for the shared bs x bs block, row and
+    column statistics from the same epilogue) — SURVEY S3 shapes (512 x 512, 512 x 1536) and shapes that are no multiple of a tile:
+    losses, is_correct, averaged scores and the gradients of txt / img vs the fp64 oracle of train_itm.py:195-222, with upstream
+    gradients into loss_nce, into the two direction losses and into the averaged scores (the KD branch, :224-241); and against the
+    two-call composition on the HIP BiEncoderNllLoss."""
+    import torch
+    from lightningdot_amd.loss import BiEncoderNllLoss, train_step_loss
+    rng = np.random.default_rng(7 * bs + nh)
+    n = bs * (1 + nh)
+    txt = (rng.standard_normal((n, d)) * 0.2).astype(np.float32)
+    img = (rng.standard_normal((n, d)) * 0.2).astype(np.float32)
+    img[:bs] += txt[:bs]
+    if bs > 40:
+        txt[37] = txt[3]              # equal scores in different column tiles: first arg-max in both directions
+    pos = list(range(bs))
+    args = types.SimpleNamespace(caption_score_weight=0.0, num_hard_negatives=nh)
+    batch = dict(sample_size=bs, pos_ctx_indices=pos, neg_ctx_indices=list(range(bs, n)))
+    g_avg = rng.standard_normal((bs, n)).astype(np.float32) * 1e-3
+    for case in ('nce', 'all'):
+        tt, ti = _cuda(txt, True), _cuda(img, True)
+        loss, is_correct, scores, (lt, li) = train_step_loss(args, tt, ti, None, batch)
+        assert torch.is_tensor(is_correct) and is_correct.is_cuda           # no host round trip in front of backward()
+        gn, gt, gi, ga = (1.0, 0.0, 0.0, None) if case == 'nce' else (0.7, 0.3, -0.2, g_avg)
+        (l1, l2, lnce, ic, savg), dtxt, dimg = _bidir_oracle(txt.astype(np.float64), img.astype(np.float64), bs, pos, gn, gt, gi, ga)
+        if case == 'nce':
+            loss.backward()
+        else:
+            (gn * loss + gt * lt + gi * li + (scores * _cuda(g_avg)).sum()).backward()
+        assert abs(float(lt) - l1) < 1e-4 and abs(float(li) - l2) < 1e-4 and abs(float(loss) - lnce) < 1e-4
+        np.testing.assert_allclose(scores.detach().cpu().numpy(), savg, rtol=0, atol=5e-5)
+        # the oracle's arg-max is taken on fp64 scores: count with the same first-maximum rule on fp32 scores of the HIP calc
+        r1 = BiEncoderNllLoss().calc(_cuda(img[:bs]), _cuda(txt), None, pos)
+        r2 = BiEncoderNllLoss().calc(_cuda(txt[:bs]), _cuda(img), None, pos)
+        assert float(is_correct) == (int(r1[1]) + int(r2[1])) / 2
+        scale = max(float(np.abs(dtxt).max()), float(np.abs(dimg).max()))
+        np.testing.assert_allclose(tt.grad.cpu().numpy(), dtxt, rtol=2e-4, atol=2e-4 * scale)
+        np.testing.assert_allclose(ti.grad.cpu().numpy(), dimg, rtol=2e-4, atol=2e-4 * scale)
+        if case == 'nce':
+            # the two-call composition (the reference's own structure) on the same inputs
+            t2, i2 = _cuda(txt, True), _cuda(img, True)
+            loss2, ic2, scores2, (lt2, li2) = train_step_loss(args, t2, i2, None, batch, loss_function=BiEncoderNllLoss())
+            loss2.backward()
+            assert abs(float(loss2) - float(loss)) < 2e-6 and ic2 == float(is_correct)
+            assert abs(float(lt2) - float(lt)) < 2e-6 and abs(float(li2) - float(li)) < 2e-6
+            np.testing.assert_allclose(scores2.detach().cpu().numpy(), scores.detach().cpu().numpy(), rtol=0, atol=1e-5)
+            np.testing.assert_allclose(t2.grad.cpu().numpy(), tt.grad.cpu().numpy(), rtol=1e-4, atol=1e-4 * scale)
+            np.testing.assert_allclose(i2.grad.cpu().numpy(), ti.grad.cpu().numpy(), rtol=1e-4, atol=1e-4 * scale)
+
+
+def test_bidirectional_step_large_and_ragged_k_take_the_staged_kernels():
+    """shapes the direct kernel does not take (K not a multiple of 32; more than 256 tiles of 128 x 128): the same entry point on the
+    staged kernels"""
+    import torch
+    from lightningdot_amd.loss import train_step_loss
+    for bs, nh, d in ((48, 1, 50), (2304, 0, 64)):
+        rng = np.random.default_rng(bs)
+        n = bs * (1 + nh)
+        txt = (rng.standard_normal((n, d)) * 0.2).astype(np.float32)
+        img = (rng.standard_normal((n, d)) * 0.2).astype(np.float32)
+        img[:bs] += txt[:bs]
+        pos = list(range(bs))
+        args = types.SimpleNamespace(caption_score_weight=0.0, num_hard_negatives=nh)
+        batch = dict(sample_size=bs, pos_ctx_indices=pos, neg_ctx_indices=list(range(bs, n)))
+        tt, ti = _cuda(txt, True), _cuda(img, True)
+        loss, is_correct, scores, (lt, li) = train_step_loss(args, tt, ti, None, batch)
+        loss.backward()
+        (l1, l2, lnce, ic, savg), dtxt, dimg = _bidir_oracle(txt.astype(np.float64), img.astype(np.float64), bs, pos)
+        assert abs(float(loss) - lnce) < 1e-4 and abs(float(lt) - l1) < 1e-4 and abs(float(li) - l2) < 1e-4
+        np.testing.assert_allclose(scores.detach().cpu().numpy(), savg, rtol=0, atol=5e-5)
+        scale = max(float(np.abs(dtxt).max()), float(np.abs(dimg).max()))
+        np.testing.assert_allclose(tt.grad.cpu().numpy(), dtxt, rtol=2e-4, atol=2e-4 * scale)
+        np.testing.assert_allclose(ti.grad.cpu().numpy(), dimg, rtol=2e-4, atol=2e-4 * scale)
+
+
 def test_loss_rejects_cpu_tensors():
     import torch
     from lightningdot_amd import LdotError
