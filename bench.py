@@ -397,6 +397,7 @@ def loss_step_metrics(dev, D):
         def ours():
             loss, _ic, _sc, _ = train_step_loss(args, txt, img, None, batch)
             loss.backward()
+            txt.grad = img.grad = None     # (in a training step the towers' backward consumes them; accumulating into leaves would add two kernels)
 
         def ref():        # the reference's formulation (bi_encoder.py:615-656 twice, train_itm.py:195-222) in torch ops
             def nll(q, c):
@@ -410,6 +411,7 @@ def loss_step_metrics(dev, D):
             loss = 0.5 * lt + 0.5 * li
             _sc = st * 0.5 + si * 0.5
             loss.backward()
+            txt.grad = img.grad = None
 
         def device_us(fn):
             # device time of one step: events around a step issued behind a long-running kernel, so that host gaps do not count

@@ -283,18 +283,18 @@ __device__ __forceinline__ void half_wave_softmax_stats(float v, bool valid, int
 }
 
 // EPI 0: C = alpha * acc (+ C).  EPI 1 (forward of the loss): C = mix, + the softmax statistics of the tile's rows over its 32 columns.
+// (body of sgemm_direct_kernel; smem: KS * (MIX ? 3 : 2) * kTrFloats floats; (bx, by) = the workgroup's tile)
 template <bool AKF, bool BKF, bool MIX, int EPI, int KS>
-__global__ __launch_bounds__(64 * KS) void sgemm_direct_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
-                                                           int64_t ldb, const float* __restrict__ B2, float* __restrict__ C, int64_t ldc,
-                                                           int64_t M, int64_t N, int64_t K, float alpha, float w2, int accumulate,
-                                                           NllFused nll) {
+__device__ __forceinline__ void sgemm_direct_body(float* __restrict__ smem, const int bx, const int by, const float* __restrict__ A,
+                                                  int64_t lda, const float* __restrict__ B, int64_t ldb, const float* __restrict__ B2,
+                                                  float* __restrict__ C, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha,
+                                                  float w2, int accumulate, const NllFused& nll) {
     // LDS: the waves' transposition areas (A, B, B2) during the K loop, the four partial tiles afterwards
     constexpr int kTrOps = MIX ? 3 : 2;
-    __shared__ __attribute__((aligned(16))) float smem[KS * kTrOps * kTrFloats];
     static_assert(KS * 32 * 33 <= KS * 2 * kTrFloats, "partial tiles alias the transposition areas");
     float (*red)[32][33] = (float (*)[32][33])smem;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: scalar chunk addresses)
-    const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
+    const int64_t m0 = (int64_t)by * 32, n0 = (int64_t)bx * 32;
     const int64_t nch = (K + 31) / 32;
     f32x16 acc1, acc2;
 #pragma unroll
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(64 * KS) void sgemm_direct_kernel(const float* __re
         half_wave_softmax_stats(fin[i], n < N, n + nll.col_off, mx, am, z);
         if (m < M) {
             if ((threadIdx.x & 31) == 0)
-                nll.stat[m * nll.ldstat + nll.stat_col0 + blockIdx.x] = make_uint4(__float_as_uint(mx), __float_as_uint(z), (uint32_t)am, 0u);
+                nll.stat[m * nll.ldstat + nll.stat_col0 + bx] = make_uint4(__float_as_uint(mx), __float_as_uint(z), (uint32_t)am, 0u);
             if (n < N && (int64_t)nll.pos[m] == n + nll.col_off) nll.spos[m] = fin[i];
         }
     }
@@ -398,8 +398,41 @@ __global__ __launch_bounds__(64 * KS) void sgemm_direct_kernel(const float* __re
                 nll.Ct[n * nll.ldct + m] = v;
                 if ((int64_t)nll.pos[n] == m) nll.spos_t[n] = v;
             }
-            if (r == 0) nll.stat_t[n * nll.ldstat_t + blockIdx.y] = make_uint4(__float_as_uint(mx), __float_as_uint(z), (uint32_t)am, 0u);
+            if (r == 0) nll.stat_t[n * nll.ldstat_t + by] = make_uint4(__float_as_uint(mx), __float_as_uint(z), (uint32_t)am, 0u);
         }
+    }
+}
+
+template <bool AKF, bool BKF, bool MIX, int EPI, int KS>
+__global__ __launch_bounds__(64 * KS) void sgemm_direct_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                                           int64_t ldb, const float* __restrict__ B2, float* __restrict__ C, int64_t ldc,
+                                                           int64_t M, int64_t N, int64_t K, float alpha, float w2, int accumulate,
+                                                           NllFused nll) {
+    __shared__ __attribute__((aligned(16))) float smem[KS * (MIX ? 3 : 2) * kTrFloats];
+    sgemm_direct_body<AKF, BKF, MIX, EPI, KS>(smem, (int)blockIdx.x, (int)blockIdx.y, A, lda, B, ldb, B2, C, ldc, M, N, K, alpha, w2,
+                                              accumulate, nll);
+}
+
+// The two GEMMs of the bidirectional backward at num_hard_negatives = 0 in ONE launch (the step's cost is launches, not flops):
+//   workgroups [0, g0):       dimg = dS . txt      (A = dS K-contiguous, B = txt K-major)
+//   workgroups [g0, g0 + g1): dtxt = dS^T . img    (A = dS K-major,      B = img K-major)
+struct SgPairSide {
+    const float *A, *B;
+    float* C;
+    int64_t lda, ldb, ldc, M, N, K;
+    int gx, gy;
+};
+__global__ __launch_bounds__(256) void sgemm_direct_pair_kernel(SgPairSide p0, SgPairSide p1) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * 2 * kTrFloats];
+    const int g0 = p0.gx * p0.gy;
+    if ((int)blockIdx.x < g0) {
+        const int b = blockIdx.x;
+        sgemm_direct_body<true, false, false, 0, 4>(smem, b % p0.gx, b / p0.gx, p0.A, p0.lda, p0.B, p0.ldb, nullptr, p0.C, p0.ldc, p0.M,
+                                                    p0.N, p0.K, 1.f, 0.f, 0, NllFused{});
+    } else {
+        const int b = blockIdx.x - g0;
+        sgemm_direct_body<false, false, false, 0, 4>(smem, b % p1.gx, b / p1.gx, p1.A, p1.lda, p1.B, p1.ldb, nullptr, p1.C, p1.ldc, p1.M,
+                                                     p1.N, p1.K, 1.f, 0.f, 0, NllFused{});
     }
 }
 
@@ -1012,8 +1045,16 @@ int ldot_inbatch_nll_bidir_bwd(const float* img, const float* txt, const int32_t
     LDOT_HIP_CHECK(hipGetLastError());
     int rc;
     // S_txt = img[:bs] . txt^T  ->  dimg[:bs] = dS1 . txt,  dtxt = dS1^T . img[:bs]
-    if (dimg && (rc = launch_sgemm_nn(a.ds1, n, txt, d, 1.f, dimg, d, bs, d, n, 0, st))) return rc;
-    if (dtxt && (rc = launch_sgemm_tn(a.ds1, n, img, d, 1.f, dtxt, d, n, d, bs, 0, st))) return rc;
+    if (dimg && dtxt && sgemm_is_small(bs, d) && sgemm_is_small(n, d) && sgemm_direct_ok(a.ds1, n, 1, n) && sgemm_direct_ok(txt, 1, d, n) &&
+        sgemm_direct_ok(a.ds1, 1, n, bs) && sgemm_direct_ok(img, 1, d, bs)) {
+        SgPairSide p0{a.ds1, txt, dimg, n, d, d, bs, d, n, (int)((d + 31) / 32), (int)((bs + 31) / 32)};
+        SgPairSide p1{a.ds1, img, dtxt, n, d, d, n, d, bs, (int)((d + 31) / 32), (int)((n + 31) / 32)};
+        hipLaunchKernelGGL(sgemm_direct_pair_kernel, dim3((unsigned)(p0.gx * p0.gy + p1.gx * p1.gy)), dim3(256), 0, st, p0, p1);
+        LDOT_HIP_CHECK(hipGetLastError());
+    } else {
+        if (dimg && (rc = launch_sgemm_nn(a.ds1, n, txt, d, 1.f, dimg, d, bs, d, n, 0, st))) return rc;
+        if (dtxt && (rc = launch_sgemm_tn(a.ds1, n, img, d, 1.f, dtxt, d, n, d, bs, 0, st))) return rc;
+    }
     if (nb > 0) {   // S_img[:, bs:] = txt[:bs] . img[bs:]^T  ->  dtxt[:bs] += dS2b . img[bs:],  dimg[bs:] = dS2b^T . txt[:bs]
         if (dtxt && (rc = launch_sgemm_nn(a.ds2b, nb, img + bs * d, d, 1.f, dtxt, d, bs, d, nb, 1, st))) return rc;
         if (dimg && (rc = launch_sgemm_tn(a.ds2b, nb, txt, d, 1.f, dimg + bs * d, d, nb, d, bs, 0, st))) return rc;

@@ -203,34 +203,44 @@ class BiEncoderNllLoss(object):
         return dot_product_scores
 
 
+def _f32c(t: T) -> T:
+    """detached fp32 contiguous view / copy of a CUDA tensor (one op when it already is one)"""
+    if not t.is_cuda:
+        raise L.LdotError(-2, 'lightningdot_amd loss kernels need CUDA(HIP) tensors: there is no CPU fallback')
+    if t.dtype == torch.float32 and t.is_contiguous():
+        return t.detach()
+    return t.detach().float().contiguous()
+
+
 class _BidirNll(torch.autograd.Function):
     """The two _calc_loss calls of a fine-tuning step (train_itm.py:195-222) as ONE forward and ONE backward call into the library:
     S_txt = img[:bs].txt^T and S_img = txt[:bs].img^T share their bs x bs block (transposed), so one GEMM tile pass leaves both with
     row and column softmax statistics (ldot_inbatch_nll_bidir_fwd); nothing is read back by the host, the upstream gradients are
-    read by the backward kernel from device memory."""
+    read by the backward kernel from device memory.  The step's cost is the HOST's (a handful of launches around ~60 us of kernels), so
+    the Python below avoids tensor views (buffers are addressed by pointer arithmetic) and conversions that would be no-ops."""
 
     @staticmethod
     def forward(ctx, txt, img, pos, bs: int, want_scores: bool):
         lib = L.load_library()
-        tf, mf = _prep(txt), _prep(img)
+        tf, mf = _f32c(txt), _f32c(img)
         n, d = tf.shape
         if mf.shape != tf.shape:
             raise ValueError('txt and img vectors of a step have the same shape (bs + bs * num_hard_negatives rows)')
         dev = tf.device
         big = torch.empty((3 if want_scores else 2, bs, n), dtype=torch.float32, device=dev)        # S_txt | S_img | scores_avg
-        small = torch.empty((4 * bs + 8,), dtype=torch.float32, device=dev)                          # lse [2][bs] | row_loss [2][bs] | out [6]
-        lse, row_loss, out = small[:2 * bs], small[2 * bs:4 * bs], small[4 * bs:]
-        L.check(lib.ldot_inbatch_nll_bidir_fwd(_ptr(mf), _ptr(tf), _ptr(pos), bs, n, d, _ptr(big[0]), _ptr(big[1]),
-                                               _ptr(big[2]) if want_scores else None, _ptr(lse), _ptr(row_loss), _ptr(out), _stream()))
+        small = torch.empty((4 * bs,), dtype=torch.float32, device=dev)                              # lse [2][bs] | row_loss [2][bs]
+        out = torch.empty((6,), dtype=torch.float32, device=dev)       # loss_txt, loss_img, loss_nce, is_correct, #correct_txt, #correct_img
+        pb, ps, sz = big.data_ptr(), small.data_ptr(), 4 * bs * n
+        L.check(lib.ldot_inbatch_nll_bidir_fwd(mf.data_ptr(), tf.data_ptr(), pos.data_ptr(), bs, n, d, pb, pb + sz,
+                                               pb + 2 * sz if want_scores else None, ps, ps + 8 * bs, out.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream))
         ctx.save_for_backward(tf, mf, pos, big, small)
         ctx.bs = bs
         ctx.in_dtypes = (txt.dtype, img.dtype)
         ctx.set_materialize_grads(False)
-        is_correct = out[3]
+        loss_txt, loss_img, loss_nce, is_correct, _, _ = out.unbind(0)
         ctx.mark_non_differentiable(is_correct)
-        scores = big[2] if want_scores else None
-        # loss_nce, loss_txt, loss_img, is_correct, scores
-        return out[2], out[0], out[1], is_correct, scores
+        return loss_nce, loss_txt, loss_img, is_correct, (big[2] if want_scores else None)
 
     @staticmethod
     def backward(ctx, g_nce, g_txt, g_img, _g_ic, g_scores):
@@ -238,16 +248,22 @@ class _BidirNll(torch.autograd.Function):
         tf, mf, pos, big, small = ctx.saved_tensors
         bs = ctx.bs
         n, d = tf.shape
-        dev = tf.device
         need_t, need_i = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dt = torch.empty_like(tf) if need_t else None
         di = torch.empty_like(mf) if need_i else None
-        work = torch.empty((bs * n + bs * (n - bs),), dtype=torch.float32, device=dev)
-        g = [None if x is None else x.float().contiguous() for x in (g_nce, g_txt, g_img, g_scores)]
-        L.check(lib.ldot_inbatch_nll_bidir_bwd(_ptr(mf), _ptr(tf), _ptr(pos), bs, n, d, _ptr(big[0]), _ptr(big[1]), _ptr(small),
-                                               _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _ptr(work), _ptr(di), _ptr(dt), _stream()))
+        work = torch.empty((bs * n + bs * (n - bs),), dtype=torch.float32, device=tf.device)
+        g = [None if x is None else _f32c(x) for x in (g_nce, g_txt, g_img, g_scores)]     # (kept alive across the call)
+        gp = [None if x is None else x.data_ptr() for x in g]
+        pb, sz = big.data_ptr(), 4 * bs * n
+        L.check(lib.ldot_inbatch_nll_bidir_bwd(mf.data_ptr(), tf.data_ptr(), pos.data_ptr(), bs, n, d, pb, pb + sz, small.data_ptr(),
+                                               gp[0], gp[1], gp[2], gp[3], work.data_ptr(), di.data_ptr() if need_i else None,
+                                               dt.data_ptr() if need_t else None, torch.cuda.current_stream().cuda_stream))
         tt, ti = ctx.in_dtypes
-        return (dt.to(tt) if dt is not None else None, di.to(ti) if di is not None else None, None, None, None)
+        if need_t and tt != torch.float32:
+            dt = dt.to(tt)
+        if need_i and ti != torch.float32:
+            di = di.to(ti)
+        return dt, di, None, None, None
 
 
 class _AllGatherCat(torch.autograd.Function):

@@ -2,7 +2,7 @@
 # per-kernel GPU durations of the loss path by kernel AND grid size (the shapes of tools/loss_kernels_bench.py differ in grid):
 #   tools/loss_kernel_trace.sh > gpurun_out/loss_kernel_trace.txt
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/lk
-timeout 600 rocprofv3 --kernel-trace -d /tmp/lk -o t --output-format csv -- python $GRAFT_REPO_ROOT/tools/loss_kernels_bench.py > /tmp/lk.log 2>&1
+timeout 600 rocprofv3 --kernel-trace -d /tmp/lk -o t --output-format csv -- python $GRAFT_REPO_ROOT/tools/loss_kernels_bench.py "$@" > /tmp/lk.log 2>&1
 grep "forward" /tmp/lk.log
 python - <<'PY'
 import csv, glob, collections

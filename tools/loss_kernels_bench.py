@@ -18,7 +18,8 @@ def gpu_us(fn, n=200):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
 
 torch.manual_seed(99)
-for n1, n2, d, w in ((512, 512, 768, 0.0), (512, 1536, 768, 0.0), (512, 1536, 768, 0.1)):
+SHAPES = ((4096, 4096, 768, 0.0),) if '--big' in sys.argv else ((512, 512, 768, 0.0), (512, 1536, 768, 0.0), (512, 1536, 768, 0.1))
+for n1, n2, d, w in SHAPES:
     q = torch.randn(n1, d, device='cuda'); c = torch.randn(n2, d, device='cuda')
     cap = torch.randn(n2, d, device='cuda') if w else None
     pos = torch.arange(n1, device='cuda', dtype=torch.int32); pos64 = pos.long()
