@@ -393,10 +393,11 @@ def loss_step_metrics(dev, D):
         args = types.SimpleNamespace(caption_score_weight=0.0, num_hard_negatives=nh)
         batch = dict(sample_size=bs, pos_ctx_indices=list(range(bs)), neg_ctx_indices=list(range(bs, n)))
         pos_t = torch.arange(bs, device=dev)
+        one = torch.ones((), device=dev)
 
         def ours():
             loss, _ic, _sc, _ = train_step_loss(args, txt, img, None, batch)
-            loss.backward()
+            loss.backward(one)             # (a cached seed gradient, as train_itm.TRAIN passes: loss.backward() alone launches a fill per step)
             txt.grad = img.grad = None     # (in a training step the towers' backward consumes them; accumulating into leaves would add two kernels)
 
         def ref():        # the reference's formulation (bi_encoder.py:615-656 twice, train_itm.py:195-222) in torch ops
@@ -410,7 +411,7 @@ def loss_step_metrics(dev, D):
             li, ci, si = nll(txt[:bs], img)
             loss = 0.5 * lt + 0.5 * li
             _sc = st * 0.5 + si * 0.5
-            loss.backward()
+            loss.backward(one)
             txt.grad = img.grad = None
 
         def device_us(fn):

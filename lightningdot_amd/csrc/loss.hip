@@ -94,8 +94,10 @@ __global__ __launch_bounds__(kSgThreads) void sgemm_kernel(const float* __restri
                                                            float* __restrict__ C, int64_t ldc, int64_t M, int64_t N,
                                                            int64_t K, float alpha, int accumulate, int vec) {
     constexpr int BK = kSgSlab / TILE, LD = TILE + 4, WT = TILE / 64;
-    __shared__ __attribute__((aligned(16))) float As[BK][LD];
-    __shared__ __attribute__((aligned(16))) float Bs[BK][LD];
+    // two LDS stages: slab k + 1 is written (from the registers its global loads landed in) while slab k is being multiplied by waves
+    // that are behind — ONE barrier per slab (the single-stage version needed two; 4096 x 4096 x 768: profiles/r05_loss_trace_4096.txt)
+    __shared__ __attribute__((aligned(16))) float As[2][BK][LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t m0 = (int64_t)blockIdx.y * TILE, n0 = (int64_t)blockIdx.x * TILE;
     const int wm = wave >> 1, wn = wave & 1;
@@ -110,11 +112,13 @@ __global__ __launch_bounds__(kSgThreads) void sgemm_kernel(const float* __restri
     SgOperand<TILE, BKF> ob;
     oa.fetch(A, lda, m0, M, 0, K, vec & 1);
     ob.fetch(B, ldb, n0, N, 0, K, (vec >> 1) & 1);
+    oa.stash(As[0]);
+    ob.stash(Bs[0]);
+    __syncthreads();
+    int cur = 0;
     for (int64_t k0 = 0; k0 < K; k0 += BK) {
-        oa.stash(As);
-        ob.stash(Bs);
-        __syncthreads();
-        if (k0 + BK < K) {
+        const bool more = k0 + BK < K;
+        if (more) {
             oa.fetch(A, lda, m0, M, k0 + BK, K, vec & 1);
             ob.fetch(B, ldb, n0, N, k0 + BK, K, (vec >> 1) & 1);
         }
@@ -122,15 +126,20 @@ __global__ __launch_bounds__(kSgThreads) void sgemm_kernel(const float* __restri
         for (int ks = 0; ks < BK; ks += 2) {
             float a[WT], b[WT];
 #pragma unroll
-            for (int i = 0; i < WT; ++i) a[i] = As[ks + (lane >> 5)][(wm * WT + i) * 32 + (lane & 31)];
+            for (int i = 0; i < WT; ++i) a[i] = As[cur][ks + (lane >> 5)][(wm * WT + i) * 32 + (lane & 31)];
 #pragma unroll
-            for (int j = 0; j < WT; ++j) b[j] = Bs[ks + (lane >> 5)][(wn * WT + j) * 32 + (lane & 31)];
+            for (int j = 0; j < WT; ++j) b[j] = Bs[cur][ks + (lane >> 5)][(wn * WT + j) * 32 + (lane & 31)];
 #pragma unroll
             for (int i = 0; i < WT; ++i)
 #pragma unroll
                 for (int j = 0; j < WT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (more) {     // (stage cur ^ 1 was last read two slabs ago: every wave has passed the barrier after that)
+            oa.stash(As[cur ^ 1]);
+            ob.stash(Bs[cur ^ 1]);
+        }
         __syncthreads();
+        cur ^= 1;
     }
 #pragma unroll
     for (int i = 0; i < WT; ++i)
@@ -550,7 +559,9 @@ static int launch_sgemm_direct(const float* A, int64_t sam, int64_t sak, const f
 }
 
 // small problems take the direct kernel (see there); 128^2 LDS tiles once they alone fill the chip
-static bool sgemm_is_small(int64_t M, int64_t N) { return (M + 127) / 128 * ((N + 127) / 128) < 256; }
+// (and while the contraction is short: a 32 x 32 tile re-reads its operands once per tile — 4096 x 768 x 4096 took 440 us on the direct kernel
+// against 250 on the staged one, profiles/r05_loss_trace_4096.txt)
+static bool sgemm_is_small(int64_t M, int64_t N, int64_t K = 0) { return (M + 127) / 128 * ((N + 127) / 128) < 256 && K <= 2048; }
 // ... if their operands allow its unguarded loads: whole 32-deep chunks, 16-byte aligned rows of a K-contiguous operand, a K-major
 // operand's 16 ld inside 32 bits
 static bool sgemm_direct_ok(const float* P, int64_t s_row, int64_t s_k, int64_t K) {
@@ -566,7 +577,7 @@ static int launch_sgemm(const float* A, int64_t sam, int64_t sak, const float* B
     const bool ak = (sak == 1), bk = (sbk == 1);
     const int64_t lda = ak ? sam : sak, ldb = bk ? sbn : sbk;
     const int vec = ((lda % 4 == 0 && ((uintptr_t)A & 15) == 0) ? 1 : 0) | ((ldb % 4 == 0 && ((uintptr_t)B & 15) == 0) ? 2 : 0);
-    if (sgemm_is_small(M, N) && sgemm_direct_ok(A, sam, sak, K) && sgemm_direct_ok(B, sbn, sbk, K))
+    if (sgemm_is_small(M, N, K) && sgemm_direct_ok(A, sam, sak, K) && sgemm_direct_ok(B, sbn, sbk, K))
         return launch_sgemm_direct<0>(A, sam, sak, B, sbn, sbk, nullptr, C, ldc, M, N, K, alpha, 0.f, accumulate, NllFused{}, st);
     // 128^2 tiles once they alone fill the chip, else 64^2 (more workgroups: these problems are latency bound)
     if ((M + 127) / 128 * ((N + 127) / 128) >= 256) {
@@ -585,7 +596,7 @@ int launch_sgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, co
                     int64_t ldc, int64_t M, int64_t N, int64_t K, hipStream_t st) {
     const bool mix = (B2 != nullptr && w != 0.f);
     const float a1 = mix ? (float)(1.0 - (double)w) : 1.f;
-    if (M > 0 && N > 0 && sgemm_is_small(M, N) && sgemm_direct_ok(A, lda, 1, K) && sgemm_direct_ok(B, ldb, 1, K) &&
+    if (M > 0 && N > 0 && sgemm_is_small(M, N, K) && sgemm_direct_ok(A, lda, 1, K) && sgemm_direct_ok(B, ldb, 1, K) &&
         (!mix || sgemm_direct_ok(B2, ldb, 1, K)))   // both products in one launch
         return launch_sgemm_direct<0>(A, lda, 1, B, ldb, 1, mix ? B2 : nullptr, C, ldc, M, N, K, a1, w, 0, NllFused{}, st);
     int rc = launch_sgemm(A, lda, 1, B, ldb, 1, C, ldc, M, N, K, a1, 0, st);
@@ -1045,7 +1056,7 @@ int ldot_inbatch_nll_bidir_bwd(const float* img, const float* txt, const int32_t
     LDOT_HIP_CHECK(hipGetLastError());
     int rc;
     // S_txt = img[:bs] . txt^T  ->  dimg[:bs] = dS1 . txt,  dtxt = dS1^T . img[:bs]
-    if (dimg && dtxt && sgemm_is_small(bs, d) && sgemm_is_small(n, d) && sgemm_direct_ok(a.ds1, n, 1, n) && sgemm_direct_ok(txt, 1, d, n) &&
+    if (dimg && dtxt && sgemm_is_small(bs, d, n) && sgemm_is_small(n, d, bs) && sgemm_direct_ok(a.ds1, n, 1, n) && sgemm_direct_ok(txt, 1, d, n) &&
         sgemm_direct_ok(a.ds1, 1, n, bs) && sgemm_direct_ok(img, 1, d, bs)) {
         SgPairSide p0{a.ds1, txt, dimg, n, d, d, bs, d, n, (int)((d + 31) / 32), (int)((bs + 31) / 32)};
         SgPairSide p1{a.ds1, img, dtxt, n, d, d, n, d, bs, (int)((d + 31) / 32), (int)((n + 31) / 32)};

@@ -227,37 +227,39 @@ class _BidirNll(torch.autograd.Function):
         if mf.shape != tf.shape:
             raise ValueError('txt and img vectors of a step have the same shape (bs + bs * num_hard_negatives rows)')
         dev = tf.device
-        big = torch.empty((3 if want_scores else 2, bs, n), dtype=torch.float32, device=dev)        # S_txt | S_img | scores_avg
-        small = torch.empty((4 * bs,), dtype=torch.float32, device=dev)                              # lse [2][bs] | row_loss [2][bs]
-        out = torch.empty((6,), dtype=torch.float32, device=dev)       # loss_txt, loss_img, loss_nce, is_correct, #correct_txt, #correct_img
-        pb, ps, sz = big.data_ptr(), small.data_ptr(), 4 * bs * n
+        # ONE allocation: S_txt | S_img | scores_avg | dS work of the backward (bs * (2 n - bs) floats) | lse [2][bs] | row_loss [2][bs] | out [8]
+        # out = loss_txt, loss_img, loss_nce, is_correct, #correct_txt, #correct_img
+        o_work, o_small = 3 * bs * n, 3 * bs * n + bs * (2 * n - bs)
+        buf = torch.empty((o_small + 4 * bs + 8,), dtype=torch.float32, device=dev)
+        pb, sz = buf.data_ptr(), 4 * bs * n
+        ps = pb + 4 * o_small
         L.check(lib.ldot_inbatch_nll_bidir_fwd(mf.data_ptr(), tf.data_ptr(), pos.data_ptr(), bs, n, d, pb, pb + sz,
-                                               pb + 2 * sz if want_scores else None, ps, ps + 8 * bs, out.data_ptr(),
+                                               pb + 2 * sz if want_scores else None, ps, ps + 8 * bs, ps + 16 * bs,
                                                torch.cuda.current_stream().cuda_stream))
-        ctx.save_for_backward(tf, mf, pos, big, small)
+        ctx.save_for_backward(tf, mf, pos, buf)
         ctx.bs = bs
         ctx.in_dtypes = (txt.dtype, img.dtype)
         ctx.set_materialize_grads(False)
-        loss_txt, loss_img, loss_nce, is_correct, _, _ = out.unbind(0)
+        loss_txt, loss_img, loss_nce, is_correct = buf[o_small + 4 * bs:o_small + 4 * bs + 4].unbind(0)
         ctx.mark_non_differentiable(is_correct)
-        return loss_nce, loss_txt, loss_img, is_correct, (big[2] if want_scores else None)
+        return loss_nce, loss_txt, loss_img, is_correct, (buf[2 * bs * n:3 * bs * n].view(bs, n) if want_scores else None)
 
     @staticmethod
     def backward(ctx, g_nce, g_txt, g_img, _g_ic, g_scores):
         lib = L.load_library()
-        tf, mf, pos, big, small = ctx.saved_tensors
+        tf, mf, pos, buf = ctx.saved_tensors
         bs = ctx.bs
         n, d = tf.shape
         need_t, need_i = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dt = torch.empty_like(tf) if need_t else None
         di = torch.empty_like(mf) if need_i else None
-        work = torch.empty((bs * n + bs * (n - bs),), dtype=torch.float32, device=tf.device)
         g = [None if x is None else _f32c(x) for x in (g_nce, g_txt, g_img, g_scores)]     # (kept alive across the call)
         gp = [None if x is None else x.data_ptr() for x in g]
-        pb, sz = big.data_ptr(), 4 * bs * n
-        L.check(lib.ldot_inbatch_nll_bidir_bwd(mf.data_ptr(), tf.data_ptr(), pos.data_ptr(), bs, n, d, pb, pb + sz, small.data_ptr(),
-                                               gp[0], gp[1], gp[2], gp[3], work.data_ptr(), di.data_ptr() if need_i else None,
-                                               dt.data_ptr() if need_t else None, torch.cuda.current_stream().cuda_stream))
+        pb, sz = buf.data_ptr(), 4 * bs * n
+        L.check(lib.ldot_inbatch_nll_bidir_bwd(mf.data_ptr(), tf.data_ptr(), pos.data_ptr(), bs, n, d, pb, pb + sz,
+                                               pb + 4 * (3 * bs * n + bs * (2 * n - bs)), gp[0], gp[1], gp[2], gp[3], pb + 3 * sz,
+                                               di.data_ptr() if need_i else None, dt.data_ptr() if need_t else None,
+                                               torch.cuda.current_stream().cuda_stream))
         tt, ti = ctx.in_dtypes
         if need_t and tt != torch.float32:
             dt = dt.to(tt)

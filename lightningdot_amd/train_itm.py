@@ -129,7 +129,7 @@ def TRAIN(args, bi_encoder, train_dataset, val_dataloader, val_img2txt: Dict, *,
     elif nh > 0 and not getattr(args, 'sample_init_hard_negatives', False) and start_epoch == 0:
         raise NotImplementedError('random init hard negatives not impelmented yet')                              # :155-156
 
-    best_eval_metric, history = 0.0, []
+    best_eval_metric, history, seed_grad = 0.0, [], None
     for epoch in range(start_epoch, int(args.num_train_epochs)):
         epoch_loss, epoch_correct, n_steps = 0.0, 0.0, 0
         bi_encoder.train()
@@ -157,7 +157,9 @@ def TRAIN(args, bi_encoder, train_dataset, val_dataloader, val_img2txt: Dict, *,
             last_micro = (step + 1) % gas == 0
             if reducer is not None and last_micro:
                 reducer.arm()
-            loss.backward()
+            if seed_grad is None or seed_grad.dtype != loss.dtype:
+                seed_grad = torch.ones((), dtype=loss.dtype, device=loss.device)     # (loss.backward() alone fills a fresh one per step)
+            loss.backward(seed_grad)
             if last_micro:
                 if reducer is not None:
                     reducer.finish()                                        # C1: only the first layers' bucket is still in flight here
