@@ -205,11 +205,20 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
     sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)l_p * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
     sb.rsrc = ring_make_rsrc_n(Q16 + (int64_t)(qsub + l_q * qg) * kRBN * ldq_b, kRBN * ldq_b);
     int64_t issued = 0;
+    const int krot = (VAR & 32) ? (nsub * nk) / nstream : 0;
     // one slab = kLoads pieces per wave (3 of the row panel, 2 of the query panel); issue() sends them into the stage of slab
     // `issued` as a burst and moves the cursor on
     auto issue = [&]() {
         char* st = smem + (int)(issued & 3) * Geo::kStage;
-        const int k0b = l_k * 1024;   // slab l_k of a 16-row group = its l_k-th KiB block
+        // (VAR & 32, measurement: the row streams of an XCD walk K from different starting slabs — stream nsub starts at slab
+        // nsub * nk / nstream —, so that a query panel's lines are touched by one of its streams every quarter unit instead of by all of
+        // them at once: LRU distance 1.4 MB instead of 5.5 MB, the panels stay in the 4 MiB L2.  The sum over K is rotated, not changed.)
+        int kslab = l_k;
+        if (VAR & 32) {
+            kslab += krot;
+            if (kslab >= nk) kslab -= nk;
+        }
+        const int k0b = kslab * 1024;   // slab kslab of a 16-row group = its kslab-th KiB block
 #pragma unroll
         for (int j = 0; j < Geo::kLoads; ++j) {
             if (j < Geo::kALoads)
@@ -460,6 +469,8 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     if (variant == 16) rk = score_filter_t16_kernel<16>;
     if (variant == 17) rk = score_filter_t16_kernel<17>;
     if (variant == 8) rk = score_filter_t16_kernel<8>;
+    if (variant == 32) rk = score_filter_t16_kernel<32>;      // K walk rotated per row stream (query panels L2-resident?)
+    if (variant == 48) rk = score_filter_t16_kernel<48>;      // ... with tau = +inf
     if (variant == 128) rk = score_filter_t16_kernel<128>;    // row blocks NOT pinned in program order (the scheduler sinks the fragment loads)
     LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<6>::kLds));
 #else
