@@ -245,7 +245,7 @@ def main():
         'overflowed_queries': int(stats['overflowed_queries']),
         'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': ach / PEAK_BF16_TFLOPS, 'traffic': None,
-                     'kernel': 'score kernels of rank 0 (score_filter_t16_kernel + warm-up score_dense_kernel)',
+                     'kernel': 'score kernels of rank 0 (score_filter_t16_kernel + warm-up score_dense_t16_kernel)',
                      'launches_per_step': prof['launches'] / max(args.steps, 1),
                      'kernel_ms_per_step': prof['kernel_ms'] / max(args.steps, 1),
                      'flops_per_step': prof['flops'] / max(args.steps, 1)},
