@@ -165,6 +165,7 @@ def main():
         sh = ShardedFlatIndexer(D, equal_query_counts=(Q % world == 0))   # equal slices: no per-search exchange of the query counts
         sh.local.index.set_option(L.OPT_MODE, mode)
         sh.local.index.set_option(L.OPT_PROFILE, 1)
+        sh.profile_phases = True       # device time of every phase of the exchange (events on the search stream)
         if args.split_bf16:
             sh.local.index.set_option(L.OPT_PRECISION, 1)
         sh.index_local_shard(list(range(lo, hi)), x_local)
@@ -187,6 +188,7 @@ def main():
     for _ in range(args.warmup):
         step()
     prof = dict(launches=0.0, kernel_ms=0.0, flops=0.0, bytes=0.0)
+    phases = {}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -194,6 +196,9 @@ def main():
         p = flat.last_profile()
         for k_ in prof:
             prof[k_] += p[k_]
+        if sharded:
+            for k_, v in sh.last_phases.items():
+                phases[k_] = phases.get(k_, 0.0) + v
     barrier()
     dt = time.perf_counter() - t0
     ranks_seen = 1
@@ -250,6 +255,12 @@ def main():
                      'kernel_ms_per_step': prof['kernel_ms'] / max(args.steps, 1),
                      'flops_per_step': prof['flops'] / max(args.steps, 1)},
     }
+    if sharded:
+        # rank 0's device time per phase and step (the phases follow each other on one stream: they add up to `total`, which is the
+        # step minus the host's share — enqueue, the end-of-search synchronisation, Python)
+        out['phases_ms_per_step'] = {k_: v / max(args.steps, 1) for k_, v in phases.items()}
+        out['phases_note'] = ('rank 0, HIP events on the search stream; backend %s%s' %
+                              (args.backend, '' if args.backend == 'nccl' else ' (collectives bounce through host copies: exchange phases include them)'))
     if args.no_kernel_events:
         out['roofline']['note'] = 'kernel events disabled (--no-kernel-events): no kernel timing in this run'
     # measured-offline HBM traffic of the dominant kernel (rocprofv3 PMC passes, tools/pmc.sh; see profiles/)

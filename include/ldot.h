@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDOT_ABI_VERSION 5
+#define LDOT_ABI_VERSION 6
 
 /* status codes */
 #define LDOT_OK 0
@@ -83,6 +83,16 @@ extern "C" {
                                  * pools assume; +1 % on rows stored in random order.  0 (default):
                                  * storage order until one query in a thousand of a search fails the optimistic check, scrambled from then
                                  * on.  Results are identical in every order */
+#define LDOT_OPT_ROW_SHUFFLE 13 /* rows stored in a pseudo-random order behind a label table kept inside the library (labels, tie order and
+                                 * ldot_index_get_rows / _save keep referring to insertion order; what DenseFlatIndexer(shuffle_seed=) does in
+                                 * Python, for callers that bind ldot_index_add / _search directly).  For rows that arrive sorted in SHORT runs
+                                 * of similar rows (by class, by fine cluster: runs about as long as a 384-row tile), which fail the optimistic
+                                 * check in the scrambled tile order too.  1: the rows of every ldot_index_add call are stored in a
+                                 * pseudo-random order ((mul j + add) mod n, mul ~ n / golden ratio).  0 (default): rows are stored as added;
+                                 * when a large-batch search fails the check in the scrambled tile order for more than 1 / 64 of its queries the
+                                 * library re-orders the stored rows ONCE before the next search (a transient second fp32 copy; skipped when it
+                                 * does not fit) and shuffles later adds.  2: never (the inverted-file row store: lists are row ranges).
+                                 * Results are identical in every order */
 #define LDOT_OPT_VERIFY 10      /* 1: after every search flag the queries whose top-k cannot be vouched for: the k-th exact score is not above
                                  * the candidate threshold by E = 4 * 2^-8 * |q| * max|x| / sqrt(d), a STATISTICAL bound of the bf16
                                  * rounding error of a d-term inner product (4 standard deviations for independent rounding errors;
@@ -212,12 +222,24 @@ int ldot_ivf_search(ldot_index_t* ix, ldot_index_t* coarse, const void* queries,
 /* own on-disk format ("LDOTIDX1": header + fp32 rows); bf16 shadow is rebuilt on load */
 int ldot_index_save(ldot_index_t* ix, const char* path);
 int ldot_index_load(const char* path, ldot_index_t** out);
-/* copy rows [row0,row0+n) of the fp32 master copy to a caller buffer (inspection / resharding) */
+/* copy the rows with labels [row0,row0+n) (insertion order, also when the store is shuffled) of the fp32 master copy to a caller buffer
+ * (inspection / resharding) */
 int ldot_index_get_rows(ldot_index_t* ix, int64_t row0, int64_t n, float* out, int out_mem, void* stream);
 /* statistics of the last search on this index: [0]=candidate records appended by the fused filter (8 scores each), [1]=queries
  * that were searched again — a candidate pool overflowed, or the end-of-scan check of the optimistic thresholds failed
  * (LDOT_OPT_OPTIMISTIC) —, [2]=(query,row) pairs scored densely, [3]=pairs scored fused */
 int ldot_index_last_stats(const ldot_index_t* ix, int64_t out[4]);
+/* which regime the last search on this index ran in, and the adaptive state the handle carries (the same search costs more on an index
+ * that backed off; nothing else reports it):
+ *   out[0] path: 0 none, 1 narrow search (<= 64 queries), 2 dense chunks, 3 fused scan with one query block (65..256 queries), 4 fused scan
+ *   out[1] thresholds of a fused scan: 1 guaranteed (k'-th best so far), 2 optimistic (verified per query), 3 pooled over a sharded index
+ *   out[2] scan order: 1 storage order, 2 scrambled tile order
+ *   out[3] queries searched again (pool overflow / failed optimistic check)
+ *   out[4] large-batch searches this index will still run on guaranteed thresholds (back-off after failed checks; 0 = none)
+ *   out[5] few-query searches that will still skip the narrow search (back-off after a full candidate buffer)
+ *   out[6] 1: the index switched itself to the scrambled tile order (LDOT_OPT_SCAN_ORDER auto)
+ *   out[7] rows: 0 stored as added, 1 shuffled at add time, 2 re-ordered by the library (LDOT_OPT_ROW_SHUFFLE auto) */
+int ldot_index_last_regime(const ldot_index_t* ix, int64_t out[8]);
 /* LDOT_OPT_VERIFY = 1: flags_out [nq of the last search] (host, may be NULL) receives 1 for every query whose result is not proven
  * exact, *count_out their number.  No reference counterpart (faiss IndexFlatIP is fp32 end to end); this is how the bf16 candidate
  * pass reports that its margin may have been too small for a query. */

@@ -16,8 +16,9 @@ MODE_AUTO, MODE_DENSE, MODE_FUSED = 0, 1, 2
 OPT_MODE, OPT_RESCORE, OPT_CHUNK_ROWS, OPT_MARGIN, OPT_PROFILE, OPT_WARM_ROWS, OPT_GROWTH_PCT, OPT_PRECISION, OPT_RESERVE_ROWS = 1, 2, 3, 4, 5, 6, 7, 8, 9
 OPT_OPTIMISTIC = 11
 OPT_SCAN_ORDER = 12
+OPT_ROW_SHUFFLE = 13
 OPT_VERIFY = 10
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_MARGIN = 1024
 PAD_LABEL = -1
 PAD_SCORE = -3.4028234663852886e+38
@@ -52,6 +53,7 @@ SYMBOLS = {
     'ldot_index_load': (_i, [_c.c_char_p, _c.POINTER(_vp)]),
     'ldot_index_get_rows': (_i, [_vp, _i64, _i64, _vp, _i, _vp]),
     'ldot_index_last_stats': (_i, [_vp, _c.POINTER(_i64)]),
+    'ldot_index_last_regime': (_i, [_vp, _c.POINTER(_i64)]),
     'ldot_index_last_unproven': (_i, [_vp, _vp, _c.POINTER(_i64)]),
     'ldot_index_last_profile': (_i, [_vp, _c.POINTER(_c.c_double)]),
     'ldot_merge_topk': (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _i, _vp]),

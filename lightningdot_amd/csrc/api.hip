@@ -153,7 +153,39 @@ struct ldot_index {
     int64_t pool_total = 0;
     int pool_parts = 1;
     bool pooled_used = false;
+    // LDOT_OPT_ROW_SHUFFLE: rows stored in a pseudo-random order behind a label table.  row_shuffle: 0 auto (rows are stored as added; the
+    // store is re-shuffled ONCE when a large-batch search fails the optimistic check in the scrambled tile order too — rows sorted in runs
+    // about as long as a tile —, adds are shuffled from then on), 1 every add is shuffled, 2 never.  shuffled: the tables exist — stored row p
+    // carries label w_label[p], label l sits at row w_pos[l] (int32 [cap_rows] each)
+    int row_shuffle = 0;
+    bool shuffled = false, reshuffled = false, want_reshuffle = false;
+    DevBuf w_label, w_pos;
+    uint64_t shuffle_calls = 0;
+    // what the last search did (ldot_index_last_regime)
+    int last_path = 0, last_thresholds = 0, last_order = 0;
 };
+
+// label tables of a shuffled index for `cap` rows (contents of the first ntotal entries are kept)
+static int tables_reserve(ldot_index* ix, int64_t cap, hipStream_t st) {
+    const size_t need = (size_t)cap * 4;
+    for (DevBuf* b : {&ix->w_label, &ix->w_pos}) {
+        if (b->bytes >= need) continue;
+        void* np = nullptr;
+        LDOT_HIP_CHECK(hipMalloc(&np, need));
+        hipError_t e = hipSuccess;
+        if (b->p && ix->ntotal > 0) e = hipMemcpyAsync(np, b->p, (size_t)ix->ntotal * 4, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            (void)hipFree(np);
+            set_error("label table copy failed: %s", hipGetErrorString(e));
+            return LDOT_EDEVICE;
+        }
+        if (b->p) (void)hipFree(b->p);
+        b->p = np;
+        b->bytes = need;
+    }
+    return LDOT_OK;
+}
 
 static int index_reserve(ldot_index* ix, int64_t rows, hipStream_t st) {
     // capacity is a multiple of 256 rows (the MFMA tile) and rows beyond ntotal are kept zero
@@ -187,6 +219,71 @@ static int index_reserve(ldot_index* ix, int64_t rows, hipStream_t st) {
     ix->x32 = n32;
     ix->x16b = n16b;
     ix->cap_rows = cap;
+    if (ix->shuffled) return tables_reserve(ix, cap, st);
+    return LDOT_OK;
+}
+
+// first shuffled add (or the re-shuffle) of an index: label tables, identity for the rows already stored
+static int shuffle_engage(ldot_index* ix, hipStream_t st) {
+    if (ix->shuffled) return LDOT_OK;
+    int rc = tables_reserve(ix, ix->cap_rows, st);
+    if (rc) return rc;
+    if ((rc = launch_perm_labels((int32_t*)ix->w_label.p, (int32_t*)ix->w_pos.p, 0, ix->ntotal, RowPerm(), st))) return rc;
+    ix->shuffled = true;
+    return LDOT_OK;
+}
+
+static RowPerm row_perm(ldot_index* ix, int64_t n) {
+    RowPerm p;
+    if (n < 2) return p;
+    p.mul = scan_order_multiplier(n);   // ~ n / golden ratio, coprime to n: consecutive stored rows come from far apart
+    p.add = (int64_t)((0x9E3779B97F4A7C15ull * ++ix->shuffle_calls) >> 20) % n;
+    p.n = n;
+    return p;
+}
+
+// LDOT_OPT_ROW_SHUFFLE auto: the rows already stored are re-ordered pseudo-randomly (new row j = old row (mul j + add) mod n), once per index.
+// Needs room for a second fp32 copy while it runs; without it the index stays as it is.  `st` is synchronised.
+static int reshuffle_rows(ldot_index* ix, hipStream_t st) {
+    const int64_t n = ix->ntotal;
+    ix->reshuffled = true;
+    if (n < 2) return LDOT_OK;
+    LDOT_HIP_CHECK(hipStreamSynchronize(st));
+    const size_t b32 = (size_t)ix->cap_rows * ix->dpad * 4, bt = (size_t)ix->cap_rows * 4;
+    float* n32 = nullptr;
+    void *nl = nullptr, *np = nullptr, *idx = nullptr;
+    if (hipMalloc((void**)&n32, b32) != hipSuccess || hipMalloc(&nl, bt) != hipSuccess || hipMalloc(&np, bt) != hipSuccess ||
+        hipMalloc(&idx, bt) != hipSuccess) {
+        (void)hipGetLastError();
+        for (void* p : {(void*)n32, nl, np, idx})
+            if (p) (void)hipFree(p);
+        return LDOT_OK;
+    }
+    const RowPerm perm = row_perm(ix, n);
+    int rc = launch_reshuffle_tables(ix->shuffled ? (const int32_t*)ix->w_label.p : nullptr, (int32_t*)nl, (int32_t*)np, (int32_t*)idx, n, perm, st);
+    if (!rc) rc = launch_gather_rows_f32(ix->x32, ix->dpad, (const int32_t*)idx, n, n, n32, st);
+    hipError_t e = hipMemsetAsync(n32 + n * ix->dpad, 0, b32 - (size_t)n * ix->dpad * 4, st);
+    if (!rc) rc = launch_convert_rows(n32, LDOT_F32, ix->dpad, n, n, ix->d, ix->dpad, 0, nullptr, nullptr, ix->precision ? 1 : 0, ix->x16b, 0, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(idx);
+    if (rc || e != hipSuccess) {
+        (void)hipFree(n32);
+        (void)hipFree(nl);
+        (void)hipFree(np);
+        if (!rc) {
+            set_error("re-shuffle failed: %s", hipGetErrorString(e));
+            rc = LDOT_EDEVICE;
+        }
+        return rc;   // (the shadow may be half rewritten: the caller's search fails with this status)
+    }
+    (void)hipFree(ix->x32);
+    ix->x32 = n32;
+    ix->w_label.release();
+    ix->w_pos.release();
+    ix->w_label.p = nl;
+    ix->w_pos.p = np;
+    ix->w_label.bytes = ix->w_pos.bytes = bt;
+    ix->shuffled = true;
     return LDOT_OK;
 }
 
@@ -235,6 +332,8 @@ int ldot_index_destroy(ldot_index_t* ix) {
     ix->w_qcnt.release();
     ix->w_tau_opt.release();
     ix->w_redone.release();
+    ix->w_label.release();
+    ix->w_pos.release();
     ix->w_unproven.release();
     ix->w_norm.release();
     ix->w_nmax.release();
@@ -270,6 +369,9 @@ int ldot_index_reset(ldot_index_t* ix) {
         LDOT_HIP_CHECK(hipDeviceSynchronize());
     }
     ix->ntotal = 0;
+    ix->shuffled = ix->reshuffled = ix->want_reshuffle = false;   // (an empty index is in storage order again; the option stays)
+    ix->w_label.release();
+    ix->w_pos.release();
     if (ix->w_norm.p) LDOT_HIP_CHECK(hipMemset(ix->w_norm.p, 0, 16));
     return LDOT_OK;
 }
@@ -348,6 +450,12 @@ int ldot_index_set_option(ldot_index_t* ix, int option, int64_t value) {
             ix->scan_order = (int)value;
             ix->scrambled_auto = false;
             return LDOT_OK;
+        case LDOT_OPT_ROW_SHUFFLE:
+            LDOT_REQUIRE(value >= 0 && value <= 2, LDOT_EINVAL, "LDOT_OPT_ROW_SHUFFLE is 0 (auto), 1 (shuffle every add) or 2 (never)");
+            LDOT_REQUIRE(!(value == 2 && ix->shuffled), LDOT_ESTATE, "the rows of this index are shuffled already (reset it first)");
+            ix->row_shuffle = (int)value;
+            if (value == 2) ix->want_reshuffle = false;
+            return LDOT_OK;
         case LDOT_OPT_GROWTH_PCT:
             LDOT_REQUIRE(value >= 5 && value <= 10000, LDOT_EINVAL, "growth_pct must be in [5, 10000]");
             ix->growth_pct = (int)value;
@@ -378,9 +486,16 @@ int ldot_index_add(ldot_index_t* ix, const void* rows, int64_t n, int dtype, int
         LDOT_HIP_CHECK(hipMemcpyAsync(ix->w_stage.p, rows, bytes, hipMemcpyHostToDevice, st));
         src = ix->w_stage.p;
     }
+    // LDOT_OPT_ROW_SHUFFLE: the rows of this call go into the store in a pseudo-random order; the label tables remember which is which
+    RowPerm perm;
+    if (ix->row_shuffle == 1 || (ix->row_shuffle == 0 && ix->shuffled)) {
+        if ((rc = shuffle_engage(ix, st))) return rc;
+        perm = row_perm(ix, n);
+    }
     rc = launch_convert_rows(src, dtype, ix->d, n, n, ix->d, ix->dpad, normalize, ix->x32 + ix->ntotal * ix->dpad,
-                             nullptr, ix->precision ? 1 : 0, ix->x16b, ix->ntotal, st);
+                             nullptr, ix->precision ? 1 : 0, ix->x16b, ix->ntotal, st, perm);
     if (rc) return rc;
+    if (ix->shuffled && (rc = launch_perm_labels((int32_t*)ix->w_label.p, (int32_t*)ix->w_pos.p, ix->ntotal, n, perm, st))) return rc;
     // largest row norm so far (device scalar; the LDOT_OPT_VERIFY bound reads it)
     if (ix->w_norm.p == nullptr) {
         if ((rc = ix->w_norm.ensure(16))) return rc;
@@ -398,6 +513,15 @@ int ldot_index_get_rows(ldot_index_t* ix, int64_t row0, int64_t n, float* out, i
     if (n == 0) return LDOT_OK;
     DeviceGuard guard(ix->device);
     hipStream_t st = (hipStream_t)stream;
+    if (ix->shuffled) {   // rows are addressed by LABEL: gathered through the position table
+        int rc = ix->w_stage.ensure((size_t)n * ix->dpad * 4);
+        if (rc) return rc;
+        if ((rc = launch_gather_rows_f32(ix->x32, ix->dpad, (const int32_t*)ix->w_pos.p + row0, n, n, (float*)ix->w_stage.p, st))) return rc;
+        LDOT_HIP_CHECK(hipMemcpy2DAsync(out, (size_t)ix->d * 4, ix->w_stage.p, (size_t)ix->dpad * 4, (size_t)ix->d * 4, (size_t)n,
+                                        out_mem == LDOT_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
+        LDOT_HIP_CHECK(hipStreamSynchronize(st));   // (the staging buffer is reused)
+        return LDOT_OK;
+    }
     LDOT_HIP_CHECK(hipMemcpy2DAsync(out, (size_t)ix->d * 4, ix->x32 + row0 * ix->dpad, (size_t)ix->dpad * 4,
                                     (size_t)ix->d * 4, (size_t)n,
                                     out_mem == LDOT_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
@@ -419,6 +543,19 @@ int ldot_index_last_stats(const ldot_index_t* cix, int64_t out[4]) {
         ix->qcnt_n = 0;
     }
     for (int i = 0; i < 4; ++i) out[i] = ix->stats[i];
+    return LDOT_OK;
+}
+
+int ldot_index_last_regime(const ldot_index_t* ix, int64_t out[8]) {
+    LDOT_REQUIRE(ix != nullptr && out != nullptr, LDOT_EINVAL, "NULL argument");
+    out[0] = ix->last_path;
+    out[1] = ix->last_thresholds;
+    out[2] = ix->last_order;
+    out[3] = ix->redone;
+    out[4] = ix->opt_backoff;
+    out[5] = ix->narrow_backoff;
+    out[6] = ix->scrambled_auto ? 1 : 0;
+    out[7] = ix->reshuffled && ix->shuffled ? 2 : ix->shuffled ? 1 : 0;
     return LDOT_OK;
 }
 
@@ -452,6 +589,23 @@ static void prof_begin(ldot_index* ix, hipStream_t st, double flops, double byte
     ev.bytes = bytes;
     (void)hipEventRecord(ev.a, st);
     ix->prof_events.push_back(ev);
+}
+// the same for a kernel whose launcher attaches the events to the dispatch itself (hipExtLaunchKernel): nothing is recorded on the stream,
+// *a / *b stay NULL when profiling is off
+static void prof_attach(ldot_index* ix, double flops, double bytes, hipEvent_t* a, hipEvent_t* b) {
+    *a = *b = nullptr;
+    if (!ix->profile) return;
+    ldot_index::ProfEv ev;
+    if (hipEventCreate(&ev.a) != hipSuccess) return;
+    if (hipEventCreate(&ev.b) != hipSuccess) {
+        (void)hipEventDestroy(ev.a);
+        return;
+    }
+    ev.flops = flops;
+    ev.bytes = bytes;
+    ix->prof_events.push_back(ev);
+    *a = ev.a;
+    *b = ev.b;
 }
 static void prof_end(ldot_index* ix, hipStream_t st) {
     if (!ix->profile || ix->prof_events.empty()) return;
@@ -488,11 +642,10 @@ static int dense_scan(ldot_index* ix, int64_t q0, int64_t nqb, int64_t nqb_pad, 
         const int64_t nrows = std::min(chunk, r1 - r);
         const int64_t nrows_pad = round_up(nrows, kBN);
         // algorithmic work: the VALID queries x rows x d (tile padding is overhead, not work)
-        prof_begin(ix, st, 2.0 * nqb * nrows * ix->d,
-                   (double)nrows * ix->d * 2 + (double)nqb * ix->d * 2 + (double)nqb * nrows * 4);
+        hipEvent_t ea, eb;
+        prof_attach(ix, 2.0 * nqb * nrows * ix->d, (double)nrows * ix->d * 2 + (double)nqb * ix->d * 2 + (double)nqb * nrows * 4, &ea, &eb);
         rc = launch_score_dense(q16, ix->ld16(), nqb_pad, ix->x16b, ix->ld16(), r, nrows_pad, (int)ix->ld16(), (float*)ix->w_S.p,
-                                chunk, nqb, st);
-        prof_end(ix, st);
+                                chunk, nqb, st, 256, ea, eb);
         if (rc) return rc;
         rc = launch_select_dense((const float*)ix->w_S.p, chunk, nqb, nrows, r, ls, li, kp, tau ? tau + q0 : nullptr,
                                  st);
@@ -714,11 +867,12 @@ static int fused_launch_and_select(ldot_index* ix, int64_t q0, int64_t nq, int64
     const int qg = fused_query_group(nq_pad);
     const int64_t nslices = 256 / qg, nsubs = kPoolSubsPerSlice * nslices;
     int rc;
-    prof_begin(ix, st, 2.0 * nq * len * ix->d, (double)len * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * kp * 8);
+    hipEvent_t ea, eb;
+    prof_attach(ix, 2.0 * nq * len * ix->d, (double)len * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * kp * 8, &ea, &eb);
     // (scrambled scan: rows [r, r + len) of the pseudo-random tile order of the whole index)
     rc = launch_score_filter(ix->x16b, ix->ld16(), scramble_tiles ? 0 : r, len, q16, ix->ld16(), nq_pad, (int)ix->ld16(), filter_tau,
-                             (uint4*)ix->w_pool.p, (int32_t*)ix->w_pool_cnt.p, st, scramble_tiles, scramble_tiles ? r / fused_tile_rows() : 0);
-    prof_end(ix, st);
+                             (uint4*)ix->w_pool.p, (int32_t*)ix->w_pool_cnt.p, st, scramble_tiles, scramble_tiles ? r / fused_tile_rows() : 0,
+                             ea, eb);
     if (rc) return rc;
     if (nq <= kFewSelectMaxQueries && nsubs >= 128 * kPoolSubsPerSlice && kp + 512 + 32 <= 1024) {
         // few queries: G waves per query fold the sub-pools into partial lists, one merge joins them with the running list
@@ -820,9 +974,9 @@ static int fused_warm_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_p
     const uint16_t* q16 = (const uint16_t*)ix->w_q16b.p + q0 * ix->ld16();
     int rc = ix->w_S.ensure((size_t)nq_pad * wpad * sizeof(float));
     if (rc) return rc;
-    prof_begin(ix, st, 2.0 * nq * wpad * ix->d, (double)wpad * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * wpad * 4);
-    rc = launch_score_dense(q16, ix->ld16(), nq_pad, ix->x16b, ix->ld16(), 0, wpad, (int)ix->ld16(), (float*)ix->w_S.p, wpad, nq, st, stride);
-    prof_end(ix, st);
+    hipEvent_t ea, eb;
+    prof_attach(ix, 2.0 * nq * wpad * ix->d, (double)wpad * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * wpad * 4, &ea, &eb);
+    rc = launch_score_dense(q16, ix->ld16(), nq_pad, ix->x16b, ix->ld16(), 0, wpad, (int)ix->ld16(), (float*)ix->w_S.p, wpad, nq, st, stride, ea, eb);
     if (rc) return rc;
     ix->stats[2] += wpad * nq;
     return launch_select_dense((const float*)ix->w_S.p, wpad, nq, wpad, 0, (float*)ix->w_ls.p + q0 * kp, (int32_t*)ix->w_li.p + q0 * kp, kp,
@@ -1037,6 +1191,10 @@ static bool fused_overflow_check(ldot_index* ix) {
         // of the queries cost more than the optimistic thresholds save: back off to the guaranteed ones for a while.
         if (ix->scan_order == 0 && !ix->scrambled_auto && !ix->scrambled_now && n_over >= 4 && n_over * 1024 > ix->opt_nq) {
             ix->scrambled_auto = true;
+        } else if (n_over * 64 > ix->opt_nq && ix->scrambled_now && ix->row_shuffle == 0 && !ix->shuffled && !ix->reshuffled) {
+            // failing in the scrambled TILE order too: similar rows sit in runs about as long as a tile.  The store is re-shuffled row by
+            // row before the next search (once per index; LDOT_OPT_ROW_SHUFFLE)
+            ix->want_reshuffle = true;
         } else if (n_over * 64 > ix->opt_nq) {
             ix->opt_backoff = ix->opt_penalty;
             ix->opt_penalty = std::min(2 * ix->opt_penalty, 1024);
@@ -1162,6 +1320,13 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
     DeviceGuard guard(ix->device);
     for (int i = 0; i < 4; ++i) ix->stats[i] = 0;
     ix->redone = 0;
+    ix->last_path = ix->last_thresholds = 0;
+    ix->last_order = 1;
+    if (ix->want_reshuffle) {
+        ix->want_reshuffle = false;
+        int rrc = reshuffle_rows(ix, st);
+        if (rrc) return rrc;
+    }
     const int kp = candidate_len(ix, k);
     const int64_t nq_pad = round_up(nq, kBM);
     int rc;
@@ -1226,6 +1391,7 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
         return LDOT_OK;
     }
     if (narrow) {
+        ix->last_path = 1;
         if ((rc = narrow_search(ix, nq, kp, st, direct))) return rc;
         if (!defer_check) {
             LDOT_HIP_CHECK(hipStreamSynchronize(st));
@@ -1243,8 +1409,11 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
         const bool fused = ix->mode == LDOT_MODE_FUSED ||
                            (ix->mode == LDOT_MODE_AUTO && !(nq <= 16 && narrow_ok(ix, nq)) &&
                             (ix->ntotal >= 32768 || (ix->ntotal >= 16384 && nq >= 16384)));
+        ix->last_path = !fused ? 2 : nq <= kFewSelectMaxQueries ? 3 : 4;
         if (fused) {
             if ((rc = fused_scan(ix, nq, nq_pad, kp, st))) return rc;
+            ix->last_thresholds = ix->pooled_used ? 3 : ix->opt_used ? 2 : 1;
+            ix->last_order = ix->scrambled_now ? 2 : 1;
             if (!defer_check) {
                 LDOT_HIP_CHECK(hipStreamSynchronize(st));
                 if (fused_overflow_check(ix) && (rc = redo_flagged(ix, nq, nq_pad, kp, st))) return rc;
@@ -1351,6 +1520,7 @@ static int search_finish_impl(ldot_index_t* ix, const float* floor, float* out_s
     if (!keep_pending) ix->pend_nq = 0;
     DeviceGuard guard(ix->device);
     int rc;
+    const int32_t* lmap = ix->shuffled ? (const int32_t*)ix->w_label.p : nullptr;   // (LDOT_OPT_ROW_SHUFFLE: stored row -> label)
     // LDOT_OPT_VERIFY (plain searches only: a sharded search compares against the GLOBAL threshold, which this shard cannot judge)
     auto verify = [&](const float* dev_s, const int64_t* dev_l) -> int {
         if (!ix->verify || floor != nullptr || !ix->rescore || ix->w_norm.p == nullptr) return LDOT_OK;
@@ -1363,7 +1533,7 @@ static int search_finish_impl(ldot_index_t* ix, const float* floor, float* out_s
     };
     if (out_mem == LDOT_DEVICE) {   // device outputs are written by the re-score kernel directly
         if ((rc = launch_rescore((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, nq, (const float*)ix->w_ls.p,
-                                 (const int32_t*)ix->w_li.p, kp, k, ix->rescore, floor, out_scores, out_labels, st)))
+                                 (const int32_t*)ix->w_li.p, kp, k, ix->rescore, floor, out_scores, out_labels, st, nullptr, lmap)))
             return rc;
         if ((rc = verify(out_scores, out_labels))) return rc;
         prof_collect(ix, st);
@@ -1377,7 +1547,7 @@ static int search_finish_impl(ldot_index_t* ix, const float* floor, float* out_s
     (void)hipGetLastError();   // (a pageable buffer makes the query fail: not an error of this call)
     if (mapped) {
         if ((rc = launch_rescore((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, nq, (const float*)ix->w_ls.p,
-                                 (const int32_t*)ix->w_li.p, kp, k, ix->rescore, floor, (float*)ms, (int64_t*)ml, st)))
+                                 (const int32_t*)ix->w_li.p, kp, k, ix->rescore, floor, (float*)ms, (int64_t*)ml, st, nullptr, lmap)))
             return rc;
         if ((rc = verify((const float*)ms, (const int64_t*)ml))) return rc;
         LDOT_HIP_CHECK(hipStreamSynchronize(st));
@@ -1389,7 +1559,7 @@ static int search_finish_impl(ldot_index_t* ix, const float* floor, float* out_s
     if ((rc = ix->w_outl.ensure((size_t)nq * k * 8))) return rc;
     if ((rc = launch_rescore((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, nq, (const float*)ix->w_ls.p,
                              (const int32_t*)ix->w_li.p, kp, k, ix->rescore, floor, (float*)ix->w_outs.p,
-                             (int64_t*)ix->w_outl.p, st)))
+                             (int64_t*)ix->w_outl.p, st, nullptr, lmap)))
         return rc;
     if ((rc = verify((const float*)ix->w_outs.p, (const int64_t*)ix->w_outl.p))) return rc;
     LDOT_HIP_CHECK(hipMemcpyAsync(out_scores, ix->w_outs.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
@@ -1419,7 +1589,7 @@ int ldot_index_search_finish_blocked(ldot_index_t* ix, const float* floor, void*
     ix->pend_nq = 0;
     DeviceGuard guard(ix->device);
     hipStream_t st = (hipStream_t)stream;
-    const RescoreOut lay{block_rows, block_bytes / 4, block_bytes / 8, label_base};
+    const RescoreOut lay{block_rows, block_bytes / 4, block_bytes / 8, label_base, ix->shuffled ? (const int32_t*)ix->w_label.p : nullptr};
     int rc = launch_rescore((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, nq, (const float*)ix->w_ls.p,
                             (const int32_t*)ix->w_li.p, kp, k, ix->rescore, floor, (float*)out_blocks,
                             (int64_t*)((char*)out_blocks + lab_off), st, &lay);
@@ -1438,7 +1608,7 @@ int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dty
     // where the final top-k may be written by a kernel directly (device memory, or pinned host memory through its device mapping):
     // a few-query search then ends in ONE kernel after the scan (narrow_finish_kernel)
     DirectOut direct{nullptr, nullptr, k};
-    if (nq > 0 && ix && !ix->verify) {
+    if (nq > 0 && ix && !ix->verify && !ix->shuffled) {   // (a shuffled index translates rows to labels in the re-score kernel)
         if (out_mem == LDOT_DEVICE) {
             direct.scores = out_scores;
             direct.labels = out_labels;
@@ -1654,6 +1824,7 @@ int ldot_index_search_lists(ldot_index_t* ix, const void* queries, int64_t nq, i
     LDOT_REQUIRE(dtype >= 0 && dtype <= 2, LDOT_EINVAL, "bad dtype %d", dtype);
     LDOT_REQUIRE(out_mem == LDOT_HOST || out_mem == LDOT_DEVICE, LDOT_EINVAL, "bad memory space");
     LDOT_REQUIRE(nlist >= 1 && nprobe >= 1 && nprobe <= nlist && max_list_len >= 0, LDOT_EINVAL, "bad list geometry");
+    LDOT_REQUIRE(!ix->shuffled, LDOT_ESTATE, "list search over an index whose rows are shuffled (LDOT_OPT_ROW_SHUFFLE): lists are row ranges");
     if (nq == 0) return LDOT_OK;
     LDOT_REQUIRE(queries && list_offsets && probes && out_scores && out_labels, LDOT_EINVAL, "NULL buffer");
     DeviceGuard guard(ix->device);
@@ -1671,6 +1842,7 @@ int ldot_ivf_search(ldot_index_t* ix, ldot_index_t* coarse, const void* queries,
     LDOT_REQUIRE(nq >= 0 && k >= 1 && k <= kMaxK, LDOT_EINVAL, "bad nq / k");
     LDOT_REQUIRE(dtype >= 0 && dtype <= 2, LDOT_EINVAL, "bad dtype %d", dtype);
     LDOT_REQUIRE(out_mem == LDOT_HOST || out_mem == LDOT_DEVICE, LDOT_EINVAL, "bad memory space");
+    LDOT_REQUIRE(!ix->shuffled && !coarse->shuffled, LDOT_ESTATE, "inverted-file search over an index whose rows are shuffled (LDOT_OPT_ROW_SHUFFLE)");
     LDOT_REQUIRE(coarse->d == ix->d + 2 && coarse->device == ix->device, LDOT_EINVAL,
                  "the coarse index must hold (d + 2)-dimensional augmented centroids on the same device");
     const int64_t nlist = coarse->ntotal;

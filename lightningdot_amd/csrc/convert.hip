@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(const void* __restric
                                                            int64_t n_pad, int d, int dpad, int normalize,
                                                            float* __restrict__ dst32,
                                                            uint16_t* __restrict__ dst16, int split,
-                                                           uint16_t* __restrict__ dst16b, int64_t row0b) {
+                                                           uint16_t* __restrict__ dst16b, int64_t row0b, RowPerm perm) {
     // dst16b (optional): the same shadow row in the BLOCKED layout the fused kernel streams — 16 rows x 32 k (1 KiB) blocks,
     // block (g, s) at ((g * nslab + s) * 512 elements, row r % 16 at +32 * (r % 16): one wave-level direct-to-LDS load
     // instruction of the ring engine then reads ONE contiguous KiB (full 128-B lines) instead of 16 half lines.
@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(const void* __restric
         }
         return;
     }
-    const int64_t so = row * ld_src;
+    // (LDOT_OPT_ROW_SHUFFLE: destination row j of an add takes source row (mul * j + add) mod n)
+    const int64_t so = (perm.n > 0 ? (row * perm.mul + perm.add) % perm.n : row) * ld_src;
     float scale = 1.f;
     if (normalize) {
         // fp64 accumulation of the squared norm: matches x / max(||x||, eps) of the oracle to fp32 rounding
@@ -179,6 +180,43 @@ int launch_augment_queries(const void* src, int dtype, int d, int64_t n, int nor
     return LDOT_OK;
 }
 
+// ---- LDOT_OPT_ROW_SHUFFLE: label tables of an index whose rows are stored in a pseudo-random order -------------------------------------
+// label[p] = external label (insertion number) of stored row p, pos[l] = stored row of label l
+__global__ __launch_bounds__(256) void perm_labels_kernel(int32_t* __restrict__ label, int32_t* __restrict__ pos, int64_t base, int64_t n,
+                                                          RowPerm perm) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int64_t sgm = perm.n > 0 ? (j * perm.mul + perm.add) % perm.n : j;   // stored row base + j holds the add's row sgm
+    label[base + j] = (int32_t)(base + sgm);
+    pos[base + sgm] = (int32_t)(base + j);
+}
+
+// re-shuffle of the rows [0, n) already stored: new row j = old row idx[j] = (mul * j + add) mod n, labels follow
+__global__ __launch_bounds__(256) void reshuffle_tables_kernel(const int32_t* __restrict__ old_label, int32_t* __restrict__ new_label,
+                                                               int32_t* __restrict__ new_pos, int32_t* __restrict__ idx, int64_t n, RowPerm perm) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int64_t o = (j * perm.mul + perm.add) % perm.n;
+    const int32_t l = old_label ? old_label[o] : (int32_t)o;
+    idx[j] = (int32_t)o;
+    new_label[j] = l;
+    new_pos[l] = (int32_t)j;
+}
+
+int launch_perm_labels(int32_t* label, int32_t* pos, int64_t base, int64_t n, RowPerm perm, hipStream_t st) {
+    if (n <= 0) return LDOT_OK;
+    hipLaunchKernelGGL(perm_labels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, label, pos, base, n, perm);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+int launch_reshuffle_tables(const int32_t* old_label, int32_t* new_label, int32_t* new_pos, int32_t* idx, int64_t n, RowPerm perm, hipStream_t st) {
+    if (n <= 0) return LDOT_OK;
+    hipLaunchKernelGGL(reshuffle_tables_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, old_label, new_label, new_pos, idx, n, perm);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
 // ---- recovery of overflowed queries (api.hip: redo_flagged): compact copies of the flagged queries' rows / thresholds, and the
 // way back for their finished lists ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gather_rows_f32_kernel(const float* __restrict__ src, int64_t ld, const int32_t* __restrict__ idx,
@@ -249,22 +287,22 @@ int launch_scatter_lists(const float* cs, const int32_t* ci, const float* ctau, 
 
 int launch_convert_rows(const void* src, int dtype, int64_t ld_src, int64_t n, int64_t n_pad, int d, int dpad,
                         int normalize, float* dst32, uint16_t* dst16, int split, uint16_t* dst16b, int64_t row0b,
-                        hipStream_t st) {
+                        hipStream_t st, RowPerm perm) {
     if (n_pad < n) n_pad = n;
     if (n_pad <= 0) return LDOT_OK;
     const dim3 grid((unsigned)((n_pad + 3) / 4)), block(256);
     switch (dtype) {
         case LDOT_F32:
             hipLaunchKernelGGL(convert_rows_kernel<LDOT_F32>, grid, block, 0, st, src, ld_src, n, n_pad, d, dpad, normalize,
-                               dst32, dst16, split, dst16b, row0b);
+                               dst32, dst16, split, dst16b, row0b, perm);
             break;
         case LDOT_BF16:
             hipLaunchKernelGGL(convert_rows_kernel<LDOT_BF16>, grid, block, 0, st, src, ld_src, n, n_pad, d, dpad, normalize,
-                               dst32, dst16, split, dst16b, row0b);
+                               dst32, dst16, split, dst16b, row0b, perm);
             break;
         case LDOT_F16:
             hipLaunchKernelGGL(convert_rows_kernel<LDOT_F16>, grid, block, 0, st, src, ld_src, n, n_pad, d, dpad, normalize,
-                               dst32, dst16, split, dst16b, row0b);
+                               dst32, dst16, split, dst16b, row0b, perm);
             break;
         default:
             set_error("unsupported dtype %d", dtype);

@@ -40,9 +40,17 @@ constexpr int kPoolSubsMax = 1024;     // query-group width 1: 256 row slices x 
 // split != 0: split-bf16 shadow of 3 * dpad per row (1: index side [hi|hi|lo], 2: query side [hi|lo|hi]).
 // dst16b (optional, ARRAY base; row0b = array row of this launch's first row): the same shadow in the blocked layout of
 // the fused kernel (1 KiB blocks of 16 rows x 32 k).
+// perm (LDOT_OPT_ROW_SHUFFLE): n > 0 -> destination row j takes source row (mul * j + add) mod n (mul coprime to n)
+struct RowPerm {
+    int64_t mul = 0, add = 0, n = 0;
+};
 int launch_convert_rows(const void* src, int dtype, int64_t ld_src, int64_t n, int64_t n_pad, int d, int dpad,
                         int normalize, float* dst32, uint16_t* dst16, int split, uint16_t* dst16b, int64_t row0b,
-                        hipStream_t st);
+                        hipStream_t st, RowPerm perm = RowPerm());
+// label tables of a shuffled index: label[p] = external label of stored row p, pos[l] = stored row of label l.  _perm_labels: the rows
+// [base, base + n) of one add; _reshuffle_tables: all stored rows re-ordered (new row j = old row idx[j]; old_label NULL = identity)
+int launch_perm_labels(int32_t* label, int32_t* pos, int64_t base, int64_t n, RowPerm perm, hipStream_t st);
+int launch_reshuffle_tables(const int32_t* old_label, int32_t* new_label, int32_t* new_pos, int32_t* idx, int64_t n, RowPerm perm, hipStream_t st);
 
 // recovery of overflowed queries: dst row i = src row idx[i] (rows [n, n_pad) zero); their thresholds (lowered by a hair); and the
 // way back for finished lists: list / threshold of compact query i -> query idx[i]
@@ -55,7 +63,8 @@ int launch_scatter_lists(const float* cs, const int32_t* ci, const float* ctau, 
 // q16 / x16 are the BLOCKED shadows (launch_convert_rows dst16b), nq_pad a multiple of 256, xrow0 a multiple of 16
 int launch_score_dense(const void* q16, int64_t ldq_elems, int64_t nq_pad, const void* x16, int64_t ldx_elems,
                        int64_t xrow0, int64_t nrows_pad, int dpad, float* S, int64_t lds_elems, int64_t nq_valid,
-                       hipStream_t st, int64_t tile_stride = 256);   // (tile_stride: rows between the starts of consecutive 256-row tiles)
+                       hipStream_t st, int64_t tile_stride = 256,   // (tile_stride: rows between the starts of consecutive 256-row tiles)
+                       hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr);   // (start / stop events attached to the dispatch: LDOT_OPT_PROFILE)
 
 // <= 64 queries (serving): wave-per-16-row-group scan straight from global memory (score_narrow.hip)
 constexpr int kNarrowMaxQueries = 64;    // 1, 2 or 4 groups of 16 queries per scan
@@ -156,11 +165,12 @@ int launch_select_lists(const float* cand_s, const int64_t* cand_l, int64_t part
 // stride_s floats / stride_l int64 apart (the per-destination blocks of a sharded search's send buffer); label_base is added to every valid label
 struct RescoreOut {
     int64_t block_rows, stride_s, stride_l, label_base;
+    const int32_t* label_map;   // (LDOT_OPT_ROW_SHUFFLE) label of stored row r = label_map[r]; NULL: the row number itself
 };
 int launch_rescore(const float* q32, int64_t ldq, const float* x32, int64_t ldx, int dpad, int64_t nq,
                    const float* list_s, const int32_t* list_i, int kp, int k, int do_rescore, const float* floor,
                    float* out_s, int64_t* out_l, hipStream_t st,
-                   const RescoreOut* layout = nullptr);
+                   const RescoreOut* layout = nullptr, const int32_t* label_map = nullptr);
 
 // running maximum of the L2 norms of the rows of a padded fp32 matrix (atomicMax into *out_max, a non-negative float)
 int launch_row_norm_max(const float* x32, int64_t ld, int64_t n, int d, float* out_max, hipStream_t st);
@@ -191,7 +201,8 @@ int scan_order_multiplier(int64_t mod);
 // tiles [scramble_base, scramble_base + ceil(nrows / 384)) of a fixed pseudo-random order of all tiles instead of a contiguous range
 int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_t nrows, const void* q16,
                         int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, uint4* pool, int32_t* pool_cnt,
-                        hipStream_t st, int64_t scramble_tiles = 0, int64_t scramble_base = 0);
+                        hipStream_t st, int64_t scramble_tiles = 0, int64_t scramble_base = 0, hipEvent_t ev_a = nullptr,
+                        hipEvent_t ev_b = nullptr);   // (ev_a / ev_b: start / stop events attached to the dispatch: LDOT_OPT_PROFILE)
 
 // loss path (fp32-input MFMA)
 int launch_sgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* B2, float w, float* C,

@@ -892,6 +892,20 @@ int loss_workspace(hipStream_t st, size_t need, char** out) {
     for (LossWs& w : g_loss_ws)
         if (w.device == dev && w.stream == st) ws = &w;
     if (!ws) {
+        // at most kLossWsPerDevice cached workspaces per device: a caller that creates streams as it goes evicts the oldest one (the
+        // stream it belonged to may be gone: the device is drained before its buffer is freed)
+        constexpr size_t kLossWsPerDevice = 8;
+        size_t mine = 0, oldest = g_loss_ws.size();
+        for (size_t i = 0; i < g_loss_ws.size(); ++i)
+            if (g_loss_ws[i].device == dev) {
+                if (oldest == g_loss_ws.size()) oldest = i;
+                ++mine;
+            }
+        if (mine >= kLossWsPerDevice) {
+            LDOT_HIP_CHECK(hipDeviceSynchronize());
+            if (g_loss_ws[oldest].p) (void)hipFree(g_loss_ws[oldest].p);
+            g_loss_ws.erase(g_loss_ws.begin() + (long)oldest);
+        }
         g_loss_ws.push_back(LossWs{dev, st, nullptr, 0});
         ws = &g_loss_ws.back();
     }

@@ -94,7 +94,8 @@ __global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __rest
         if (lane == 0) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (e0 + u < m) keys[e0 + u] = ((uint64_t)desc_key(s[u]) << 32) | (uint32_t)r[u];
+                if (e0 + u < m)   // (a shuffled index reports — and breaks ties by — the row's label, not its place in the store)
+                    keys[e0 + u] = ((uint64_t)desc_key(s[u]) << 32) | (uint32_t)(lay.label_map ? lay.label_map[r[u]] : r[u]);
         }
     }
     __syncthreads();
@@ -250,9 +251,10 @@ int launch_verify_exact(const float* q32, int64_t ldq, int d, int64_t nq, const 
 
 int launch_rescore(const float* q32, int64_t ldq, const float* x32, int64_t ldx, int dpad, int64_t nq,
                    const float* list_s, const int32_t* list_i, int kp, int k, int do_rescore, const float* floor,
-                   float* out_s, int64_t* out_l, hipStream_t st, const RescoreOut* layout) {
+                   float* out_s, int64_t* out_l, hipStream_t st, const RescoreOut* layout, const int32_t* label_map) {
     if (nq <= 0) return LDOT_OK;
-    const RescoreOut lay = layout ? *layout : RescoreOut{0, 0, 0, 0};
+    RescoreOut lay = layout ? *layout : RescoreOut{0, 0, 0, 0, nullptr};
+    if (label_map) lay.label_map = label_map;
     if (nq <= 128)
         hipLaunchKernelGGL(rescore_kernel<1024>, dim3((unsigned)nq), dim3(1024), 0, st, q32, ldq, x32, ldx, dpad, list_s,
                            list_i, kp, k, do_rescore, floor, out_s, out_l, lay);

@@ -24,6 +24,8 @@
 
 #include <type_traits>
 
+#include <hip/hip_ext.h>
+
 #include "gemm_ring.h"
 #include "kernels.h"
 
@@ -176,7 +178,8 @@ __global__ __launch_bounds__(kRingThreads, (CB <= 4 ? 4 : 2)) void score_dense_t
 
 template <int CB, int STAGES>
 static int launch_dense_variant(const void* q16, int64_t ld_elems, int64_t nq_pad, const void* x16, int64_t xrow0, int64_t nrows_pad,
-                                int dpad, float* S, int64_t lds_elems, int64_t nq_valid, hipStream_t st, int64_t tile_stride, bool* attr_set) {
+                                int dpad, float* S, int64_t lds_elems, int64_t nq_valid, hipStream_t st, int64_t tile_stride, bool* attr_set, hipEvent_t ev_a,
+                                hipEvent_t ev_b) {
     using Geo = DenseGeom<CB, STAGES>;
     constexpr int kWgPerCu = CB <= 4 ? 2 : 1;
     const int tiles_q = (int)(nq_pad / Geo::kQ), tiles_n = (int)(nrows_pad / Geo::kRows);
@@ -184,8 +187,8 @@ static int launch_dense_variant(const void* q16, int64_t ld_elems, int64_t nq_pa
     auto kern = score_dense_t16_kernel<CB, STAGES>;
     LDOT_HIP_CHECK(set_max_dynamic_lds_once((const void*)kern, Geo::kLds, attr_set));
     const int grid = (int)std::min<int64_t>(nunits, 256 * kWgPerCu);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kRingThreads), Geo::kLds, st, (const char*)x16, ld_elems * 2, xrow0, tiles_n, tile_stride,
-                       (const char*)q16, tiles_q, dpad / kRBK, S, lds_elems, nq_valid);
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kRingThreads), Geo::kLds, st, ev_a, ev_b, 0, (const char*)x16, ld_elems * 2, xrow0, tiles_n,
+                          tile_stride, (const char*)q16, tiles_q, dpad / kRBK, S, lds_elems, nq_valid);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }
@@ -203,7 +206,7 @@ static double dense_cost(int64_t nq_pad, int64_t nrows_pad, int cb, double f4) {
 // q16 / x16 are the BLOCKED shadows; nq_pad = rows of the query shadow (multiple of 256, zero padded)
 int launch_score_dense(const void* q16, int64_t ldq_elems, int64_t nq_pad, const void* x16, int64_t ldx_elems,
                        int64_t xrow0, int64_t nrows_pad, int dpad, float* S, int64_t lds_elems, int64_t nq_valid,
-                       hipStream_t st, int64_t tile_stride) {
+                       hipStream_t st, int64_t tile_stride, hipEvent_t ev_a, hipEvent_t ev_b) {
     if (nq_pad <= 0 || nrows_pad <= 0) return LDOT_OK;
     LDOT_REQUIRE(ldq_elems == ldx_elems, LDOT_EINVAL, "index and query shadows must have the same row stride");
     LDOT_REQUIRE(xrow0 % 16 == 0 && nrows_pad % kRBN == 0 && nq_pad % 256 == 0 && tile_stride % 16 == 0 && tile_stride >= kRBN, LDOT_EINVAL,
@@ -224,8 +227,8 @@ int launch_score_dense(const void* q16, int64_t ldq_elems, int64_t nq_pad, const
     if (force == 4 || force == 8) cb = force;
 #endif
     if (cb == 4)
-        return launch_dense_variant<4, 3>(q16, ldq_elems, nq_pad, x16, xrow0, nrows_pad, dpad, S, lds_elems, nq_valid, st, tile_stride, attr_set4);
-    return launch_dense_variant<8, 4>(q16, ldq_elems, nq_pad, x16, xrow0, nrows_pad, dpad, S, lds_elems, nq_valid, st, tile_stride, attr_set8);
+        return launch_dense_variant<4, 3>(q16, ldq_elems, nq_pad, x16, xrow0, nrows_pad, dpad, S, lds_elems, nq_valid, st, tile_stride, attr_set4, ev_a, ev_b);
+    return launch_dense_variant<8, 4>(q16, ldq_elems, nq_pad, x16, xrow0, nrows_pad, dpad, S, lds_elems, nq_valid, st, tile_stride, attr_set8, ev_a, ev_b);
 }
 
 }  // namespace ldot

@@ -56,6 +56,8 @@
 
 #include <type_traits>
 
+#include <hip/hip_ext.h>
+
 #include "gemm_ring.h"
 #include "kernels.h"
 
@@ -202,7 +204,10 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
     const int p0 = (int)(((int64_t)(so.base + t0) * so.mul) % so.mod);
     int l_q = g0, l_t = t0, l_p = p0, l_k = 0;
     RingSrc sa, sb;
-    sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)l_p * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
+    // (measurement, ablation builds: VAR & 64 aliases the row tiles onto 32 tiles — the row stream comes from the Infinity Cache instead of
+    // HBM —, VAR & 512 onto ONE tile per XCD — rows and query panels L2-resident: the bound of any locality work)
+    auto phys = [&](int p) { return (VAR & 512) ? xcd : (VAR & 64) ? (p & 31) : p; };
+    sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)phys(l_p) * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
     sb.rsrc = ring_make_rsrc_n(Q16 + (int64_t)(qsub + l_q * qg) * kRBN * ldq_b, kRBN * ldq_b);
     int64_t issued = 0;
     const int krot = (VAR & 32) ? (nsub * nk) / nstream : 0;
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
                     } while (l_t >= ntiles);
                     sb.rsrc = ring_make_rsrc_n(Q16 + (int64_t)(qsub + l_q * qg) * kRBN * ldq_b, kRBN * ldq_b);
                 }
-                sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)l_p * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
+                sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)phys(l_p) * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
             }
         }
     };
@@ -453,7 +458,7 @@ int scan_order_multiplier(int64_t mod) {
 
 int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_t nrows, const void* q16,
                         int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, uint4* pool, int32_t* pool_cnt,
-                        hipStream_t st, int64_t scramble_tiles, int64_t scramble_base) {
+                        hipStream_t st, int64_t scramble_tiles, int64_t scramble_base, hipEvent_t ev_a, hipEvent_t ev_b) {
     if (nrows <= 0 || nq_pad <= 0) return LDOT_OK;
     LDOT_REQUIRE(ldx_elems == ldq_elems, LDOT_EINVAL, "index and query shadows must have the same row stride");
     auto rk = score_filter_t16_kernel<0>;
@@ -471,6 +476,8 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     if (variant == 8) rk = score_filter_t16_kernel<8>;
     if (variant == 32) rk = score_filter_t16_kernel<32>;      // K walk rotated per row stream (query panels L2-resident?)
     if (variant == 48) rk = score_filter_t16_kernel<48>;      // ... with tau = +inf
+    if (variant == 81) rk = score_filter_t16_kernel<81>;      // no filter, row tiles aliased onto 32 tiles (rows from the Infinity Cache)
+    if (variant == 529) rk = score_filter_t16_kernel<529>;    // no filter, one row tile per XCD (everything L2-resident)
     if (variant == 128) rk = score_filter_t16_kernel<128>;    // row blocks NOT pinned in program order (the scheduler sinks the fragment loads)
     LDOT_HIP_CHECK(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<6>::kLds));
 #else
@@ -499,9 +506,10 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
         so.da = (int)nslices;
         so.dn = (int)ntiles;
     }
-    hipLaunchKernelGGL(rk, dim3(256), dim3(kRingThreads), RingGeom<6>::kLds, st, (const char*)x16, ldx_elems * 2, row0,
-                       nrows, (const char*)q16, ldq_elems * 2, (int)(nq_pad / kRBN), dpad / kRBK, tau, pool, pool_cnt,
-                       qg_log2, so);
+    // (ev_a / ev_b, LDOT_OPT_PROFILE: start / stop events attached to THIS dispatch — its own timestamps, no marker packets around it)
+    hipExtLaunchKernelGGL(rk, dim3(256), dim3(kRingThreads), RingGeom<6>::kLds, st, ev_a, ev_b, 0, (const char*)x16, ldx_elems * 2, row0,
+                          nrows, (const char*)q16, ldq_elems * 2, (int)(nq_pad / kRBN), dpad / kRBK, tau, pool, pool_cnt,
+                          qg_log2, so);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

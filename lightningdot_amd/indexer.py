@@ -320,6 +320,18 @@ class FlatIPIndex:
         L.check(self._lib.ldot_index_last_stats(self._h, a))
         return dict(fused_candidates=a[0], overflowed_queries=a[1], dense_pairs=a[2], fused_pairs=a[3])
 
+    _PATHS = ('none', 'narrow', 'dense', 'fused_one_block', 'fused')
+    _THRESHOLDS = ('n/a', 'guaranteed', 'optimistic', 'pooled')
+    _ORDERS = ('n/a', 'storage', 'scrambled_tiles')
+    _ROWS = ('as_added', 'shuffled_at_add', 'reshuffled_by_library')
+
+    def last_regime(self):
+        """Which regime the last search ran in + the adaptive state of the handle (ldot_index_last_regime)."""
+        a = (ctypes.c_int64 * 8)()
+        L.check(self._lib.ldot_index_last_regime(self._h, a))
+        return dict(path=self._PATHS[a[0]], thresholds=self._THRESHOLDS[a[1]], scan_order=self._ORDERS[a[2]], redone_queries=a[3],
+                    guaranteed_searches_left=a[4], narrow_skips_left=a[5], scrambled_auto=bool(a[6]), rows=self._ROWS[a[7]])
+
     def last_profile(self):
         a = (ctypes.c_double * 4)()
         L.check(self._lib.ldot_index_last_profile(self._h, a))

@@ -107,7 +107,7 @@ class DenseIVFFlatIndexer(DenseIndexer):
         # (cluster-sorted rows are the order the optimistic thresholds of the exact scan must not assume away: a query's best rows
         # sit together, often early — the scan would flag and redo most queries; the library also backs off by itself.  The scrambled
         # scan order does not help here: it permutes 384-row tiles, and a list of ~250 rows IS a tile)
-        self.index.set_option(L.OPT_OPTIMISTIC, 0)
+        self._configure_row_index()
         self.nlist, self.nprobe = nlist, nprobe
         self.train_iters, self.train_rows_per_list, self.seed = train_iters, train_rows_per_list, seed
         # longest list allowed (None: 4 x the mean list length, at least 64 rows, when nlist is chosen automatically; 0: lists as
@@ -247,6 +247,11 @@ class DenseIVFFlatIndexer(DenseIndexer):
         ids = self.index_id_to_db_id
         return [([ids[i] for i in row], s[j]) for j, row in enumerate(l)]        # (-1 -> last id, the reference's :85 behaviour)
 
+    def _configure_row_index(self):
+        """options of the row store (also re-applied to a freshly loaded index: ldot_index_load returns the defaults)"""
+        self.index.set_option(L.OPT_OPTIMISTIC, 0)
+        self.index.set_option(L.OPT_ROW_SHUFFLE, 2)      # lists are row ranges: the store must never be re-ordered
+
     # ---- persistence: the reference's two files + the clustering in the meta file ---------------------------------------------------
     def serialize(self, file: str):
         self.index.save(file + '.index.dpr')
@@ -257,6 +262,7 @@ class DenseIVFFlatIndexer(DenseIndexer):
     def deserialize_from(self, file: str):
         import torch
         self.index = FlatIPIndex.load(file + '.index.dpr')
+        self._configure_row_index()
         with open(file + '.index_meta.dpr', 'rb') as f:
             m = pickle.load(f)
         self.index_id_to_db_id = m['ids']

@@ -84,6 +84,12 @@ class ShardedFlatIndexer:
         self._bad_host = None                    # pinned int32: the check's verdict
         self._verdict = None                     # (work handle, counts, k') of the search in progress
         self._blocks = {}                        # send buffers of the blocked exchange, by size
+        # profile_phases = True: every search leaves the device time of its phases in last_phases (ms, by name: query all-gather,
+        # candidate pass, statistics all-reduce, floor, re-score, list exchange, merge, verdict) — events on the search's stream, read
+        # after the search's own synchronisation; on a backend without device collectives the exchange phases include the host copies
+        self.profile_phases = False
+        self.last_phases: dict = {}
+        self._marks: list = []
         self._custom = local_search is not None
         self.local = None if self._custom else DenseFlatIndexer(vector_sz, normalize=normalize)
         self._local_search = local_search
@@ -107,6 +113,7 @@ class ShardedFlatIndexer:
             self.local.index_tensor(db_ids, vectors)
         self.n_local += n
         self.local_ids.extend(db_ids)
+        self._id_kind_cache = None               # (the wire format of resolve_ids is decided over ALL local ids: decide again)
         dev = self._tensor_device()
         mine = torch.tensor([self.n_local], dtype=torch.int64, device=dev)
         sizes = [torch.empty_like(mine) for _ in range(self.world)]
@@ -218,6 +225,23 @@ class ShardedFlatIndexer:
         return [[table[g if g >= 0 else self.ntotal - 1] for g in r] for r in rows]
 
     # ---- search ------------------------------------------------------------------------------------------
+    def _mark(self, name: str) -> None:
+        """end of phase `name` on the current stream (profile_phases)"""
+        if self.profile_phases and torch.cuda.is_available():
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._marks.append((name, ev))
+
+    def _collect_phases(self) -> None:
+        if not self.profile_phases or len(self._marks) < 2:
+            return
+        torch.cuda.current_stream().synchronize()
+        ph: dict = {}
+        for (_, a), (name, b) in zip(self._marks[:-1], self._marks[1:]):
+            ph[name] = ph.get(name, 0.0) + a.elapsed_time(b)
+        ph['total'] = self._marks[0][1].elapsed_time(self._marks[-1][1])
+        self.last_phases = ph
+
     def _gather_queries(self, q: torch.Tensor) -> Tuple[torch.Tensor, List[int]]:
         # query counts travel as one small tensor (no pickling; one host sync)
         nccl = dist.get_backend(self.group) == 'nccl'
@@ -287,7 +311,11 @@ class ShardedFlatIndexer:
             pooled = False
         self.last_search = {'pooled': pooled, 'repeated': False}
         self._verdict = None
+        self._marks = []
+        self._mark('start')
         res = self._search(local_queries, k, out, pooled)
+        if not (pooled and self._verdict is not None):
+            self._collect_phases()
         if pooled and self._verdict is not None:
             # the counts were all-reduced (SUM) while the re-score, the list exchange and the merge ran
             work, count, kp = self._verdict
@@ -296,18 +324,24 @@ class ShardedFlatIndexer:
             if self._bad_host is None:
                 self._bad_host = torch.zeros(1, dtype=torch.int32).pin_memory()
             self._bad_host.copy_((count < kp).sum(dtype=torch.int32).reshape(1), non_blocking=True)
+            self._mark('verdict')
             torch.cuda.current_stream().synchronize()
+            self._collect_phases()
             if int(self._bad_host[0]) > 0:       # the same number on every rank: all of them repeat the search
                 self.last_search['repeated'] = True
                 self._pooled_backoff = self._pooled_penalty
                 self._pooled_penalty = min(2 * self._pooled_penalty, 1024)
                 self._verdict = None
-                return self._search(local_queries, k, out, False)
+                res = self._search(local_queries, k, out, False)
+                self._mark('repeat')
+                self._collect_phases()
+                return res
             self._pooled_penalty = 16
         return res
 
     def _search(self, local_queries: torch.Tensor, k: int, out, pooled: bool):
         q_all, counts = self._gather_queries(local_queries.float())
+        self._mark('all_gather_queries')
         if self._custom:
             s, l = self._local_search(q_all, k)
         else:
@@ -324,24 +358,34 @@ class ShardedFlatIndexer:
             ix = self.local.index
             if self.world > 1 and self.exchange_warmup:
                 stat = ix.search_warmup(q_all, k, self.world)
+                self._mark('candidate_pass')
                 self._all_reduce_max(stat)
+                self._mark('all_reduce_statistics')
                 tau = ix.search_scan(stat)
+                self._mark('candidate_pass')
                 self._all_reduce_max(tau)
+                self._mark('all_reduce_statistics')
             elif q_all.is_cuda:   # (also with ONE rank: the same calls and collectives, which is how RCCL gets exercised on a one-GPU box)
                 stat = ix.search_begin_shard(q_all, k, self.world, self.ntotal if pooled else 0, share=self._share())
+                self._mark('candidate_pass')
                 self._all_reduce_max(stat)
+                self._mark('all_reduce_statistics')
                 tau, count, kp = ix.shard_floor(stat)
+                self._mark('floor')
                 if pooled:
                     # the verdict (off the critical path): k' rows at or above the largest level of any shard, all ranks together
                     self._verdict = (self._all_reduce_sum_async(count), count, kp)
             else:
                 tau = ix.search_begin(q_all, k)
+                self._mark('candidate_pass')
                 if self.world > 1:
                     self._all_reduce_max(tau)
+                    self._mark('all_reduce_statistics')
             mx = max(counts)
             if (self.exchange == 'all_to_all' and self._merge is _hip_merge and min(counts) == mx and mx > 0 and q_all.is_cuda):
                 return self._finish_blocked(ix, tau, mx, k, out)
             s, l = ix.search_finish(tau)
+            self._mark('rescore')
         l = torch.where(l >= 0, l + self.offsets[self.rank], l)          # local row -> global row, padding stays -1
         starts = [0]
         for c in counts:
@@ -360,6 +404,7 @@ class ShardedFlatIndexer:
                     send_s[r, :counts[r]] = s[starts[r]:starts[r + 1]]
                     send_l[r, :counts[r]] = l[starts[r]:starts[r + 1]]
             recv_s, recv_l = self._all_to_all(send_s.contiguous()), self._all_to_all(send_l.contiguous())
+            self._mark('exchange_lists')
             part_s, part_l = recv_s[:, :nq_mine], recv_l[:, :nq_mine]
         else:
             gs = [torch.empty_like(s) for _ in range(self.world)]
@@ -368,14 +413,18 @@ class ShardedFlatIndexer:
             dist.all_gather(gl, l.contiguous(), group=self.group)
             part_s = torch.stack([t[mine] for t in gs], 0)
             part_l = torch.stack([t[mine] for t in gl], 0)
+            self._mark('exchange_lists')
         if nq_mine == 0:
             return s.new_empty((0, k)), l.new_empty((0, k))
         if out is not None:
             res = self._merge(part_s.contiguous(), part_l.contiguous(), k, out=out)
+            self._mark('merge')
             if self._verdict is None:            # (a pooled search synchronises once, after its verdict)
                 torch.cuda.current_stream().synchronize()
             return res
-        return self._merge(part_s.contiguous(), part_l.contiguous(), k)
+        res = self._merge(part_s.contiguous(), part_l.contiguous(), k)
+        self._mark('merge')
+        return res
 
     def _finish_blocked(self, ix, tau, mx: int, k: int, out):
         """Equal query slices: the re-score kernel writes every destination rank's block of the send buffer (scores + global labels),
@@ -389,7 +438,9 @@ class ShardedFlatIndexer:
             send = torch.empty((self.world, block_bytes), dtype=torch.uint8, device=dev)
             self._blocks = {(self.world, block_bytes): send}
         ix.search_finish_blocked(tau, send, mx, block_bytes, self.offsets[self.rank])
+        self._mark('rescore')
         recv = self._all_to_all(send)
+        self._mark('exchange_lists')
         if out is not None:
             out_s, out_l = out
             if not (out_s.is_pinned() and out_l.is_pinned() and out_s.is_contiguous() and out_l.is_contiguous()
@@ -402,6 +453,7 @@ class ShardedFlatIndexer:
         L.check(lib.ldot_merge_topk_blocked(ctypes.c_void_p(recv.data_ptr()), self.world, mx, block_bytes, mx, k, k,
                                             ctypes.c_void_p(out_s.data_ptr()), ctypes.c_void_p(out_l.data_ptr()),
                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        self._mark('merge')
         if out is not None and self._verdict is None:   # (a pooled search synchronises once, after its verdict)
             torch.cuda.current_stream().synchronize()
         return out_s, out_l

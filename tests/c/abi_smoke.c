@@ -56,7 +56,35 @@ int main(void) {
         if (l[i * k] != besti || fabs(s[i * k] - best) > 1e-3) { fprintf(stderr, "query %d: got %lld %.6f want %d %.6f\n", i, (long long)l[i * k], s[i * k], besti, best); ++bad; }
         for (int j = 1; j < k; ++j) if (s[i * k + j] > s[i * k + j - 1]) { fprintf(stderr, "query %d not sorted\n", i); ++bad; }
     }
+    /* which regime did that search run in?  (9 queries: the narrow search; nothing redone; rows stored as added) */
+    int64_t reg[8];
+    if (ldot_index_last_regime(ix, reg) != LDOT_OK || reg[0] != 1 || reg[3] != 0 || reg[7] != 0) {
+        fprintf(stderr, "regime: path %lld redone %lld rows %lld\n", (long long)reg[0], (long long)reg[3], (long long)reg[7]);
+        ++bad;
+    }
     ldot_index_destroy(ix);
+
+    /* LDOT_OPT_ROW_SHUFFLE = 1: a C caller's rows are stored in a pseudo-random order inside the library; labels, scores and
+     * ldot_index_get_rows keep referring to insertion order */
+    ldot_index_t* sx = NULL;
+    float* s2 = (float*)malloc(sizeof(float) * nq * k);
+    int64_t* l2 = (int64_t*)malloc(sizeof(int64_t) * nq * k);
+    float* back = (float*)malloc(sizeof(float) * 10 * d);
+    if (ldot_index_create(d, &sx) != LDOT_OK || ldot_index_set_option(sx, LDOT_OPT_ROW_SHUFFLE, 1) != LDOT_OK ||
+        ldot_index_add(sx, x, 3000, LDOT_F32, LDOT_HOST, 0, NULL) != LDOT_OK ||
+        ldot_index_add(sx, x + 3000 * d, n - 3000, LDOT_F32, LDOT_HOST, 0, NULL) != LDOT_OK ||
+        ldot_index_search(sx, q, nq, LDOT_F32, LDOT_HOST, 0, k, s2, l2, LDOT_HOST, NULL) != LDOT_OK ||
+        ldot_index_get_rows(sx, 2995, 10, back, LDOT_HOST, NULL) != LDOT_OK || ldot_index_last_regime(sx, reg) != LDOT_OK) {
+        fprintf(stderr, "shuffled index: %s\n", ldot_last_error());
+        return 1;
+    }
+    for (int i = 0; i < nq * k; ++i)
+        if (l2[i] != l[i] || s2[i] != s[i]) { fprintf(stderr, "shuffled index: result %d differs (%lld %.6f vs %lld %.6f)\n", i, (long long)l2[i], s2[i], (long long)l[i], s[i]); ++bad; break; }
+    for (int i = 0; i < 10 * d; ++i)
+        if (back[i] != x[2995 * d + i]) { fprintf(stderr, "shuffled index: get_rows does not return rows by label\n"); ++bad; break; }
+    if (reg[7] != 1) { fprintf(stderr, "shuffled index: regime says rows = %lld\n", (long long)reg[7]); ++bad; }
+    if (ldot_index_set_option(sx, LDOT_OPT_ROW_SHUFFLE, 2) == LDOT_OK) { fprintf(stderr, "un-shuffling a shuffled index accepted\n"); ++bad; }
+    ldot_index_destroy(sx);
     printf(bad ? "FAIL\n" : "abi_smoke ok\n");
     return bad ? 1 : 0;
 }

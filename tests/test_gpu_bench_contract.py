@@ -64,3 +64,10 @@ def test_sharded_path_on_rccl_with_one_rank():
              '--force-sharded', '--backend', 'nccl')
     assert d['n_gpus'] == 1 and d['ranks_seen'] == 1 and d['recall@1'] == 1.0 and d['results_sorted'] is True
     assert d['overflowed_queries'] == 0 and d['roofline']['kernel_ms_per_step'] <= d['ms_per_step']
+    # per-phase device times of the exchange: every phase of the default path is there, they add up to the total, the total fits the step
+    ph = d['phases_ms_per_step']
+    for name in ('all_gather_queries', 'candidate_pass', 'all_reduce_statistics', 'floor', 'rescore', 'exchange_lists', 'merge', 'total'):
+        assert name in ph and ph[name] >= 0.0, name
+    parts = sum(v for k, v in ph.items() if k != 'total')
+    assert abs(parts - ph['total']) <= 0.05 * ph['total'] and ph['total'] <= d['ms_per_step'] * 1.02
+    assert ph['candidate_pass'] >= d['roofline']['kernel_ms_per_step'] * 0.98

@@ -18,6 +18,7 @@
 //   data      R  : N(0,1) random bf16 operands;  Z: all-zero operands (the DVFS give-back the guide describes)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <string.h>
 #include <stdlib.h>
 
 #include <random>
@@ -939,6 +940,10 @@ int main(int argc, char** argv) {
     CK(hipMalloc((void**)&ticks, 512 * 8));
     CK(hipMemcpy(src, h.data(), region * 8, hipMemcpyHostToDevice));
     CK(hipMemset(zsrc, 0, region * 8));
+    if (argc > 2 && !strcmp(argv[2], "t16b")) {   // only the product kernel's slab loop (PMC runs: tools/pmc_waits.sh)
+        run16b<2, 2>("T16B burst, A ring of TWO     random", src, region, sink, ticks, target_ms);
+        return 0;
+    }
     for (int rep = 0; rep < 1; ++rep) {
         printf("---- repetition %d (target %.1f ms per launch) ----\n", rep, target_ms);
         run16b<1>("T16B (4x2 waves) mfma+ds_read  random", src, region, sink, ticks, target_ms);
