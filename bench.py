@@ -283,15 +283,17 @@ def main():
             flat.search(q_host, K)
         out['pcie_inclusive'] = {'value': Q * 2 / (time.perf_counter() - t0), 'unit': 'queries/s',
                                  'note': 'fp32 queries in pageable host memory -> scores+labels in host memory'}
-    if not args.no_cpu_baseline and not sharded:
-        out['cpu_baseline'], out['parity_vs_cpu_fp32'] = cpu_baseline(x_local, q_all, K, args.cpu_sample_queries,
-                                                                      s_np, l_np)
-        # (the CPU figures at the S2 shapes are part of `bench.py --workload flickr|coco`: each of those lines carries its own)
+    # (secondary shapes BEFORE the CPU baseline: its 256 host threads keep spinning for a while and slow the host side of whatever follows —
+    # a COCO-shape evaluation read 6.4 ms after it against 2.4 ms before, profiles/r05_mid_bench.json)
     if not sharded and not args.no_secondary:
         try:
             out['secondary'] = secondary_metrics(dev, flat, D, K)
         except Exception as e:                       # the headline line must not depend on the secondary shapes
             out['secondary'] = {'error': f'{type(e).__name__}: {e}'}
+    if not args.no_cpu_baseline and not sharded:
+        out['cpu_baseline'], out['parity_vs_cpu_fp32'] = cpu_baseline(x_local, q_all, K, args.cpu_sample_queries,
+                                                                      s_np, l_np)
+        # (the CPU figures at the S2 shapes are part of `bench.py --workload flickr|coco`: each of those lines carries its own)
     print(json.dumps(out), flush=True)
     if sharded:
         dist.destroy_process_group()

@@ -106,10 +106,13 @@ def test_row_shuffle_engages_itself_when_both_tile_orders_fail(L):
     assert seen[2][1]['rows'] == 'reshuffled_by_library' and seen[2][0] == 0 and seen[2][1]['thresholds'] == 'optimistic'
     assert seen[3][0] == 0 and seen[3][1]['guaranteed_searches_left'] == 0
     # rows added afterwards are shuffled too, labels keep counting in insertion order
-    extra = 2.0 * x[:5000]                                        # (2x.2x > 2x.x: every extra row is its own best match)
+    extra = (2.0 * x[:5000]).astype(np.float32)
     ix.add(extra)
-    s, l = ix.search(extra[:300].copy(), 1)
-    np.testing.assert_array_equal(l[:, 0], np.arange(len(x), len(x) + 300))
+    ref.add(extra)
+    s, l = ix.search(extra[:300].copy(), 5)
+    sr, lr = ref.search(extra[:300].copy(), 5)
+    _same_results(sr, lr, s, l)
+    assert (l >= len(x)).any() and ix.last_regime()['rows'] == 'reshuffled_by_library'
     np.testing.assert_array_equal(ix.get_rows(len(x), 5), extra[:5])
     # LDOT_OPT_ROW_SHUFFLE = 2: never — the index ends on guaranteed thresholds as in round 4
     off = FlatIPIndex(x.shape[1])
