@@ -53,7 +53,7 @@ extern "C" {
 /* search-mode flags (ldot_index_set_option(LDOT_OPT_MODE, ...)) */
 #define LDOT_MODE_AUTO 0   /* chosen per search from the batch and index size: <= 64 queries the narrow search (one pass over the
                             * bf16 index at HBM speed + run-maxima selection; <= 16 queries always, 17..64 when k' fits its candidate
-                            * buffer); otherwise the fused filter from 32768 rows (from 16384 rows for >= 16384 queries), with one query
+                            * buffer); otherwise the fused filter from 32768 rows (from 20480 rows for >= 4096 queries, from 8192 rows for >= 16384), with one query
                             * block for 65..256 queries; the dense path below that */
 #define LDOT_MODE_DENSE 1  /* materialise score chunks + streaming top-k' select */
 #define LDOT_MODE_FUSED 2  /* fused MFMA score + threshold filter (never materialises Q x N) */

@@ -1291,6 +1291,17 @@ static int stage_unstaged_queries(ldot_index* ix, int64_t nq, hipStream_t st) {
                                (uint16_t*)ix->w_q16b.p, 0, st);
 }
 
+// LDOT_MODE_AUTO: fused scan or dense chunks?  The dense path writes and re-reads 8 bytes per (query, row) pair, the fused scan pays a
+// warm-up, a pool select per launch and its admissions: it wins from 32 768 rows for any batch, from ~20 000 rows for >= 4096 queries and
+// from ~8 000 rows for >= 16 384 (tools/auto_threshold.py with the round-5 dense kernel, profiles/r05_auto_threshold.txt: 5 000 x 24 576
+// 0.759 -> 0.715 ms, 25 000 x 8 192 2.16 -> 2.06, 25 000 x 16 384 2.94 -> 2.56).  <= 16 queries whose narrow search is not available take
+// the wide dense scan at every size (tools/serving_latency.py).
+static bool auto_fused(const ldot_index* ix, int64_t nq) {
+    if (nq <= 16 && narrow_ok(ix, nq)) return false;
+    const int64_t n = ix->ntotal;
+    return n >= 32768 || (n >= 20480 && nq >= 4096) || (n >= 8192 && nq >= 16384);
+}
+
 // defer_check: enqueue a fused scan speculatively and leave the overflow check to the caller's own synchronisation point
 // warm_only (ldot_index_search_warmup): stop after the local warm-up of a fused scan, leave the statistics the ranks exchange in
 // stat_out (2 * nq floats) and remember the path in split_path; ldot_index_search_scan continues from there
@@ -1370,10 +1381,7 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
     if (!narrow && (rc = launch_init_lists((float*)ix->w_ls.p, (int32_t*)ix->w_li.p, nq_pad * kp, tau, nq, nq_pad, st))) return rc;
 
     if (warm_only) {
-        const bool fused = !narrow && ix->ntotal > 0 &&
-                           (ix->mode == LDOT_MODE_FUSED ||
-                            (ix->mode == LDOT_MODE_AUTO && !(nq <= 16 && narrow_ok(ix, nq)) &&
-                             (ix->ntotal >= 32768 || (ix->ntotal >= 16384 && nq >= 16384))));
+        const bool fused = !narrow && ix->ntotal > 0 && (ix->mode == LDOT_MODE_FUSED || (ix->mode == LDOT_MODE_AUTO && auto_fused(ix, nq)));
         if (fused) {
             if ((rc = fused_scan(ix, nq, nq_pad, kp, st, 1))) return rc;
             // m = ceil(k' / parts): every rank has m rows at or above its own m-th best warm-up score
@@ -1406,9 +1414,7 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
         // <= 16 queries whose narrow search is not available (large k', or the index recently filled its candidate buffer): one pass
         // over the index at HBM speed (score_narrow.hip) + segmented streaming select still beats the fused scan's warm-up / filter /
         // pool-select chain at every index size (tools/serving_latency.py)
-        const bool fused = ix->mode == LDOT_MODE_FUSED ||
-                           (ix->mode == LDOT_MODE_AUTO && !(nq <= 16 && narrow_ok(ix, nq)) &&
-                            (ix->ntotal >= 32768 || (ix->ntotal >= 16384 && nq >= 16384)));
+        const bool fused = ix->mode == LDOT_MODE_FUSED || (ix->mode == LDOT_MODE_AUTO && auto_fused(ix, nq));
         ix->last_path = !fused ? 2 : nq <= kFewSelectMaxQueries ? 3 : 4;
         if (fused) {
             if ((rc = fused_scan(ix, nq, nq_pad, kp, st))) return rc;

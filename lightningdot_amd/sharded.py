@@ -303,7 +303,10 @@ class ShardedFlatIndexer:
     def search(self, local_queries: torch.Tensor, k: int, out=None):
         """-> (scores [nq_local, k] fp32, GLOBAL row labels [nq_local, k] int64) for the local queries.  ``out`` = (scores, labels)
         pinned host tensors: the merge writes the final lists there directly and the call returns them after a stream
-        synchronisation (HIP merge only)."""
+        synchronisation (HIP merge only).
+        Collective: every rank calls it, in the same order.  An exception raised here on ONE rank leaves the others inside a collective and
+        the ranks' back-off state (``_pooled_backoff``) out of step: treat it as fatal for the process group (tear it down and
+        re-create the indexers), do not catch it and retry."""
         pooled = (not self._custom and self.world > 1 and self.pooled_statistics and not self.exchange_warmup
                   and local_queries.is_cuda)
         if pooled and self._pooled_backoff > 0:

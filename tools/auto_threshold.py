@@ -8,9 +8,9 @@ def t(ix, q, k, n=5):
     ix.search_tensors(q, k); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): ix.search_tensors(q, k)
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-for n in (8192, 16384, 20480, 24576, 32768, 49152):
+for n in (5120, 8192, 12288, 16384, 20480, 24576, 32768, 49152):
     x = torch.randn(n, 768, device='cuda')
-    for nq in (64, 1024, 5000, 25000):
+    for nq in (300, 1024, 5000, 25000):
         q = torch.randn(nq, 768, device='cuda')
         res = []
         for mode in (1, 2):
