@@ -590,8 +590,7 @@ static void prof_begin(ldot_index* ix, hipStream_t st, double flops, double byte
     (void)hipEventRecord(ev.a, st);
     ix->prof_events.push_back(ev);
 }
-// the same for a kernel whose launcher attaches the events to the dispatch itself (hipExtLaunchKernel): nothing is recorded on the stream,
-// *a / *b stay NULL when profiling is off
+// the same for a kernel whose launcher records the two events itself, right around its launch; *a / *b stay NULL when profiling is off
 static void prof_attach(ldot_index* ix, double flops, double bytes, hipEvent_t* a, hipEvent_t* b) {
     *a = *b = nullptr;
     if (!ix->profile) return;

@@ -64,7 +64,7 @@ int launch_scatter_lists(const float* cs, const int32_t* ci, const float* ctau, 
 int launch_score_dense(const void* q16, int64_t ldq_elems, int64_t nq_pad, const void* x16, int64_t ldx_elems,
                        int64_t xrow0, int64_t nrows_pad, int dpad, float* S, int64_t lds_elems, int64_t nq_valid,
                        hipStream_t st, int64_t tile_stride = 256,   // (tile_stride: rows between the starts of consecutive 256-row tiles)
-                       hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr);   // (start / stop events attached to the dispatch: LDOT_OPT_PROFILE)
+                       hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr);   // (start / stop events recorded around the launch: LDOT_OPT_PROFILE)
 
 // <= 64 queries (serving): wave-per-16-row-group scan straight from global memory (score_narrow.hip)
 constexpr int kNarrowMaxQueries = 64;    // 1, 2 or 4 groups of 16 queries per scan
@@ -202,7 +202,7 @@ int scan_order_multiplier(int64_t mod);
 int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_t nrows, const void* q16,
                         int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, uint4* pool, int32_t* pool_cnt,
                         hipStream_t st, int64_t scramble_tiles = 0, int64_t scramble_base = 0, hipEvent_t ev_a = nullptr,
-                        hipEvent_t ev_b = nullptr);   // (ev_a / ev_b: start / stop events attached to the dispatch: LDOT_OPT_PROFILE)
+                        hipEvent_t ev_b = nullptr);   // (ev_a / ev_b: start / stop events recorded around the launch: LDOT_OPT_PROFILE)
 
 // loss path (fp32-input MFMA)
 int launch_sgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* B2, float w, float* C,

@@ -24,8 +24,6 @@
 
 #include <type_traits>
 
-#include <hip/hip_ext.h>
-
 #include "gemm_ring.h"
 #include "kernels.h"
 
@@ -187,8 +185,10 @@ static int launch_dense_variant(const void* q16, int64_t ld_elems, int64_t nq_pa
     auto kern = score_dense_t16_kernel<CB, STAGES>;
     LDOT_HIP_CHECK(set_max_dynamic_lds_once((const void*)kern, Geo::kLds, attr_set));
     const int grid = (int)std::min<int64_t>(nunits, 256 * kWgPerCu);
-    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kRingThreads), Geo::kLds, st, ev_a, ev_b, 0, (const char*)x16, ld_elems * 2, xrow0, tiles_n,
-                          tile_stride, (const char*)q16, tiles_q, dpad / kRBK, S, lds_elems, nq_valid);
+    if (ev_a) (void)hipEventRecord(ev_a, st);   // (LDOT_OPT_PROFILE: events around the launch; see launch_score_filter)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kRingThreads), Geo::kLds, st, (const char*)x16, ld_elems * 2, xrow0, tiles_n,
+                       tile_stride, (const char*)q16, tiles_q, dpad / kRBK, S, lds_elems, nq_valid);
+    if (ev_b) (void)hipEventRecord(ev_b, st);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

@@ -56,8 +56,6 @@
 
 #include <type_traits>
 
-#include <hip/hip_ext.h>
-
 #include "gemm_ring.h"
 #include "kernels.h"
 
@@ -506,10 +504,14 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
         so.da = (int)nslices;
         so.dn = (int)ntiles;
     }
-    // (ev_a / ev_b, LDOT_OPT_PROFILE: start / stop events attached to THIS dispatch — its own timestamps, no marker packets around it)
-    hipExtLaunchKernelGGL(rk, dim3(256), dim3(kRingThreads), RingGeom<6>::kLds, st, ev_a, ev_b, 0, (const char*)x16, ldx_elems * 2, row0,
-                          nrows, (const char*)q16, ldq_elems * 2, (int)(nq_pad / kRBN), dpad / kRBK, tau, pool, pool_cnt,
-                          qg_log2, so);
+    // (ev_a / ev_b, LDOT_OPT_PROFILE: events recorded around the launch.  Attaching them to the dispatch itself — hipExtLaunchKernel — was
+    // measured in round 5: the dispatch gaps stay, and the queue stays in its profiling mode afterwards, which slowed LATER searches of
+    // other indexes in the same process up to 3x: profiles/r05_secondary_probe.txt)
+    if (ev_a) (void)hipEventRecord(ev_a, st);
+    hipLaunchKernelGGL(rk, dim3(256), dim3(kRingThreads), RingGeom<6>::kLds, st, (const char*)x16, ldx_elems * 2, row0,
+                       nrows, (const char*)q16, ldq_elems * 2, (int)(nq_pad / kRBN), dpad / kRBK, tau, pool, pool_cnt,
+                       qg_log2, so);
+    if (ev_b) (void)hipEventRecord(ev_b, st);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

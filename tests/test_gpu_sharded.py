@@ -9,6 +9,8 @@ import sys
 import numpy as np
 import pytest
 
+from tests.util import assert_topk_matches
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -170,6 +172,15 @@ def test_sharded_search_four_ranks_fused_path_baseline_shapes(tmp_path):
         q = _gen_queries(int(qs[-1]), c['d'], 500 + ci, n)
         es, el = ix.search_tensors(q, c['k'])
         es, el = es.cpu().numpy(), el.cpu().numpy()
+        # ... and the checker itself, not only the unsharded HIP search: the merged lists of the four ranks against an fp64 brute-force
+        # scan of the whole index, for the first queries of every rank's slice
+        x_all = _case_rows(c, 0, n, 11 + ci).cpu().numpy()
+        for r in range(world):
+            nchk = min(8, c['counts'][r])
+            if nchk:
+                a = np.load(os.path.join(str(tmp_path), f'{name}_r{r}.npz'))
+                assert_topk_matches(q[qs[r]:qs[r] + nchk].cpu().numpy(), x_all, a['s'][:nchk], a['l'][:nchk], c['k'])
+        del x_all
         cand = []
         for r in range(world):
             a = np.load(os.path.join(str(tmp_path), f'{name}_r{r}.npz'))
