@@ -183,6 +183,10 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
     const int64_t nunits = (int64_t)nq_iter * ntiles;                            // (group, tile) units of this qsub
     const int ntile_total = (nunits > slice) ? (int)((nunits - slice + nslices - 1) / nslices) : 0;
     if (ntile_total == 0) return;
+    // (measurement, ablation builds: static wave priority — waves w and w + 4 share a SIMD and the second-dispatched half loses every VALU
+    // arbitration; VAR & 2 raises waves 4..7, VAR & 4 waves 0..3)
+    if ((VAR & 2) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if ((VAR & 4) && wave < 4) __builtin_amdgcn_s_setprio(1);
     const int64_t S = (int64_t)ntile_total * nk;
     const int g0 = slice / ntiles, t0 = slice % ntiles;                          // first unit of this stream
 
@@ -474,6 +478,10 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     if (variant == 8) rk = score_filter_t16_kernel<8>;
     if (variant == 32) rk = score_filter_t16_kernel<32>;      // K walk rotated per row stream (query panels L2-resident?)
     if (variant == 48) rk = score_filter_t16_kernel<48>;      // ... with tau = +inf
+    if (variant == 2) rk = score_filter_t16_kernel<2>;        // s_setprio 1 for waves 4..7
+    if (variant == 4) rk = score_filter_t16_kernel<4>;        // s_setprio 1 for waves 0..3
+    if (variant == 18) rk = score_filter_t16_kernel<18>;      // ... with tau = +inf
+    if (variant == 20) rk = score_filter_t16_kernel<20>;
     if (variant == 81) rk = score_filter_t16_kernel<81>;      // no filter, row tiles aliased onto 32 tiles (rows from the Infinity Cache)
     if (variant == 529) rk = score_filter_t16_kernel<529>;    // no filter, one row tile per XCD (everything L2-resident)
     if (variant == 128) rk = score_filter_t16_kernel<128>;    // row blocks NOT pinned in program order (the scheduler sinks the fragment loads)
