@@ -181,14 +181,19 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
     const int ntiles = (int)((nrows + Geo::kBM - 1) / Geo::kBM);
     const int nq_iter = (nqb > qsub) ? (nqb - qsub + qg - 1) >> qg_log2 : 0;   // query groups in which this qsub is valid
     const int64_t nunits = (int64_t)nq_iter * ntiles;                            // (group, tile) units of this qsub
-    const int ntile_total = (nunits > slice) ? (int)((nunits - slice + nslices - 1) / nslices) : 0;
+    // (measurement, ablation builds, no-filter variants only: VAR & 1024 = TILE-MAJOR unit order — stream s takes the row tiles s, s + nslices,
+    // ... and multiplies each with ALL its query groups back to back, so that a row tile comes from HBM once and from the L2 for the other
+    // groups; thresholds / cursors are not handled: the bound of what that order could give)
+    constexpr bool TM = (VAR & 1024) != 0;
+    const int tm_tiles = (ntiles > slice) ? (ntiles - slice + nslices - 1) / nslices : 0;
+    const int ntile_total = TM ? tm_tiles * nq_iter : (nunits > slice) ? (int)((nunits - slice + nslices - 1) / nslices) : 0;
     if (ntile_total == 0) return;
     // (measurement, ablation builds: static wave priority — waves w and w + 4 share a SIMD and the second-dispatched half loses every VALU
     // arbitration; VAR & 2 raises waves 4..7, VAR & 4 waves 0..3)
     if ((VAR & 2) && wave >= 4) __builtin_amdgcn_s_setprio(1);
     if ((VAR & 4) && wave < 4) __builtin_amdgcn_s_setprio(1);
     const int64_t S = (int64_t)ntile_total * nk;
-    const int g0 = slice / ntiles, t0 = slice % ntiles;                          // first unit of this stream
+    const int g0 = TM ? 0 : slice / ntiles, t0 = TM ? slice : slice % ntiles;    // first unit of this stream
 
     // ---- load cursor -------------------------------------------------------------------------------------------------------
     // staging instruction j of wave w fills LDS bytes [(j*8+w)*1024, +1024) = slab rows (j*8+w)*16 .. +16; lane i lands on row
@@ -236,7 +241,18 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
         }
         ++issued;
         if (issued < S) {
-            if (++l_k == nk) {   // next unit of this stream
+            if (TM) {
+                if (++l_k == nk) {   // next unit: the next query group on the same row tile, then the stream's next tile
+                    l_k = 0;
+                    if (++l_q == nq_iter) {
+                        l_q = 0;
+                        l_t += nslices;
+                        l_p = l_t;
+                        sa.rsrc = ring_make_rsrc_n(X16 + (row0 + (int64_t)phys(l_p) * Geo::kBM) * ldx_b, Geo::kBM * ldx_b);
+                    }
+                    sb.rsrc = ring_make_rsrc_n(Q16 + (int64_t)(qsub + l_q * qg) * kRBN * ldq_b, kRBN * ldq_b);
+                }
+            } else if (++l_k == nk) {   // next unit of this stream
                 l_k = 0;
                 l_t += nslices;
                 l_p += so.da;
@@ -482,6 +498,7 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     if (variant == 4) rk = score_filter_t16_kernel<4>;        // s_setprio 1 for waves 0..3
     if (variant == 18) rk = score_filter_t16_kernel<18>;      // ... with tau = +inf
     if (variant == 20) rk = score_filter_t16_kernel<20>;
+    if (variant == 1041) rk = score_filter_t16_kernel<1041>;  // no filter, tile-major unit order (sequential scan only)
     if (variant == 81) rk = score_filter_t16_kernel<81>;      // no filter, row tiles aliased onto 32 tiles (rows from the Infinity Cache)
     if (variant == 529) rk = score_filter_t16_kernel<529>;    // no filter, one row tile per XCD (everything L2-resident)
     if (variant == 128) rk = score_filter_t16_kernel<128>;    // row blocks NOT pinned in program order (the scheduler sinks the fragment loads)
