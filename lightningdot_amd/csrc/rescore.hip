@@ -16,10 +16,19 @@ __global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __rest
                                                              const int32_t* __restrict__ list_i, int kp, int k,
                                                              int do_rescore, const float* __restrict__ floor,
                                                              float* __restrict__ out_s,
-                                                             int64_t* __restrict__ out_l, RescoreOut lay) {
+                                                             int64_t* __restrict__ out_l, RescoreOut lay, int64_t nq) {
     __shared__ __attribute__((aligned(16))) uint64_t keys[4096];   // next power of two >= kMaxKp
     static_assert(kMaxKp <= 4096, "re-score key buffer");
-    const int64_t q = blockIdx.x;
+    // Block b is observed on XCD b % 8 (speed only).  Neighbouring queries of a retrieval evaluation are captions of the same image
+    // (dvl/trainer.py:130-154 walks the dataset in order) and share most of their candidate rows: sixteen consecutive queries go to ONE XCD,
+    // so that the rows they share are gathered from that XCD's L2 instead of eight times from the Infinity Cache / HBM.  Within a group of
+    // 128 blocks, block r takes query (r % 8) * 16 + r / 8.
+    int64_t q = blockIdx.x;
+    if (gridDim.x >= 128) {
+        const int64_t r = q & 127;
+        q = (q - r) + (r & 7) * 16 + (r >> 3);
+    }
+    if (q >= nq) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* qrow = q32 + q * ldq;
     // 1. compact the live candidates (valid row, and at or above the floor of a sharded search: candidates below the best
@@ -257,10 +266,10 @@ int launch_rescore(const float* q32, int64_t ldq, const float* x32, int64_t ldx,
     if (label_map) lay.label_map = label_map;
     if (nq <= 128)
         hipLaunchKernelGGL(rescore_kernel<1024>, dim3((unsigned)nq), dim3(1024), 0, st, q32, ldq, x32, ldx, dpad, list_s,
-                           list_i, kp, k, do_rescore, floor, out_s, out_l, lay);
-    else
-        hipLaunchKernelGGL(rescore_kernel<256>, dim3((unsigned)nq), dim3(256), 0, st, q32, ldq, x32, ldx, dpad, list_s,
-                           list_i, kp, k, do_rescore, floor, out_s, out_l, lay);
+                           list_i, kp, k, do_rescore, floor, out_s, out_l, lay, nq);
+    else   // (whole groups of 128 blocks: the kernel deals sixteen consecutive queries to one XCD)
+        hipLaunchKernelGGL(rescore_kernel<256>, dim3((unsigned)round_up(nq, 128)), dim3(256), 0, st, q32, ldq, x32, ldx, dpad, list_s,
+                           list_i, kp, k, do_rescore, floor, out_s, out_l, lay, nq);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }
