@@ -243,41 +243,49 @@ static RowPerm row_perm(ldot_index* ix, int64_t n) {
 }
 
 // LDOT_OPT_ROW_SHUFFLE auto: the rows already stored are re-ordered pseudo-randomly (new row j = old row (mul j + add) mod n), once per index.
-// Needs room for a second fp32 copy while it runs; without it the index stays as it is.  `st` is synchronised.
+// Built into NEW buffers (fp32 master, bf16 shadow, label tables) that replace the old ones only when everything has succeeded: a failure
+// leaves the index exactly as it was.  Needs room for a second copy of the store while it runs; without it the index stays as it is.
+// `st` is synchronised.
 static int reshuffle_rows(ldot_index* ix, hipStream_t st) {
     const int64_t n = ix->ntotal;
     ix->reshuffled = true;
     if (n < 2) return LDOT_OK;
     LDOT_HIP_CHECK(hipStreamSynchronize(st));
-    const size_t b32 = (size_t)ix->cap_rows * ix->dpad * 4, bt = (size_t)ix->cap_rows * 4;
+    const size_t b32 = (size_t)ix->cap_rows * ix->dpad * 4, b16 = (size_t)ix->cap_rows * ix->ld16() * 2, bt = (size_t)ix->cap_rows * 4;
     float* n32 = nullptr;
+    uint16_t* n16b = nullptr;
     void *nl = nullptr, *np = nullptr, *idx = nullptr;
-    if (hipMalloc((void**)&n32, b32) != hipSuccess || hipMalloc(&nl, bt) != hipSuccess || hipMalloc(&np, bt) != hipSuccess ||
-        hipMalloc(&idx, bt) != hipSuccess) {
-        (void)hipGetLastError();
-        for (void* p : {(void*)n32, nl, np, idx})
+    auto drop = [&]() {
+        for (void* p : {(void*)n32, (void*)n16b, nl, np, idx})
             if (p) (void)hipFree(p);
+    };
+    if (hipMalloc((void**)&n32, b32) != hipSuccess || hipMalloc((void**)&n16b, b16) != hipSuccess || hipMalloc(&nl, bt) != hipSuccess ||
+        hipMalloc(&np, bt) != hipSuccess || hipMalloc(&idx, bt) != hipSuccess) {
+        (void)hipGetLastError();
+        drop();
         return LDOT_OK;
     }
     const RowPerm perm = row_perm(ix, n);
     int rc = launch_reshuffle_tables(ix->shuffled ? (const int32_t*)ix->w_label.p : nullptr, (int32_t*)nl, (int32_t*)np, (int32_t*)idx, n, perm, st);
     if (!rc) rc = launch_gather_rows_f32(ix->x32, ix->dpad, (const int32_t*)idx, n, n, n32, st);
     hipError_t e = hipMemsetAsync(n32 + n * ix->dpad, 0, b32 - (size_t)n * ix->dpad * 4, st);
-    if (!rc) rc = launch_convert_rows(n32, LDOT_F32, ix->dpad, n, n, ix->d, ix->dpad, 0, nullptr, nullptr, ix->precision ? 1 : 0, ix->x16b, 0, st);
+    if (e == hipSuccess) e = hipMemsetAsync(n16b, 0, b16, st);
+    if (!rc && e == hipSuccess)
+        rc = launch_convert_rows(n32, LDOT_F32, ix->dpad, n, n, ix->d, ix->dpad, 0, nullptr, nullptr, ix->precision ? 1 : 0, n16b, 0, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(idx);
     if (rc || e != hipSuccess) {
-        (void)hipFree(n32);
-        (void)hipFree(nl);
-        (void)hipFree(np);
+        drop();
         if (!rc) {
             set_error("re-shuffle failed: %s", hipGetErrorString(e));
             rc = LDOT_EDEVICE;
         }
-        return rc;   // (the shadow may be half rewritten: the caller's search fails with this status)
+        return rc;
     }
+    (void)hipFree(idx);
     (void)hipFree(ix->x32);
+    (void)hipFree(ix->x16b);
     ix->x32 = n32;
+    ix->x16b = n16b;
     ix->w_label.release();
     ix->w_pos.release();
     ix->w_label.p = nl;
