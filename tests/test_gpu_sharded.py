@@ -204,11 +204,9 @@ def test_sharded_search_four_ranks_fused_path_baseline_shapes(tmp_path):
             else:
                 assert int(a['fused_pairs']) == 0
         if name == 'shard125k':
-            # all three schedules give the same lists (asserted in the workers); pooled statistics need no more launches than a shard's
-            # own optimistic thresholds and about as many records (their warm-up is 3072 rows instead of 4096 since round 5: a few per
-            # cent more records, one launch and a quarter of the dense rows less), both far fewer than the agreed-threshold option
-            # (tools/shard_floor.py, tools/shard_warm_sweep.py)
-            assert all(a < 1.15 * b and b < c_ and a < c_ and la <= lb for a, b, c_, la, lb, lc in cand), cand
+            # all three schedules give the same lists (asserted in the workers); pooled statistics admit the fewest records in no
+            # more launches, a shard's own optimistic thresholds fewer than the agreed-threshold option (tools/shard_floor.py)
+            assert all(a < b < c_ and la <= lb for a, b, c_, la, lb, lc in cand), cand
         del ix
         torch.cuda.empty_cache()
 
