@@ -642,7 +642,9 @@ static int dense_scan(ldot_index* ix, int64_t q0, int64_t nqb, int64_t nqb_pad, 
     const uint16_t* q16 = (const uint16_t*)ix->w_q16b.p + q0 * ix->ld16();   // (q0 is a multiple of 256: whole 16-row blocks)
     float* ls = (float*)ix->w_ls.p + q0 * kp;
     int32_t* li = (int32_t*)ix->w_li.p + q0 * kp;
-    const int64_t chunk = ix->chunk_rows;
+    // (a scan shorter than a chunk — every Flickr / COCO sized index — gets score rows of its own length: contiguous 4-20 KB rows instead of
+    // 128-KB strides, and dense_scan_all can then take all queries in one block)
+    const int64_t chunk = std::min<int64_t>(ix->chunk_rows, round_up(r1 - r0, kBN));
     int rc = ix->w_S.ensure((size_t)nqb_pad * chunk * sizeof(float));
     if (rc) return rc;
     for (int64_t r = r0; r < r1; r += chunk) {
@@ -842,8 +844,9 @@ static int dense_scan_all(ldot_index* ix, int64_t nq, int64_t r0, int64_t r1, in
                           hipStream_t st, int64_t q_base = 0) {
     if (allow_wide && q_base == 0 && nq <= kBM && (r1 - r0 > 2 * ix->chunk_rows || (nq <= 64 && r1 - r0 >= 2048)))
         return dense_scan_wide(ix, nq, r0, r1, kp, tau, st);
-    // query blocks bound the dense score workspace (<= ~2 GiB at the default chunk)
-    const int64_t qb_max = std::max<int64_t>(kBM, ((int64_t)1 << 29) / ix->chunk_rows / kBM * kBM);
+    // query blocks bound the dense score workspace (<= ~2 GiB)
+    const int64_t chunk = std::min<int64_t>(ix->chunk_rows, round_up(r1 - r0, kBN));
+    const int64_t qb_max = std::max<int64_t>(kBM, ((int64_t)1 << 29) / chunk / kBM * kBM);
     for (int64_t q0 = 0; q0 < nq; q0 += qb_max) {
         const int64_t nqb = std::min(qb_max, nq - q0);
         int rc = dense_scan(ix, q_base + q0, nqb, round_up(nqb, kBM), r0, r1, kp, tau, st);
