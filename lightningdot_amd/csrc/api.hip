@@ -79,6 +79,7 @@ struct ldot_index {
         double flops, bytes;
     };
     std::vector<ProfEv> prof_events;
+    std::vector<hipEvent_t> prof_pool;   // events of finished searches, reused (creating and destroying ten per search is host time inside the step)
     double prof[4] = {0, 0, 0, 0};
     // workspaces
     DevBuf w_q16b;
@@ -356,6 +357,11 @@ int ldot_index_destroy(ldot_index_t* ix) {
     ix->w_lprobe_l.release();
     for (auto& c : ix->compact)
         for (DevBuf* b : {&c.fidx, &c.q32, &c.q16b, &c.ls, &c.li, &c.tau}) b->release();
+    for (auto& ev : ix->prof_events) {
+        (void)hipEventDestroy(ev.a);
+        (void)hipEventDestroy(ev.b);
+    }
+    for (hipEvent_t e : ix->prof_pool) (void)hipEventDestroy(e);
     if (ix->h_over_sum) (void)hipHostFree(ix->h_over_sum);
     if (ix->h_nover) (void)hipHostFree(ix->h_nover);
     delete ix;
@@ -589,10 +595,22 @@ static int candidate_len(const ldot_index* ix, int k) {
     return std::min(kp, kMaxKp);
 }
 
+static bool prof_event(ldot_index* ix, hipEvent_t* e) {
+    if (!ix->prof_pool.empty()) {
+        *e = ix->prof_pool.back();
+        ix->prof_pool.pop_back();
+        return true;
+    }
+    return hipEventCreate(e) == hipSuccess;
+}
 static void prof_begin(ldot_index* ix, hipStream_t st, double flops, double bytes) {
     if (!ix->profile) return;
     ldot_index::ProfEv ev;
-    if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) return;
+    if (!prof_event(ix, &ev.a)) return;
+    if (!prof_event(ix, &ev.b)) {
+        ix->prof_pool.push_back(ev.a);
+        return;
+    }
     ev.flops = flops;
     ev.bytes = bytes;
     (void)hipEventRecord(ev.a, st);
@@ -603,9 +621,9 @@ static void prof_attach(ldot_index* ix, double flops, double bytes, hipEvent_t* 
     *a = *b = nullptr;
     if (!ix->profile) return;
     ldot_index::ProfEv ev;
-    if (hipEventCreate(&ev.a) != hipSuccess) return;
-    if (hipEventCreate(&ev.b) != hipSuccess) {
-        (void)hipEventDestroy(ev.a);
+    if (!prof_event(ix, &ev.a)) return;
+    if (!prof_event(ix, &ev.b)) {
+        ix->prof_pool.push_back(ev.a);
         return;
     }
     ev.flops = flops;
@@ -630,8 +648,8 @@ static void prof_collect(ldot_index* ix, hipStream_t st) {
             ix->prof[2] += ev.flops;
             ix->prof[3] += ev.bytes;
         }
-        (void)hipEventDestroy(ev.a);
-        (void)hipEventDestroy(ev.b);
+        ix->prof_pool.push_back(ev.a);
+        ix->prof_pool.push_back(ev.b);
     }
     ix->prof_events.clear();
 }
