@@ -1032,6 +1032,7 @@ static int fused_warm_chunk(ldot_index* ix, int64_t q0, int64_t nq, int64_t nq_p
 constexpr double kOptEps = 1e-7;                 // per query and launch; 10 000 queries x 4 launches: one redo in ~250 searches
 constexpr int64_t kOptMaxLaunchRows = 393216;    // launches beyond ~0.6 GB of rows run slower per row
 constexpr int64_t kOptGrowthX = 7;               // a launch covers up to 7x the rows already scanned
+constexpr int64_t kPooledGrowthX = 12;           // ... a shard on pooled statistics up to 12x (sweep: 10 .. 16 level, 3 .. 8 and one launch slower)
 
 static int optimistic_m(int kp, int64_t r, int64_t n, double eps) {
     const double x = (double)kp * (double)r / (double)n;
@@ -1070,7 +1071,11 @@ static int fused_rest_chunk_optimistic(ldot_index* ix, int64_t q0, int64_t nq, i
     const float* ls = (const float*)ix->w_ls.p + q0 * kp;
     const int32_t* li = (const int32_t*)ix->w_li.p + q0 * kp;
     double eps = pooled ? kOptEps / ix->pool_parts : kOptEps;   // (the floor check fails if ANY shard aimed too high)
-    int64_t growth_x = pooled ? (int64_t)1 << 20 : kOptGrowthX, max_rows = kOptMaxLaunchRows;
+    // (pooled statistics: a launch covers up to 12x the rows the thresholds were drawn from.  Up to round 5 a shard ran to its pool bound in ONE
+    // launch after the warm-up; at 8 x 125 000 rows that launch admits 274 records per query on the 4096-row threshold and one select folds
+    // them all: a 49 152-row launch first, its select, then the rest takes rank 0 from 2.00 to 1.78 ms (144 records per query).  Shards of
+    // 250 000 / 500 000 rows already split at the pool bound and are unchanged: profiles/r05_shard_growth_sweep.txt)
+    int64_t growth_x = pooled ? kPooledGrowthX : kOptGrowthX, max_rows = kOptMaxLaunchRows;
 #ifdef LDOT_ABLATION
     if (const char* e = getenv("LDOT_DEBUG_OPT_EPS")) eps = atof(e);
     if (const char* e = getenv("LDOT_DEBUG_OPT_GROWTHX")) growth_x = atoll(e);

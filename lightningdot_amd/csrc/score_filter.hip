@@ -114,7 +114,7 @@ constexpr int kFiltCols = 4;        // column blocks per filter call (half a wav
 // address in 16-byte units: (q * kPoolCap * 3) * nsubs + sub + (e * 3 + plane) * nsubs with q = q_u + 16 j + (lane & 15) and
 // e = (lane >> 4) * kPoolGroupCap + count: pbase_u carries the wave-uniform part incl. the sub-pool (a scalar), the lane's part is derived in
 // the rare path.
-template <bool NOSTORE>
+template <int SMODE>   // 0 product; ablation builds: 1 no record stores, 2 every record store issued twice (same address, same data)
 __device__ __forceinline__ void filter_admit(const f32x4* lo, const f32x4* hi, int p, int jbase, const float (&m)[kFiltCols],
                                              const float (&tau)[kFiltCols], uint32_t& curp, uint32_t pbase_u, uint32_t pstep,
                                              uint32_t nsubs, uint4* __restrict__ pool, int32_t row_w) {
@@ -132,7 +132,7 @@ __device__ __forceinline__ void filter_admit(const f32x4* lo, const f32x4* hi, i
         if (m[jj] >= tau[jj]) {
             const uint32_t e = (curp >> (8 * jj)) & 255u;
             if (e < 255u) curp += 1u << (8 * jj);
-            if (e < (uint32_t)kPoolGroupCap && !NOSTORE) {
+            if (e < (uint32_t)kPoolGroupCap && SMODE != 1) {
                 // buffer stores: the wave-uniform base lives in the (scalar) resource, the plane and the column block in the scalar
                 // offset, so the lane's address is ONE register
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -142,20 +142,25 @@ __device__ __forceinline__ void filter_admit(const f32x4* lo, const f32x4* hi, i
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo[jj]), pr, vo, so, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi[jj]), pr, vo, so + nsubs * 16u, 0);
                 __builtin_amdgcn_raw_buffer_store_b32((uint32_t)rb, pr, vo, so + nsubs * 32u, 0);
+                if (SMODE == 2) {   // (measurement: what do the stores themselves cost?  twice the store instructions, the same records)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo[jj]), pr, vo, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi[jj]), pr, vo, so + nsubs * 16u, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32((uint32_t)rb, pr, vo, so + nsubs * 32u, 0);
+                }
             }
         }
     }
 }
 
 // maxima (two statements of two interleaved chains) + admission of a pair over four column blocks
-template <bool NOSTORE>
+template <int SMODE>
 __device__ __forceinline__ void filter_pair(const f32x4* lo, const f32x4* hi, int p, int jbase, const float (&tau)[kFiltCols],
                                             uint32_t& curp, uint32_t pbase_u, uint32_t pstep, uint32_t nsubs, uint4* __restrict__ pool,
                                             int32_t row_w) {
     float m[kFiltCols];
     max8x2_raw(lo[0], hi[0], lo[1], hi[1], m[0], m[1]);
     max8x2_raw(lo[2], hi[2], lo[3], hi[3], m[2], m[3]);
-    filter_admit<NOSTORE>(lo, hi, p, jbase, m, tau, curp, pbase_u, pstep, nsubs, pool, row_w);
+    filter_admit<SMODE>(lo, hi, p, jbase, m, tau, curp, pbase_u, pstep, nsubs, pool, row_w);
 }
 
 // VAR (ablation builds): 1 no filter at all, 8 no record stores, 16 tau = +inf (fast path only), 128 program order not pinned.
@@ -400,7 +405,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
                     tau[jj] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bp + jj * 64, __builtin_bit_cast(int, tq[h])));
 #pragma unroll
                 for (int p = 0; p < kT16RowBlocks / 2; ++p)
-                    filter_pair<(VAR & 8) != 0>(&acc[2 * p][4 * h], &acc[2 * p + 1][4 * h], p, 4 * h, tau, curp[h], pbase_u, pstep,
+                    filter_pair<(VAR & 8) ? 1 : (VAR & 256) ? 2 : 0>(&acc[2 * p][4 * h], &acc[2 * p + 1][4 * h], p, 4 * h, tau, curp[h], pbase_u, pstep,
                                                 (uint32_t)nsubs, pool, row_w);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -492,6 +497,7 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     if (variant == 16) rk = score_filter_t16_kernel<16>;
     if (variant == 17) rk = score_filter_t16_kernel<17>;
     if (variant == 8) rk = score_filter_t16_kernel<8>;
+    if (variant == 256) rk = score_filter_t16_kernel<256>;    // every record store issued twice (what the stores themselves cost)
     if (variant == 32) rk = score_filter_t16_kernel<32>;      // K walk rotated per row stream (query panels L2-resident?)
     if (variant == 48) rk = score_filter_t16_kernel<48>;      // ... with tau = +inf
     if (variant == 2) rk = score_filter_t16_kernel<2>;        // s_setprio 1 for waves 4..7
