@@ -73,7 +73,7 @@ class ShardedFlatIndexer:
         # query counts (a small all-gather + a host synchronisation) is skipped
         self.equal_query_counts = equal_query_counts
         # True (default): large batches scan every shard on order statistics taken against the WHOLE index
-        # (ldot_index_search_begin_shard, total_rows > 0): ~1/world of the admitted records and one launch after the warm-up.  It assumes
+        # (ldot_index_search_begin_shard, total_rows > 0): ~1/world of the admitted records, launches of up to 12x the rows already scanned.  It assumes
         # rows spread over the shards (and stored) in no order that correlates with the queries; the ranks check the result together
         # (ldot_index_shard_floor) and a search that fails the check is repeated on every rank with each shard's own thresholds, after which
         # the pooled statistics are skipped for `_pooled_backoff` searches (16, doubling up to 1024 while searches keep failing).
