@@ -73,6 +73,7 @@ struct ldot_index {
     int margin = -1;
     int profile = 0;
     int64_t warm_rows = 4096;
+    bool warm_rows_set = false;   // LDOT_OPT_WARM_ROWS was set by the caller (a shard on pooled statistics otherwise warms up on fewer rows)
     int growth_pct = 150;
     struct ProfEv {
         hipEvent_t a, b;
@@ -420,6 +421,7 @@ int ldot_index_set_option(ldot_index_t* ix, int option, int64_t value) {
         case LDOT_OPT_WARM_ROWS:
             LDOT_REQUIRE(value >= 2048 && value % 256 == 0, LDOT_EINVAL, "warm_rows must be a multiple of 256 >= 2048");
             ix->warm_rows = value;
+            ix->warm_rows_set = true;
             return LDOT_OK;
         case LDOT_OPT_PRECISION: {
             LDOT_REQUIRE(value == 0 || value == 1, LDOT_EINVAL, "precision must be 0 (bf16) or 1 (split bf16)");
@@ -955,10 +957,13 @@ static int64_t fused_warm_rows(const ldot_index* ix, int64_t nq, int64_t nq_pad,
     const int64_t bm = fused_tile_rows();
     const int qg = fused_query_group(nq_pad);
     const int64_t nslices = 256 / qg, nsubs = kPoolSubsPerSlice * nslices;
-    // (a shorter warm-up for shards on pooled statistics — 3072 rows, the pool bound's minimum — was measured in round 5: the shards that stay
-    // clear of pool overflows gain 4 %, but half of them then search one to three queries again, +0.18 ms each, and a sharded search is as
-    // slow as its slowest rank: 2.14 against 1.94 ms; profiles/r05_shard_overflow_probe.txt)
-    int64_t warm = std::max<int64_t>(ix->warm_rows, round_up(bm * nslices * (int64_t)kp / (kFill * nsubs), 256));
+    // (a shard scanning on statistics pooled over the whole index takes its first threshold against the GLOBAL row count: a longer warm-up
+    // buys it little, and its dense rows cost ~10x fused ones — the pool bound's minimum, 3072 rows, instead of 4096.  While such a shard ran
+    // to its pool bound in one launch this overflowed a candidate pool for a few queries on half of the shards (a local redo, 2.14 vs 1.94 ms
+    // for the slowest rank); with the scan split at 12x the rows seen (fused_rest_chunk_optimistic) no shard overflows and every rank gains:
+    // 1.78 -> 1.75 ms at 8 x 125 000 rows, profiles/r05_shard_warm_probe_growth12.txt)
+    const int64_t want = (ix->pool_total > 0 && !ix->warm_rows_set) ? 2048 : ix->warm_rows;
+    int64_t warm = std::max<int64_t>(want, round_up(bm * nslices * (int64_t)kp / (kFill * nsubs), 256));
     // few queries (serving): launches and selects cost more than dense rows -> warm up over just enough rows for ONE fused launch
     // to cover the rest within the pool bound (len <= r * kFill * nsubs / kp)
     if (nq <= 64) warm = std::max(warm, round_up(ix->ntotal * kp / (kp + kFill * nsubs) + 1, 256));

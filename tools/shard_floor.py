@@ -19,6 +19,7 @@ q = torch.randn(NQ, D, device='cuda', generator=g)
 shards = []
 for r in range(G):
     ix = FlatIPIndex(D); ix.add(torch.randn(PER, D, device='cuda', generator=g)); shards.append(ix)
+    if os.environ.get('SHARD_WARM'): ix.set_option(L.OPT_WARM_ROWS, int(os.environ['SHARD_WARM']))   # (A/B of the warm-up length)
 ix0 = shards[0]
 
 

@@ -11,7 +11,7 @@ q = torch.randn(NQ, D, device='cuda', generator=g)
 shards = []
 for r in range(G):
     ix = FlatIPIndex(D); ix.add(torch.randn(PER, D, device='cuda', generator=g)); shards.append(ix)
-for warm in (0, 4096):
+for warm in ([int(a) for a in sys.argv[1:]] or [0, 4096]):
     for ix in shards:
         if warm: ix.set_option(L.OPT_WARM_ROWS, warm)
     out = []
@@ -27,4 +27,4 @@ for warm in (0, 4096):
             torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 5 * 1e3
             st = ix.last_stats()
             row.append('%.2f ms/%d over/%d rec' % (ms, st['overflowed_queries'], st['fused_candidates'] // NQ))
-        print('warm %s:' % (warm or 'default (3072 for pooled shards)'), ' | '.join(row), flush=True)
+        print('warm %s:' % (warm or 'default'), ' | '.join(row), flush=True)
