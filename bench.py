@@ -190,6 +190,8 @@ def main():
     prof = dict(launches=0.0, kernel_ms=0.0, flops=0.0, bytes=0.0)
     phases = {}
     barrier()
+    import gc
+    gc.disable()                       # (a full collection is a 50 ms stall in this process; nothing in a step needs one)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -201,6 +203,7 @@ def main():
                 phases[k_] = phases.get(k_, 0.0) + v
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     ranks_seen = 1
     if sharded:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -300,21 +303,55 @@ def main():
 
 
 def _time_ms(fn, n, warm=3):
+    """mean wall time of n back-to-back calls (the cyclic garbage collector paused: a full collection is a 50 ms stall in this process)"""
+    import gc
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    finally:
+        if was:
+            gc.enable()
+
+
+def _median_ms(fn, n, warm=3, full=False):
+    """median wall time of n individually timed calls, each one complete on the device before the next starts.  One-off host stalls
+    (profiles/r05_secondary_outliers.txt: 50-70 ms once in a while, with or without anything this library does differently) do not
+    enter; a slowdown that lasts does."""
+    import gc
+    for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e3
+    was = gc.isenabled()
+    gc.disable()
+    ts = []
+    try:
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+    finally:
+        if was:
+            gc.enable()
+    ts.sort()
+    if full:
+        return ts[len(ts) // 2], sum(ts) / len(ts), ts[-1]
+    return ts[len(ts) // 2]
 
 
 def secondary_metrics(dev, flat_main, D, K):
     """The other workloads of BASELINE.json / SURVEY 8d on the same box, measured AFTER the timed region so that the line the driver
     records carries them (each a few tens of milliseconds of GPU work; none of them enters `value`):
       * retrieval evaluation at the Flickr30k-1k and MSCOCO-5k shapes (configs[1] / [2], `--workload flickr|coco` in full): ms per
-        evaluation = text->image over all captions + image->text over every image id once, results on the host;
+        evaluation = text->image over all captions + image->text over every image id once, results on the host, ONE wait for both;
       * serving latency (dvl/utils.py:204-211 retrieve_query): 1 and 64 queries over the headline index and over 123 287 rows (the
         reference demo's COCO index), device query -> pinned host results, with the fraction of the 8 TB/s HBM peak the WHOLE search
         reaches (algorithmic bytes = the bf16 index read once);
@@ -332,11 +369,12 @@ def secondary_metrics(dev, flat_main, D, K):
         hl = [torch.empty((n, K), dtype=torch.int64).pin_memory() for n in (txt.shape[0], n_img)]
 
         def step():
-            ix_img.search_into(txt, K, hs[0], hl[0])
+            # (the first direction does not wait for its results, LDOT_OPT_DEFER_SYNC: the second search's wait covers both — same stream)
+            ix_img.search_into(txt, K, hs[0], hl[0], sync=False)
             ix_txt.search_into(img, K, hs[1], hl[1])
-        ms = _time_ms(step, 10)
+        ms, ms_mean, ms_worst = _median_ms(step, 20, full=True)
         gt = torch.arange(txt.shape[0]) // 5
-        sec[name] = {'ms_per_evaluation': ms, 'queries_searched': int(txt.shape[0] + n_img),
+        sec[name] = {'ms_per_evaluation': ms, 'timing': 'median of 20 evaluations', 'ms_mean': ms_mean, 'ms_worst': ms_worst, 'queries_searched': int(txt.shape[0] + n_img),
                      'queries_per_s': (txt.shape[0] + n_img) / ms * 1e3,
                      'recall_t2i@1': float((hl[0][:, 0] == gt).float().mean()),
                      'recall_i2t@1': float(((hl[1][:, 0] // 5) == torch.arange(n_img)).float().mean())}
@@ -356,7 +394,7 @@ def secondary_metrics(dev, flat_main, D, K):
             q = base + 0.5 * torch.randn(nq, D, generator=g).to(dev)
             hs_ = torch.empty((nq, K), dtype=torch.float32).pin_memory()
             hl_ = torch.empty((nq, K), dtype=torch.int64).pin_memory()
-            ms = _time_ms(lambda: ix.search_into(q, K, hs_, hl_), 50)
+            ms = _median_ms(lambda: ix.search_into(q, K, hs_, hl_), 50)
             serving[f'{nq}q_x_{label}'] = {'rows': int(n), 'ms': ms, 'hbm_frac_whole_search': n * D * 2 / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                                            'rank1_ok': bool((hl_[:, 0] == rows).all())}
     sec['serving_latency'] = serving
@@ -379,8 +417,8 @@ def secondary_metrics(dev, flat_main, D, K):
     orig = torch.where(l >= 0, inv[l.clamp_min(0)], l)
     rec = float(sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(orig, el)) / (10 * qc.shape[0]))
     q1 = qc[:1].contiguous()
-    ms_ivf = _time_ms(lambda: ivf.search_knn_tensors(q1, 10, 32, exact_when_cheaper=False), 50)
-    ms_exact = _time_ms(lambda: exact.search_knn_tensors(q1, 10), 50)
+    ms_ivf = _median_ms(lambda: ivf.search_knn_tensors(q1, 10, 32, exact_when_cheaper=False), 50)
+    ms_exact = _median_ms(lambda: exact.search_knn_tensors(q1, 10), 50)
     sec['loss_step'] = loss_step_metrics(dev, D)
     sec['ivf_123k'] = {'nlist': int(ivf.nlist), 'nprobe': 32, 'ms_1_query': ms_ivf, 'ms_1_query_exact_flat': ms_exact,
                        'recall@10_vs_exact': rec, 'build_s': build_s,

@@ -93,6 +93,13 @@ extern "C" {
                                  * library re-orders the stored rows ONCE before the next search (a transient second fp32 copy; skipped when it
                                  * does not fit) and shuffles later adds.  2: never (the inverted-file row store: lists are row ranges).
                                  * Results are identical in every order */
+#define LDOT_OPT_DEFER_SYNC 14  /* 1: ldot_index_search with PINNED host outputs does not wait for its results: it returns once the last kernel is
+                                 * enqueued, and the results are in the buffers when the caller has synchronised the stream — or when a later
+                                 * search on the same stream has returned with the option off.  A retrieval evaluation (the two searches of
+                                 * dvl/trainer.py:160-170) issues its text->image search with the option on and its image->text search with it
+                                 * off: ONE wait instead of two, no idle gap between the searches.  The index, the queries and the output buffers
+                                 * must stay untouched until then.  Pageable outputs and searches under LDOT_OPT_PROFILE / LDOT_OPT_VERIFY wait
+                                 * as before (the host reads their events / flags).  0 (default): a search returns with its results in place */
 #define LDOT_OPT_VERIFY 10      /* 1: after every search flag the queries whose top-k cannot be vouched for: the k-th exact score is not above
                                  * the candidate threshold by E = 4 * 2^-8 * |q| * max|x| / sqrt(d), a STATISTICAL bound of the bf16
                                  * rounding error of a d-term inner product (4 standard deviations for independent rounding errors;

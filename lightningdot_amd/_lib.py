@@ -17,6 +17,7 @@ OPT_MODE, OPT_RESCORE, OPT_CHUNK_ROWS, OPT_MARGIN, OPT_PROFILE, OPT_WARM_ROWS, O
 OPT_OPTIMISTIC = 11
 OPT_SCAN_ORDER = 12
 OPT_ROW_SHUFFLE = 13
+OPT_DEFER_SYNC = 14
 OPT_VERIFY = 10
 ABI_VERSION = 6
 MAX_MARGIN = 1024

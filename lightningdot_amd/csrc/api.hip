@@ -75,6 +75,7 @@ struct ldot_index {
     int64_t warm_rows = 4096;
     bool warm_rows_set = false;   // LDOT_OPT_WARM_ROWS was set by the caller (a shard on pooled statistics otherwise warms up on fewer rows)
     int growth_pct = 150;
+    int defer_sync = 0;           // LDOT_OPT_DEFER_SYNC
     struct ProfEv {
         hipEvent_t a, b;
         double flops, bytes;
@@ -471,6 +472,10 @@ int ldot_index_set_option(ldot_index_t* ix, int option, int64_t value) {
             LDOT_REQUIRE(!(value == 2 && ix->shuffled), LDOT_ESTATE, "the rows of this index are shuffled already (reset it first)");
             ix->row_shuffle = (int)value;
             if (value == 2) ix->want_reshuffle = false;
+            return LDOT_OK;
+        case LDOT_OPT_DEFER_SYNC:
+            LDOT_REQUIRE(value == 0 || value == 1, LDOT_EINVAL, "LDOT_OPT_DEFER_SYNC is 0 or 1");
+            ix->defer_sync = (int)value;
             return LDOT_OK;
         case LDOT_OPT_GROWTH_PCT:
             LDOT_REQUIRE(value >= 5 && value <= 10000, LDOT_EINVAL, "growth_pct must be in [5, 10000]");
@@ -1597,6 +1602,9 @@ static int search_finish_impl(ldot_index_t* ix, const float* floor, float* out_s
                                  (const int32_t*)ix->w_li.p, kp, k, ix->rescore, floor, (float*)ms, (int64_t*)ml, st, nullptr, lmap)))
             return rc;
         if ((rc = verify((const float*)ms, (const int64_t*)ml))) return rc;
+        // LDOT_OPT_DEFER_SYNC: the caller synchronises (everything this search used stays alive until the handle's next call on this
+        // stream).  Profiling events are read on the host and the verify flags are the caller's to read: both keep the synchronisation.
+        if (ix->defer_sync && !ix->profile && !ix->verify && floor == nullptr && !keep_pending) return LDOT_OK;
         LDOT_HIP_CHECK(hipStreamSynchronize(st));
         prof_collect(ix, st);
         return LDOT_OK;

@@ -166,10 +166,16 @@ class FlatIPIndex:
             todo = todo[np.nonzero(f2)[0]]
         self.last_unproven = int(len(todo))
 
-    def search_into(self, queries, k: int, out_scores, out_labels):
+    def search_into(self, queries, k: int, out_scores, out_labels, sync: bool = True):
         """Search with caller-owned HOST outputs (float32 [nq, k] / int64 [nq, k]; numpy arrays or CPU tensors — pinned memory
         makes the result copies asynchronous: the library re-scores in chunks and ships every chunk while the next one is
-        re-scored).  Returns when the results are in the buffers."""
+        re-scored).  Returns when the results are in the buffers.
+
+        ``sync=False`` (LDOT_OPT_DEFER_SYNC, pinned outputs): return once the search is enqueued; the results are in the buffers
+        after the next ``search_into(..., sync=True)`` on the same stream or a stream synchronisation.  ``queries`` must be a CUDA
+        tensor that stays alive and unchanged until then.  An evaluation runs its first direction this way."""
+        if bool(self._opts.get(L.OPT_DEFER_SYNC, 0)) != (not sync):
+            self.set_option(L.OPT_DEFER_SYNC, 0 if sync else 1)
         keep, ptr, nq, dt, mem = _describe(queries, self.d, self.device)
 
         def host_ptr(buf, itemsize):
