@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 #include <stdlib.h>
 
 #include "ldot.h"
@@ -84,6 +85,17 @@ int main(void) {
         if (back[i] != x[2995 * d + i]) { fprintf(stderr, "shuffled index: get_rows does not return rows by label\n"); ++bad; break; }
     if (reg[7] != 1) { fprintf(stderr, "shuffled index: regime says rows = %lld\n", (long long)reg[7]); ++bad; }
     if (ldot_index_set_option(sx, LDOT_OPT_ROW_SHUFFLE, 2) == LDOT_OK) { fprintf(stderr, "un-shuffling a shuffled index accepted\n"); ++bad; }
+    /* LDOT_OPT_DEFER_SYNC: accepted as 0 / 1 only; with pageable outputs (malloc) a search still returns with its results in place */
+    if (ldot_index_set_option(sx, LDOT_OPT_DEFER_SYNC, 2) == LDOT_OK) { fprintf(stderr, "LDOT_OPT_DEFER_SYNC = 2 accepted\n"); ++bad; }
+    memset(l2, 0xff, sizeof(int64_t) * nq * k);
+    if (ldot_index_set_option(sx, LDOT_OPT_DEFER_SYNC, 1) != LDOT_OK ||
+        ldot_index_search(sx, q, nq, LDOT_F32, LDOT_HOST, 0, k, s2, l2, LDOT_HOST, NULL) != LDOT_OK ||
+        ldot_index_set_option(sx, LDOT_OPT_DEFER_SYNC, 0) != LDOT_OK) {
+        fprintf(stderr, "deferred search: %s\n", ldot_last_error());
+        return 1;
+    }
+    for (int i = 0; i < nq * k; ++i)
+        if (l2[i] != l[i] || s2[i] != s[i]) { fprintf(stderr, "LDOT_OPT_DEFER_SYNC with pageable outputs: result %d not in place\n", i); ++bad; break; }
     ldot_index_destroy(sx);
     printf(bad ? "FAIL\n" : "abi_smoke ok\n");
     return bad ? 1 : 0;
