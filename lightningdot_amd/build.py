@@ -68,17 +68,22 @@ def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> 
 
 
 def build_tools(verbose: bool = True) -> str:
-    """measurement tools with device code (not part of the product library): tools/bin/mfma_ceiling"""
+    """measurement tools with device code (not part of the product library): tools/bin/mfma_ceiling, sstore_probe, l2_stride_probe"""
     root = os.path.dirname(PKG)
-    src = os.path.join(root, 'tools', 'mfma_ceiling.hip')
-    out = os.path.join(root, 'tools', 'bin', 'mfma_ceiling')
-    os.makedirs(os.path.dirname(out), exist_ok=True)
-    if _stale(out, [src, os.path.join(CSRC, 'gemm_ring.h')]):
-        cmd = [HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I', CSRC, src, '-o', out]
-        if verbose:
-            print(' '.join(cmd), flush=True)
-        subprocess.check_call(cmd)
-    return out
+    first = None
+    for name, deps in (('mfma_ceiling', [os.path.join(CSRC, 'gemm_ring.h')]), ('sstore_probe', []), ('l2_stride_probe', [])):
+        src = os.path.join(root, 'tools', name + '.hip')
+        out = os.path.join(root, 'tools', 'bin', name)
+        first = first or out
+        if not os.path.exists(src):
+            continue
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        if _stale(out, [src] + deps):
+            cmd = [HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I', CSRC, src, '-o', out]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    return first
 
 
 if __name__ == '__main__':
