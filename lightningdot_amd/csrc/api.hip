@@ -85,7 +85,7 @@ struct ldot_index {
     double prof[4] = {0, 0, 0, 0};
     // workspaces
     DevBuf w_q16b;
-    DevBuf w_stage, w_q32, w_ls, w_li, w_S, w_outs, w_outl, w_tau, w_pool, w_pool_cnt, w_over;
+    DevBuf w_stage, w_q32, w_ls, w_li, w_S, w_outs, w_outl, w_tau, w_pool, w_pool_cnt, w_over, w_cur_save;
     DevBuf w_part_s, w_part_l, w_mrg_s, w_mrg_l;
     DevBuf w_redone;   // flags of the queries the recovery searched again (kept for a shard's end-of-scan statistics)
     int64_t stats[4] = {0, 0, 0, 0};
@@ -335,7 +335,7 @@ int ldot_index_destroy(ldot_index_t* ix) {
     if (ix->x32) (void)hipFree(ix->x32);
     if (ix->x16b) (void)hipFree(ix->x16b);
     DevBuf* bufs[] = {&ix->w_q16b, &ix->w_stage, &ix->w_q32, &ix->w_ls, &ix->w_li, &ix->w_S, &ix->w_outs,
-                      &ix->w_outl, &ix->w_tau, &ix->w_pool, &ix->w_pool_cnt, &ix->w_over,
+                      &ix->w_outl, &ix->w_tau, &ix->w_pool, &ix->w_pool_cnt, &ix->w_over, &ix->w_cur_save,
                       &ix->w_part_s, &ix->w_part_l, &ix->w_mrg_s, &ix->w_mrg_l};
     DeviceGuard guard(ix->device);
     for (DevBuf* b : bufs) b->release();
@@ -905,9 +905,10 @@ static int fused_launch_and_select(ldot_index* ix, int64_t q0, int64_t nq, int64
     hipEvent_t ea, eb;
     prof_attach(ix, 2.0 * nq * len * ix->d, (double)len * ix->d * 2 + (double)nq * ix->d * 2 + (double)nq * kp * 8, &ea, &eb);
     // (scrambled scan: rows [r, r + len) of the pseudo-random tile order of the whole index)
+    if ((rc = ix->w_cur_save.ensure(fused_cursor_save_bytes(nq_pad)))) return rc;   // (cursors of the chunk-major unit order: score_filter.hip)
     rc = launch_score_filter(ix->x16b, ix->ld16(), scramble_tiles ? 0 : r, len, q16, ix->ld16(), nq_pad, (int)ix->ld16(), filter_tau,
                              (uint4*)ix->w_pool.p, (int32_t*)ix->w_pool_cnt.p, st, scramble_tiles, scramble_tiles ? r / fused_tile_rows() : 0,
-                             ea, eb);
+                             ea, eb, ix->w_cur_save.p);
     if (rc) return rc;
     if (nq <= kFewSelectMaxQueries && nsubs >= 128 * kPoolSubsPerSlice && kp + 512 + 32 <= 1024) {
         // few queries: G waves per query fold the sub-pools into partial lists, one merge joins them with the running list

@@ -202,7 +202,9 @@ int scan_order_multiplier(int64_t mod);
 int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_t nrows, const void* q16,
                         int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, uint4* pool, int32_t* pool_cnt,
                         hipStream_t st, int64_t scramble_tiles = 0, int64_t scramble_base = 0, hipEvent_t ev_a = nullptr,
-                        hipEvent_t ev_b = nullptr);   // (ev_a / ev_b: start / stop events recorded around the launch: LDOT_OPT_PROFILE)
+                        hipEvent_t ev_b = nullptr,   // (ev_a / ev_b: start / stop events recorded around the launch: LDOT_OPT_PROFILE)
+                        void* cur_save = nullptr);   // fused_cursor_save_bytes(nq_pad) bytes: lets a long sequential scan run as row CHUNKS (score_filter.hip)
+size_t fused_cursor_save_bytes(int64_t nq_pad);
 
 // loss path (fp32-input MFMA)
 int launch_sgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* B2, float w, float* C,

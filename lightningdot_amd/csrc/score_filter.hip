@@ -51,6 +51,7 @@
 // Earlier generations of this kernel (256x256 two-stage, commit da2a5a4; 256x256 on the LDS ring, commit 62cbd68; 384x256 on
 // v_mfma_f32_32x32x16_bf16 with the filter fused into the next tile's first slab, rounds 1-3 up to commit 34b001c) are in the history; their measurements are in
 // DESIGN.md section 5.2.
+#include <algorithm>
 #include <math.h>
 #include <stdlib.h>
 
@@ -138,7 +139,10 @@ __device__ __forceinline__ void filter_admit(const f32x4* lo, const f32x4* hi, i
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void*)(pool + pbase_u), 0, (int)(pstep * 16u * kT16ColBlocks), 0x00020000);
                 const uint32_t vo = vo0 + e * (kPoolPlanes * nsubs * 16u);
-                const uint32_t so = (uint32_t)(jbase + jj) * pstep * 16u;
+                // (computed HERE, opaquely: left to itself the compiler hoists the 24 store offsets of a tile's columns and planes out of the tile
+                // loop into scalar registers, spills them, and this path reads them back lane by lane)
+                uint32_t so;
+                asm volatile("s_mul_i32 %0, %1, %2" : "=s"(so) : "s"(pstep), "s"((uint32_t)(jbase + jj) * 16u));
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo[jj]), pr, vo, so, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi[jj]), pr, vo, so + nsubs * 16u, 0);
                 __builtin_amdgcn_raw_buffer_store_b32((uint32_t)rb, pr, vo, so + nsubs * 32u, 0);
@@ -170,7 +174,7 @@ template <int VAR>
 __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
     const char* __restrict__ X16, int64_t ldx_b, int64_t row0, int64_t nrows, const char* __restrict__ Q16,
     int64_t ldq_b, int nqb, int nk, const float* __restrict__ tau_g, uint4* __restrict__ pool,
-    int32_t* __restrict__ pool_cnt, int qg_log2, ScanOrder so) {
+    int32_t* __restrict__ pool_cnt, int qg_log2, ScanOrder so, uint2* __restrict__ cur_save, int later_chunk) {
     using Geo = RingGeom<6>;   // 384-row A slab + 256-row B slab per stage, 5 direct-to-LDS pieces per wave and slab
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -361,6 +365,10 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
                 (unsigned char)((curp[j >> 2] >> (8 * (j & 3))) & 255u);
         }
     };
+    // Row CHUNKS (launch_score_filter): a long scan is issued as several launches of this kernel over consecutive row chunks, all on the same
+    // thresholds and with ONE pool select after the last — every chunk is multiplied with all query groups while its rows are still in the
+    // Infinity Cache.  The sub-pool cursors then run on from launch to launch: every lane keeps its eight cursor bytes in a slot of its own,
+    // cur_save[group][workgroup][thread], written when a group is left and read back (later_chunk) when it is entered.
     auto setup_group = [&](int g) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -370,6 +378,14 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
         }
         pbase_u = (uint32_t)(((int64_t)(qsub + g * qg) * kRBN + wn * 128) * kPoolCap * kPoolPlanes * nsubs + slice * kPoolSubsPerSlice + wm);
         curp[0] = curp[1] = 0;
+        if (later_chunk) {   // (uniform)
+            const uint32_t* cs = (const uint32_t*)(cur_save + ((size_t)g * 256 + blockIdx.x) * kRingThreads) + 2 * (lane_now() + 64u * (uint32_t)wave);
+            curp[0] = __builtin_bit_cast(uint32_t, ring_launder(__builtin_bit_cast(float, cs[0])));
+            curp[1] = __builtin_bit_cast(uint32_t, ring_launder(__builtin_bit_cast(float, cs[1])));
+        }
+    };
+    auto save_cursors = [&](int g) {
+        if (cur_save) cur_save[((size_t)g * 256 + blockIdx.x) * kRingThreads + lane_now() + 64u * (uint32_t)wave] = make_uint2(curp[0], curp[1]);
     };
     int c_q = g0, c_t = t0, c_p = p0, cur_q = g0;
     setup_group(c_q);
@@ -419,17 +435,24 @@ __global__ __launch_bounds__(kRingThreads, 2) void score_filter_t16_kernel(
             slab(M1{});
             if (c_q != cur_q) {             // (uniform) the stream moves on to the next query group
                 store_counts(cur_q);
+                save_cursors(cur_q);
                 cur_q = c_q;
                 setup_group(c_q);
             }
         }
     }
     store_counts(cur_q);
+    save_cursors(cur_q);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing dummy loads must land before the LDS is released
 }
 
 // index rows per fused tile (the host sizes launches and the row padding of the index with it)
 int fused_tile_rows() { return RingGeom<6>::kBM; }
+
+// row tiles per chunk of a long sequential scan: 256 tiles = 98 304 rows = 151 MB of bf16 rows at D = 768 — what the 256 MB Infinity Cache keeps
+// next to the query panels (tools/mall_probe.hip: a re-read window holds 7.7 TB/s up to 256 MB, 6.1 beyond; tools/maxlen_sweep.sh: launches
+// capped at 98 304 rows run 2-3 % faster per row).  A multiple of every nslices (32 .. 256): the chunks deal their units evenly.
+constexpr int64_t kChunkTiles = 256;
 
 // query blocks an XCD works on concurrently for a batch of nqb query blocks (power of two <= 8); the fused launch then
 // has 256 / qg row slices and kPoolSubsPerSlice * 256 / qg sub-pools per query
@@ -462,6 +485,13 @@ int fused_query_group(int64_t nq_pad) {
     return best;
 }
 
+// bytes of the cursor save area of a batch of nq_pad queries: one uint2 per thread, workgroup and query group (score_filter_t16_kernel)
+size_t fused_cursor_save_bytes(int64_t nq_pad) {
+    const int64_t qg = fused_query_group(nq_pad);
+    const int64_t ngroups = (nq_pad / kRBN + qg - 1) / qg;
+    return (size_t)ngroups * 256 * kRingThreads * sizeof(uint2);
+}
+
 // mul coprime to mod, close to mod / golden ratio: consecutive tiles of the scan order land far apart
 int scan_order_multiplier(int64_t mod) {
     if (mod <= 2) return 1;
@@ -481,7 +511,7 @@ int scan_order_multiplier(int64_t mod) {
 
 int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_t nrows, const void* q16,
                         int64_t ldq_elems, int64_t nq_pad, int dpad, const float* tau, uint4* pool, int32_t* pool_cnt,
-                        hipStream_t st, int64_t scramble_tiles, int64_t scramble_base, hipEvent_t ev_a, hipEvent_t ev_b) {
+                        hipStream_t st, int64_t scramble_tiles, int64_t scramble_base, hipEvent_t ev_a, hipEvent_t ev_b, void* cur_save) {
     if (nrows <= 0 || nq_pad <= 0) return LDOT_OK;
     LDOT_REQUIRE(ldx_elems == ldq_elems, LDOT_EINVAL, "index and query shadows must have the same row stride");
     auto rk = score_filter_t16_kernel<0>;
@@ -538,10 +568,31 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     // (ev_a / ev_b, LDOT_OPT_PROFILE: events recorded around the launch.  Attaching them to the dispatch itself — hipExtLaunchKernel — was
     // measured in round 5: the dispatch gaps stay, and the queue stays in its profiling mode afterwards, which slowed LATER searches of
     // other indexes in the same process up to 3x: profiles/r05_secondary_probe.txt)
+    // Row chunks: a sequential scan of more than kChunkTiles tiles for more than one query group goes out as one launch per chunk (same
+    // thresholds, cursors carried in cur_save, ONE pool select after the last): the chunk's rows are read from HBM for the first query group
+    // and from the Infinity Cache for the others.  (The scrambled order has no consecutive chunks; one group reads every row once anyway.)
+    int64_t chunk = kChunkTiles;
+#ifdef LDOT_ABLATION
+    if (const char* e = getenv("LDOT_DEBUG_CHUNK_TILES")) chunk = atoll(e);
+#endif
+    const int64_t ngroups = (nq_pad / kRBN + qg - 1) / qg;
+    const bool chunked = cur_save && scramble_tiles == 0 && chunk > 0 && chunk % nslices == 0 && chunk < ntiles && ngroups > 1;
     if (ev_a) (void)hipEventRecord(ev_a, st);
-    hipLaunchKernelGGL(rk, dim3(256), dim3(kRingThreads), RingGeom<6>::kLds, st, (const char*)x16, ldx_elems * 2, row0,
-                       nrows, (const char*)q16, ldq_elems * 2, (int)(nq_pad / kRBN), dpad / kRBK, tau, pool, pool_cnt,
-                       qg_log2, so);
+    if (!chunked) {
+        hipLaunchKernelGGL(rk, dim3(256), dim3(kRingThreads), RingGeom<6>::kLds, st, (const char*)x16, ldx_elems * 2, row0,
+                           nrows, (const char*)q16, ldq_elems * 2, (int)(nq_pad / kRBN), dpad / kRBK, tau, pool, pool_cnt,
+                           qg_log2, so, (uint2*)nullptr, 0);
+    } else {
+        const int64_t crows = chunk * RingGeom<6>::kBM;
+        for (int64_t r = 0, c = 0; r < nrows; r += crows, ++c) {
+            const int64_t len = std::min(crows, nrows - r);
+            ScanOrder sc = so;
+            sc.dn = (int)((len + RingGeom<6>::kBM - 1) / RingGeom<6>::kBM);
+            hipLaunchKernelGGL(rk, dim3(256), dim3(kRingThreads), RingGeom<6>::kLds, st, (const char*)x16, ldx_elems * 2, row0 + r,
+                               len, (const char*)q16, ldq_elems * 2, (int)(nq_pad / kRBN), dpad / kRBK, tau, pool, pool_cnt,
+                               qg_log2, sc, (uint2*)cur_save, c > 0 ? 1 : 0);
+        }
+    }
     if (ev_b) (void)hipEventRecord(ev_b, st);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
