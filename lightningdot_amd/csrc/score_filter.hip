@@ -570,13 +570,13 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     // other indexes in the same process up to 3x: profiles/r05_secondary_probe.txt)
     // Row chunks: a sequential scan of more than kChunkTiles tiles for more than one query group goes out as one launch per chunk (same
     // thresholds, cursors carried in cur_save, ONE pool select after the last): the chunk's rows are read from HBM for the first query group
-    // and from the Infinity Cache for the others.  (The scrambled order has no consecutive chunks; one group reads every row once anyway.)
+    // and from the Infinity Cache for the others.  (One query group reads every row once anyway.)
     int64_t chunk = kChunkTiles;
 #ifdef LDOT_ABLATION
     if (const char* e = getenv("LDOT_DEBUG_CHUNK_TILES")) chunk = atoll(e);
 #endif
     const int64_t ngroups = (nq_pad / kRBN + qg - 1) / qg;
-    const bool chunked = cur_save && scramble_tiles == 0 && chunk > 0 && chunk % nslices == 0 && chunk < ntiles && ngroups > 1;
+    const bool chunked = cur_save && chunk > 0 && chunk % nslices == 0 && chunk < ntiles && ngroups > 1;
     if (ev_a) (void)hipEventRecord(ev_a, st);
     if (!chunked) {
         hipLaunchKernelGGL(rk, dim3(256), dim3(kRingThreads), RingGeom<6>::kLds, st, (const char*)x16, ldx_elems * 2, row0,
@@ -587,10 +587,16 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
         for (int64_t r = 0, c = 0; r < nrows; r += crows, ++c) {
             const int64_t len = std::min(crows, nrows - r);
             ScanOrder sc = so;
-            sc.dn = (int)((len + RingGeom<6>::kBM - 1) / RingGeom<6>::kBM);
-            hipLaunchKernelGGL(rk, dim3(256), dim3(kRingThreads), RingGeom<6>::kLds, st, (const char*)x16, ldx_elems * 2, row0 + r,
-                               len, (const char*)q16, ldq_elems * 2, (int)(nq_pad / kRBN), dpad / kRBK, tau, pool, pool_cnt,
-                               qg_log2, sc, (uint2*)cur_save, c > 0 ? 1 : 0);
+            const int64_t nt = (len + RingGeom<6>::kBM - 1) / RingGeom<6>::kBM;
+            if (scramble_tiles > 0) {   // (scrambled order: the chunk = the next `chunk` tiles of the pseudo-random order, wherever they lie)
+                sc.base = so.base + (int)(c * chunk);
+                sc.dn = (int)((nt * (int64_t)so.mul) % scramble_tiles);
+            } else {
+                sc.dn = (int)nt;
+            }
+            hipLaunchKernelGGL(rk, dim3(256), dim3(kRingThreads), RingGeom<6>::kLds, st, (const char*)x16, ldx_elems * 2,
+                               scramble_tiles > 0 ? row0 : row0 + r, len, (const char*)q16, ldq_elems * 2, (int)(nq_pad / kRBN), dpad / kRBK, tau,
+                               pool, pool_cnt, qg_log2, sc, (uint2*)cur_save, c > 0 ? 1 : 0);
         }
     }
     if (ev_b) (void)hipEventRecord(ev_b, st);
