@@ -68,10 +68,10 @@ def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> 
 
 
 def build_tools(verbose: bool = True) -> str:
-    """measurement tools with device code (not part of the product library): tools/bin/mfma_ceiling, sstore_probe, l2_stride_probe"""
+    """measurement tools with device code (not part of the product library): tools/bin/mfma_ceiling, sstore_probe, l2_stride_probe, mall_probe"""
     root = os.path.dirname(PKG)
     first = None
-    for name, deps in (('mfma_ceiling', [os.path.join(CSRC, 'gemm_ring.h')]), ('sstore_probe', []), ('l2_stride_probe', [])):
+    for name, deps in (('mfma_ceiling', [os.path.join(CSRC, 'gemm_ring.h')]), ('sstore_probe', []), ('l2_stride_probe', []), ('mall_probe', [])):
         src = os.path.join(root, 'tools', name + '.hip')
         out = os.path.join(root, 'tools', 'bin', name)
         first = first or out
