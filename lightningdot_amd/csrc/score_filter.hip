@@ -571,7 +571,10 @@ int launch_score_filter(const void* x16, int64_t ldx_elems, int64_t row0, int64_
     // Row chunks: a sequential scan of more than kChunkTiles tiles for more than one query group goes out as one launch per chunk (same
     // thresholds, cursors carried in cur_save, ONE pool select after the last): the chunk's rows are read from HBM for the first query group
     // and from the Infinity Cache for the others.  (One query group reads every row once anyway.)
-    int64_t chunk = kChunkTiles;
+    // (kChunkTiles is the chunk at D = 768; other row lengths — and the split-bf16 shadow, three times as long — get the same ~151 MB: a multiple of
+    // the row slices, at least one tile per slice)
+    int64_t chunk = kChunkTiles * 768 / std::max<int64_t>(ldx_elems, 1) / nslices * nslices;
+    if (chunk < nslices) chunk = nslices;
 #ifdef LDOT_ABLATION
     if (const char* e = getenv("LDOT_DEBUG_CHUNK_TILES")) chunk = atoll(e);
 #endif
