@@ -69,7 +69,7 @@ def main():
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to exercise the N > 1 '
                                                       'bookkeeping on a one-GPU box together with --all-on-device0)')
     ap.add_argument('--all-on-device0', action='store_true', help='debug: every rank uses cuda:0')
-    ap.add_argument('--cpu-sample-queries', type=int, default=512)
+    ap.add_argument('--cpu-sample-queries', type=int, default=4096)
     ap.add_argument('--workload', default='synthetic1m', choices=['synthetic1m', 'flickr', 'coco', 'serving'],
                     help='synthetic1m: BASELINE.json configs[3] (the headline); flickr / coco: the retrieval evaluation of configs[1] / '
                          'configs[2] at the SURVEY 8d S2 stand-in shapes (1 000 / 5 000 images x 5 captions, both directions)')
@@ -425,6 +425,8 @@ def secondary_metrics(dev, flat_main, D, K):
     ms_ivf = _median_ms(lambda: ivf.search_knn_tensors(q1, 10, 32, exact_when_cheaper=False), 50)
     ms_exact = _median_ms(lambda: exact.search_knn_tensors(q1, 10), 50)
     sec['loss_step'] = loss_step_metrics(dev, D)
+    del exact, ivf, xc, x_small, small
+    sec['mining_flickr_train'] = mining_metrics(dev, D)
     sec['ivf_123k'] = {'nlist': int(ivf.nlist), 'nprobe': 32, 'ms_1_query': ms_ivf, 'ms_1_query_exact_flat': ms_exact,
                        'recall@10_vs_exact': rec, 'build_s': build_s,
                        'data': '123 287 rows = 500 overlapping Gaussian clusters (centroid spread 0.2, noise 0.5), 768-d'}
@@ -495,6 +497,104 @@ def loss_step_metrics(dev, D):
                      'torch_device_us': us_ref_dev}
     out['what'] = ('train_step_loss forward + backward (both directions of train_itm.py:195-222), fp32, through autograd; end_to_end = wall '
                    'clock per step over 200 back-to-back steps, device = stream time of one step issued behind a busy stream')
+    return out
+
+
+def mining_metrics(dev, D, whole_call=True, ks=(50, 1000)):
+    """The hard-negative mining searches of dvl/hn.py:45-66 at the Flickr30k TRAIN set's size (29 000 images x 145 000 captions; the
+    largest retrieval of the reference: both directions over the train set, num_tops = min(max(2 nh + 10, 50), 1000), every epoch), at
+    num_tops 50 and 1000:
+      * t2i 145 000 x 29 000 and i2t 29 000 x 145 000 (one search per distinct image id: what the harness runs, output-identical to the
+        reference's dict comprehension), plus the reference's un-deduplicated 145 000 x 145 000 for context (default mode only);
+      * per search: device ms of the whole search (events around it), the score kernels' own ms (LDOT_OPT_PROFILE) and their fraction
+        of the bf16 MFMA peak, in the default mode (every candidate re-scored, exact scores) and in the ids-only mode the mining uses
+        (LDOT_OPT_RESULT_SET: the same top-k set, boundary candidates re-scored only) with the share of the candidates it gathered;
+      * the whole sampled_hard_negatives call (fake towers, batches of 4096, nh = 3 -> top-50), wall clock."""
+    import types
+    from lightningdot_amd import _lib as L
+    from lightningdot_amd.hn import sampled_hard_negatives
+    from lightningdot_amd.indexer import FlatIPIndex
+    from lightningdot_amd.synthetic import s2_embeddings
+    n_img, cpi = 29_000, 5
+    img, txt = s2_embeddings(n_img, D, cpi, seed=11, device=dev)
+    ix_img, ix_txt = FlatIPIndex(D), FlatIPIndex(D)
+    ix_img.add(img)
+    ix_txt.add(txt)
+    out = {'images': n_img, 'captions': n_img * cpi, 'dim': D, 'searches': {}}
+
+    def device_ms(fn, n=3):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return sorted(ts)[len(ts) // 2]
+
+    img_rep = None
+    for k in ks:
+        for name, ix, q, modes in (('t2i_145k_x_29k', ix_img, txt, (False, True)), ('i2t_29k_x_145k', ix_txt, img, (False, True)),
+                                   ('i2t_undeduplicated_145k_x_145k', ix_txt, None, (False,))):
+            if q is None:
+                if img_rep is None:
+                    img_rep = img.repeat_interleave(cpi, 0)
+                q = img_rep
+            flops = 2.0 * q.shape[0] * ix.ntotal * D
+            row = {'queries': int(q.shape[0]), 'rows': int(ix.ntotal), 'k': k, 'tflop': flops / 1e12}
+            for ids_only in modes:
+                ms = device_ms(lambda: ix.search_tensors(q, k, ids_only=ids_only))
+                ix.set_option(L.OPT_PROFILE, 1)
+                _, lab = ix.search_tensors(q, k, ids_only=ids_only)
+                prof = ix.last_profile()
+                ix.set_option(L.OPT_PROFILE, 0)
+                m = {'device_ms': ms, 'score_kernel_ms': prof['kernel_ms'], 'score_kernel_frac': flops / (prof['kernel_ms'] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                     'device_ms_over_score_kernel_ms': ms / prof['kernel_ms'], 'regime': ix.last_regime()['path'] + '/' + ix.last_regime()['thresholds']}
+                if ids_only:
+                    st = ix.last_set_stats()
+                    m['candidates_rescored_share'] = st['rescored'] / max(st['candidates'], 1)
+                    m['rows_gathered_GB'] = st['rescored'] * D * 4 / 1e9
+                else:
+                    m['rows_gathered_GB'] = float((lab >= 0).sum().item()) / k * ((k + max(28, k // 4) + 31) // 32 * 32) * D * 4 / 1e9   # k' rows per query
+                if name.startswith('t2i'):
+                    m['rank1_ok'] = bool((lab[:, 0] == torch.arange(q.shape[0], device=dev) // cpi).all()) if not ids_only else \
+                        bool((lab == (torch.arange(q.shape[0], device=dev) // cpi)[:, None]).any(dim=1).all())
+                row['ids_only' if ids_only else 'exact_scores'] = m
+                del lab
+            out['searches'][f'{name}_top{k}'] = row
+    del img_rep
+    if whole_call:
+        class _Towers:
+            def eval(self):
+                return self
+
+            def __call__(self, b):
+                return b['_q'], b['_ctx'], None
+        bs = 4096
+        names_t = [f't{j}' for j in range(n_img * cpi)]
+        names_i = [f'i{j // cpi}' for j in range(n_img * cpi)]
+        img_of = torch.arange(n_img * cpi, device=dev) // cpi
+        batches = [dict(txt_index=names_t[b0:b0 + bs], img_fname=names_i[b0:b0 + bs], txts={'input_ids': torch.zeros(min(bs, n_img * cpi - b0), 1, dtype=torch.long)},
+                        _q=txt[b0:b0 + bs], _ctx=img[img_of[b0:b0 + bs]]) for b0 in range(0, n_img * cpi, bs)]
+        img2txt = {f'i{i}': names_t[i * cpi:(i + 1) * cpi] for i in range(n_img)}
+        txt2img = dict(zip(names_t, names_i))
+        margs = types.SimpleNamespace(hnsw_index=False, vector_size=D, caption_score_weight=0.0, num_hard_negatives=3)
+        g = torch.Generator(device=dev).manual_seed(0)
+        sampled_hard_negatives([batches[:3]], margs, _Towers(), img2txt, txt2img, generator=g)
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            hn_txt, hn_img = sampled_hard_negatives([batches], margs, _Towers(), img2txt, txt2img, generator=g)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        assert len(hn_img) == n_img * cpi and len(hn_txt) == n_img
+        out['sampled_hard_negatives_wall_s'] = sorted(ts)[1]
+        out['sampled_hard_negatives_what'] = ('whole call, fake towers (embeddings in the batches), 36 batches of 4096, nh = 3 -> top-50 both ways, ids-only '
+                                              'searches, positives stripped and negatives drawn on the device, the two {id: [ids]} dicts built; median of 3')
     return out
 
 
@@ -748,62 +848,91 @@ def main_s2(args, world, rank, dev, sharded):
         dist.destroy_process_group()
 
 
+def _blas_vendor():
+    """what the host GEMMs run on (torch's and numpy's BLAS), for the cpu_baseline line"""
+    out = []
+    try:
+        cfg = torch.__config__.show()
+        out.append('torch: ' + ', '.join(sorted({w.strip(' ,') for l in cfg.splitlines() for w in l.split() if w.startswith(('BLAS_INFO=', 'LAPACK_INFO=', 'USE_MKL=', 'USE_MKLDNN='))})))
+    except Exception:
+        pass
+    try:
+        import numpy.__config__ as nc
+        info = nc.show(mode='dicts') if hasattr(nc, 'show') else {}
+        b = info.get('Build Dependencies', {}).get('blas', {})
+        out.append('numpy: %s %s' % (b.get('name', '?'), b.get('version', '')))
+    except Exception:
+        pass
+    return '; '.join(out)
+
+
 def cpu_baseline(x_dev, q_dev, k, nsample, gpu_scores, gpu_labels):
-    """The reference's CPU scorer is faiss IndexFlatIP (fp32 sgemm + per-query selection on the host cores).  faiss is used when it
-    is importable on the box.  Otherwise the baseline is the FASTEST of the restatements of that structure on this host, so that it
-    is not understated by one library's threading behaviour: (a) the stand-in SURVEY 8d prescribes, oracle_torch.search_blocked
-    (torch.matmul over 4096-query x 131072-row tiles + torch.topk(sorted)) at os.cpu_count() threads, (b) the same at half the
-    threads, (c) oracle_np.search_fast (numpy/BLAS sgemm blocks + argpartition).  Each candidate runs once after a warm-up, the
-    fastest runs four more times; `value` is the median of its five runs.  Bounded sample: the first `nsample` queries against the
-    FULL index; plus a one-thread figure on 32 queries.  The same sample is the parity check of the GPU results (rank-1 mismatches
-    and max |delta score| against the fp32 CPU path)."""
+    """The reference's CPU scorer is faiss IndexFlatIP (fp32 sgemm + per-query selection on the host cores); faiss is tried first and
+    used when it is importable on the box.  Otherwise the stand-in SURVEY 8d prescribes: oracle_torch.search_blocked (torch.matmul
+    over 4096-query x 131072-row tiles + torch.topk(sorted)), with the thread count chosen by a sweep (64 / 128 / 256 / all / half of
+    the hardware threads, one run each on the first 1024 queries; numpy's sgemm + argpartition restatement runs in the same sweep, so
+    that one library's threading behaviour does not understate the host).  The winner then searches the bounded sample — the first
+    `nsample` >= 4096 queries (one full 4096-query tile) against the FULL index — three times; `value` is the median.  Plus a
+    one-thread figure on 32 queries.  The same sample is the parity check of the GPU results (rank-1 mismatches and max |delta score|
+    against the fp32 CPU path)."""
     from oracle import oracle_np as O          # checker / baseline only — never on the product path
     from oracle import oracle_torch as OT
     cores = os.cpu_count() or 1
     x = x_dev.cpu()
     q = q_dev[:nsample].cpu()
     xn, qn = x.numpy(), q.numpy()
+    nsweep = min(1024, q.shape[0])
 
     def torch_at(threads):
-        def run():
+        def run(n):
             old = torch.get_num_threads()
             torch.set_num_threads(threads)
             try:
-                s_, l_ = OT.search_blocked(q, x, k)
+                s_, l_ = OT.search_blocked(q[:n], x, k)
             finally:
                 torch.set_num_threads(old)
             return s_.numpy(), l_.numpy()
         return run
 
-    if OT.have_faiss():
+    faiss_used = OT.have_faiss()
+    if faiss_used:
         import faiss
-        faiss.omp_set_num_threads(cores)
-        cands = {'faiss.IndexFlatIP (the reference scorer)': lambda: OT.faiss_search(qn, xn, k)}
+
+        def faiss_at(threads):
+            def run(n):
+                faiss.omp_set_num_threads(threads)
+                return OT.faiss_search(qn[:n], xn, k)
+            return run
+        cands = {f'faiss.IndexFlatIP (the reference scorer), {t} threads': faiss_at(t) for t in sorted({t for t in (64, 128, 256, cores) if 1 <= t <= cores})}
     else:
-        cands = {f'oracle_torch.search_blocked (torch.matmul tiles + torch.topk), {cores} threads': torch_at(cores),
-                 f'oracle_torch.search_blocked, {max(1, cores // 2)} threads': torch_at(max(1, cores // 2)),
-                 'oracle_np.search_fast (numpy BLAS sgemm blocks + argpartition)': lambda: O.search_fast(qn, xn, k)}
+        cands = {f'oracle_torch.search_blocked (torch.matmul 4096-query tiles + torch.topk), {t} threads': torch_at(t)
+                 for t in sorted({t for t in (64, 128, 256, cores, max(1, cores // 2)) if 1 <= t <= cores})}
+        cands['oracle_np.search_fast (numpy BLAS sgemm blocks + argpartition)'] = lambda n: O.search_fast(qn[:n], xn, k)
     OT.search_blocked(q[:8], x[:4096], k)
     O.search_fast(qn[:8], xn[:4096], k)
-    first, res = {}, {}
+    sweep = {}
     for name, fn in cands.items():
         t0 = time.perf_counter()
-        res[name] = fn()
-        first[name] = time.perf_counter() - t0
-    best = min(first, key=first.get)
-    ts = [first[best]]
-    for _ in range(4):
+        fn(nsweep)
+        sweep[name] = time.perf_counter() - t0
+    best = min(sweep, key=sweep.get)
+    ts, res = [], None
+    for _ in range(3):
         t0 = time.perf_counter()
-        cands[best]()
+        res = cands[best](q.shape[0])
         ts.append(time.perf_counter() - t0)
-    dt = sorted(ts)[2]
-    cs, cl = res[best]
+    dt = sorted(ts)[1]
+    cs, cl = res
     n1 = min(32, q.shape[0])
     dt1, _, _ = OT.timed(q[:n1], x, k, 1, runs=3)
-    base = {'value': q.shape[0] / dt, 'unit': 'queries/s', 'cores': int(cores), 'kind': 'port',
-            'sample': f'first {q.shape[0]} queries x full {x.shape[0]} x {x.shape[1]} fp32 index, top-{k}; fastest of '
-                      f'{len(cands)} host scorers: {best}; median of 5 runs after warm-up, {dt:.2f} s per run',
-            'candidates_first_run_s': {n: round(t, 3) for n, t in first.items()},
+    flops = 2.0 * q.shape[0] * x.shape[0] * x.shape[1]
+    m_thr = __import__('re').search(r', (\d+) threads', best)
+    used = int(m_thr.group(1)) if m_thr else int(cores)      # (numpy's BLAS pool: all hardware threads)
+    base = {'value': q.shape[0] / dt, 'unit': 'queries/s', 'cores': used, 'hardware_threads': int(cores), 'kind': 'reference' if faiss_used else 'port',
+            'scorer': best, 'faiss_importable': bool(faiss_used), 'blas': _blas_vendor(), 'host_tflops_fp32': flops / dt / 1e12,
+            'sample': f'first {q.shape[0]} queries (4096-query tiles) x full {x.shape[0]} x {x.shape[1]} fp32 index, top-{k}; scorer and thread count '
+                      f'chosen by a sweep on the first {nsweep} queries; median of 3 runs, {dt:.2f} s per run',
+            'sweep_s_on_%d_queries' % nsweep: {n: round(t, 3) for n, t in sweep.items()},
             'value_1thread': n1 / dt1, 'sample_1thread': f'first {n1} queries, torch scorer, 1 thread, median of 3 runs, {dt1:.2f} s per run'}
     gs, gl = gpu_scores[:q.shape[0]], gpu_labels[:q.shape[0]]
     scale = float(np.abs(cs).max()) or 1.0

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDOT_ABI_VERSION 6
+#define LDOT_ABI_VERSION 7
 
 /* status codes */
 #define LDOT_OK 0
@@ -100,6 +100,16 @@ extern "C" {
                                  * off: ONE wait instead of two, no idle gap between the searches.  The index, the queries and the output buffers
                                  * must stay untouched until then.  Pageable outputs and searches under LDOT_OPT_PROFILE / LDOT_OPT_VERIFY wait
                                  * as before (the host reads their events / flags).  0 (default): a search returns with its results in place */
+#define LDOT_OPT_RESULT_SET 15  /* 1: searches report the top-k SET for consumers that keep the ids and drop scores and order — hard-negative mining
+                                 * (dvl/hn.py:54-63 keeps r[0], strips the positives and samples at random), the largest searches of the reference
+                                 * (every train caption x every train image and back, top 50 .. 1000, every epoch).  A candidate whose bf16 score
+                                 * lies more than 2E above the k-th candidate score is in the exact top-k whatever its exact score is, one more than
+                                 * 2E below it is not (E = the error bound of LDOT_OPT_VERIFY): only the candidates in between are gathered from the
+                                 * fp32 master copy (3 KiB per row) and ordered exactly.  The k labels are those of the default search (same set,
+                                 * ties at the boundary to the lower label) whenever the bound holds for the candidates; their ORDER is: the
+                                 * certain ones by candidate score — their reported score is the bf16-input score —, then the boundary's winners
+                                 * by exact score.  Sharded searches (a floor), LDOT_OPT_RESCORE 0 and LDOT_OPT_VERIFY ignore / are ignored by
+                                 * the option.  0 (default): exact scores, descending.  See ldot_index_last_set_stats */
 #define LDOT_OPT_VERIFY 10      /* 1: after every search flag the queries whose top-k cannot be vouched for: the k-th exact score is not above
                                  * the candidate threshold by E = 4 * 2^-8 * |q| * max|x| / sqrt(d), a STATISTICAL bound of the bf16
                                  * rounding error of a d-term inner product (4 standard deviations for independent rounding errors;
@@ -247,6 +257,9 @@ int ldot_index_last_stats(const ldot_index_t* ix, int64_t out[4]);
  *   out[6] 1: the index switched itself to the scrambled tile order (LDOT_OPT_SCAN_ORDER auto)
  *   out[7] rows: 0 stored as added, 1 shuffled at add time, 2 re-ordered by the library (LDOT_OPT_ROW_SHUFFLE auto) */
 int ldot_index_last_regime(const ldot_index_t* ix, int64_t out[8]);
+/* LDOT_OPT_RESULT_SET = 1: out[0] = candidates of the last search that were re-scored exactly, out[1] = its live candidates (what the default
+ * search gathers).  Drains the device (a measurement aid). */
+int ldot_index_last_set_stats(ldot_index_t* ix, int64_t out[2]);
 /* LDOT_OPT_VERIFY = 1: flags_out [nq of the last search] (host, may be NULL) receives 1 for every query whose result is not proven
  * exact, *count_out their number.  No reference counterpart (faiss IndexFlatIP is fp32 end to end); this is how the bf16 candidate
  * pass reports that its margin may have been too small for a query. */

@@ -18,8 +18,9 @@ OPT_OPTIMISTIC = 11
 OPT_SCAN_ORDER = 12
 OPT_ROW_SHUFFLE = 13
 OPT_DEFER_SYNC = 14
+OPT_RESULT_SET = 15
 OPT_VERIFY = 10
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_MARGIN = 1024
 PAD_LABEL = -1
 PAD_SCORE = -3.4028234663852886e+38
@@ -56,6 +57,7 @@ SYMBOLS = {
     'ldot_index_last_stats': (_i, [_vp, _c.POINTER(_i64)]),
     'ldot_index_last_regime': (_i, [_vp, _c.POINTER(_i64)]),
     'ldot_index_last_unproven': (_i, [_vp, _vp, _c.POINTER(_i64)]),
+    'ldot_index_last_set_stats': (_i, [_vp, _c.POINTER(_i64)]),
     'ldot_index_last_profile': (_i, [_vp, _c.POINTER(_c.c_double)]),
     'ldot_merge_topk': (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _i, _vp]),
     'ldot_cls_pool': (_i, [_vp, _i, _i64, _i64, _i64, _i, _vp, _vp, _vp]),

@@ -76,6 +76,9 @@ struct ldot_index {
     bool warm_rows_set = false;   // LDOT_OPT_WARM_ROWS was set by the caller (a shard on pooled statistics otherwise warms up on fewer rows)
     int growth_pct = 150;
     int defer_sync = 0;           // LDOT_OPT_DEFER_SYNC
+    int result_set = 0;           // LDOT_OPT_RESULT_SET: searches report the top-k SET (exact re-score of the boundary candidates only)
+    DevBuf w_set_stats;           // {candidates gathered, live candidates} of the last search in that mode (two uint64 on the device)
+    bool set_stats_valid = false;
     struct ProfEv {
         hipEvent_t a, b;
         double flops, bytes;
@@ -346,6 +349,7 @@ int ldot_index_destroy(ldot_index_t* ix) {
     ix->w_label.release();
     ix->w_pos.release();
     ix->w_unproven.release();
+    ix->w_set_stats.release();
     ix->w_norm.release();
     ix->w_nmax.release();
     ix->w_ntau.release();
@@ -477,6 +481,10 @@ int ldot_index_set_option(ldot_index_t* ix, int option, int64_t value) {
             LDOT_REQUIRE(value == 0 || value == 1, LDOT_EINVAL, "LDOT_OPT_DEFER_SYNC is 0 or 1");
             ix->defer_sync = (int)value;
             return LDOT_OK;
+        case LDOT_OPT_RESULT_SET:
+            LDOT_REQUIRE(value == 0 || value == 1, LDOT_EINVAL, "LDOT_OPT_RESULT_SET is 0 or 1");
+            ix->result_set = (int)value;
+            return LDOT_OK;
         case LDOT_OPT_GROWTH_PCT:
             LDOT_REQUIRE(value >= 5 && value <= 10000, LDOT_EINVAL, "growth_pct must be in [5, 10000]");
             ix->growth_pct = (int)value;
@@ -534,13 +542,18 @@ int ldot_index_get_rows(ldot_index_t* ix, int64_t row0, int64_t n, float* out, i
     if (n == 0) return LDOT_OK;
     DeviceGuard guard(ix->device);
     hipStream_t st = (hipStream_t)stream;
-    if (ix->shuffled) {   // rows are addressed by LABEL: gathered through the position table
-        int rc = ix->w_stage.ensure((size_t)n * ix->dpad * 4);
+    if (ix->shuffled) {   // rows are addressed by LABEL: gathered through the position table, in bounded chunks (ldot_index_save asks for
+                          // the whole index at once: a full-size staging copy would double the fp32 footprint for the duration)
+        constexpr int64_t kGatherChunk = 65536;
+        int rc = ix->w_stage.ensure((size_t)std::min(n, kGatherChunk) * ix->dpad * 4);
         if (rc) return rc;
-        if ((rc = launch_gather_rows_f32(ix->x32, ix->dpad, (const int32_t*)ix->w_pos.p + row0, n, n, (float*)ix->w_stage.p, st))) return rc;
-        LDOT_HIP_CHECK(hipMemcpy2DAsync(out, (size_t)ix->d * 4, ix->w_stage.p, (size_t)ix->dpad * 4, (size_t)ix->d * 4, (size_t)n,
-                                        out_mem == LDOT_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
-        LDOT_HIP_CHECK(hipStreamSynchronize(st));   // (the staging buffer is reused)
+        for (int64_t r = 0; r < n; r += kGatherChunk) {
+            const int64_t len = std::min(kGatherChunk, n - r);
+            if ((rc = launch_gather_rows_f32(ix->x32, ix->dpad, (const int32_t*)ix->w_pos.p + row0 + r, len, len, (float*)ix->w_stage.p, st))) return rc;
+            LDOT_HIP_CHECK(hipMemcpy2DAsync(out + r * ix->d, (size_t)ix->d * 4, ix->w_stage.p, (size_t)ix->dpad * 4, (size_t)ix->d * 4, (size_t)len,
+                                            out_mem == LDOT_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
+            LDOT_HIP_CHECK(hipStreamSynchronize(st));   // (the staging buffer is reused)
+        }
         return LDOT_OK;
     }
     LDOT_HIP_CHECK(hipMemcpy2DAsync(out, (size_t)ix->d * 4, ix->x32 + row0 * ix->dpad, (size_t)ix->dpad * 4,
@@ -592,6 +605,18 @@ int ldot_index_last_unproven(ldot_index_t* ix, int32_t* flags_out, int64_t* coun
         if (flags_out) LDOT_HIP_CHECK(hipMemcpy(flags_out, ix->w_unproven.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     }
     if (count_out) *count_out = cnt;
+    return LDOT_OK;
+}
+
+int ldot_index_last_set_stats(ldot_index_t* ix, int64_t out[2]) {
+    LDOT_REQUIRE(ix != nullptr && out != nullptr, LDOT_EINVAL, "NULL argument");
+    out[0] = out[1] = 0;
+    if (!ix->set_stats_valid || ix->w_set_stats.p == nullptr) return LDOT_OK;
+    DeviceGuard guard(ix->device);
+    unsigned long long h[2] = {0, 0};
+    LDOT_HIP_CHECK(hipMemcpy(h, ix->w_set_stats.p, 16, hipMemcpyDeviceToHost));   // (drains the device: a measurement aid)
+    out[0] = (int64_t)h[0];
+    out[1] = (int64_t)h[1];
     return LDOT_OK;
 }
 
@@ -1576,7 +1601,7 @@ static int search_finish_impl(ldot_index_t* ix, const float* floor, float* out_s
     const int32_t* lmap = ix->shuffled ? (const int32_t*)ix->w_label.p : nullptr;   // (LDOT_OPT_ROW_SHUFFLE: stored row -> label)
     // LDOT_OPT_VERIFY (plain searches only: a sharded search compares against the GLOBAL threshold, which this shard cannot judge)
     auto verify = [&](const float* dev_s, const int64_t* dev_l) -> int {
-        if (!ix->verify || floor != nullptr || !ix->rescore || ix->w_norm.p == nullptr) return LDOT_OK;
+        if (!ix->verify || floor != nullptr || !ix->rescore || ix->w_norm.p == nullptr || ix->result_set) return LDOT_OK;
         int vrc = ix->w_unproven.ensure((size_t)(nq + 1) * 4);
         if (vrc) return vrc;
         LDOT_HIP_CHECK(hipMemsetAsync((int32_t*)ix->w_unproven.p + nq, 0, 4, st));
@@ -1584,10 +1609,24 @@ static int search_finish_impl(ldot_index_t* ix, const float* floor, float* out_s
         return launch_verify_exact((const float*)ix->w_q32.p, ix->dpad, ix->d, nq, dev_s, dev_l, k, (const float*)ix->w_tau.p,
                                    (const float*)ix->w_norm.p, (int32_t*)ix->w_unproven.p, (int32_t*)ix->w_unproven.p + nq, st);
     };
+    // LDOT_OPT_RESULT_SET (plain searches with the exact re-score on): the top-k set, boundary candidates re-scored only
+    const bool as_set = ix->result_set && floor == nullptr && ix->rescore && ix->w_norm.p != nullptr;
+    ix->set_stats_valid = false;
+    if (as_set) {
+        if ((rc = ix->w_set_stats.ensure(16))) return rc;
+        LDOT_HIP_CHECK(hipMemsetAsync(ix->w_set_stats.p, 0, 16, st));
+        ix->set_stats_valid = true;
+    }
+    auto rescore_to = [&](float* os, int64_t* ol) -> int {
+        if (as_set)
+            return launch_rescore_set((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, ix->d, nq, (const float*)ix->w_ls.p,
+                                      (const int32_t*)ix->w_li.p, kp, k, (const float*)ix->w_norm.p, kVerifyC, os, ol, lmap,
+                                      (unsigned long long*)ix->w_set_stats.p, st);
+        return launch_rescore((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, nq, (const float*)ix->w_ls.p,
+                              (const int32_t*)ix->w_li.p, kp, k, ix->rescore, floor, os, ol, st, nullptr, lmap);
+    };
     if (out_mem == LDOT_DEVICE) {   // device outputs are written by the re-score kernel directly
-        if ((rc = launch_rescore((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, nq, (const float*)ix->w_ls.p,
-                                 (const int32_t*)ix->w_li.p, kp, k, ix->rescore, floor, out_scores, out_labels, st, nullptr, lmap)))
-            return rc;
+        if ((rc = rescore_to(out_scores, out_labels))) return rc;
         if ((rc = verify(out_scores, out_labels))) return rc;
         prof_collect(ix, st);
         return LDOT_OK;
@@ -1599,9 +1638,7 @@ static int search_finish_impl(ldot_index_t* ix, const float* floor, float* out_s
                         hipHostGetDevicePointer(&ml, out_labels, 0) == hipSuccess && ml != nullptr;
     (void)hipGetLastError();   // (a pageable buffer makes the query fail: not an error of this call)
     if (mapped) {
-        if ((rc = launch_rescore((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, nq, (const float*)ix->w_ls.p,
-                                 (const int32_t*)ix->w_li.p, kp, k, ix->rescore, floor, (float*)ms, (int64_t*)ml, st, nullptr, lmap)))
-            return rc;
+        if ((rc = rescore_to((float*)ms, (int64_t*)ml))) return rc;
         if ((rc = verify((const float*)ms, (const int64_t*)ml))) return rc;
         // LDOT_OPT_DEFER_SYNC: the caller synchronises (everything this search used stays alive until the handle's next call on this
         // stream).  Profiling events are read on the host and the verify flags are the caller's to read: both keep the synchronisation.
@@ -1613,10 +1650,7 @@ static int search_finish_impl(ldot_index_t* ix, const float* floor, float* out_s
     // pageable host buffers: device workspace + two copies (hipMemcpyAsync stages them through the runtime's pinned buffers)
     if ((rc = ix->w_outs.ensure((size_t)nq * k * 4))) return rc;
     if ((rc = ix->w_outl.ensure((size_t)nq * k * 8))) return rc;
-    if ((rc = launch_rescore((const float*)ix->w_q32.p, ix->dpad, ix->x32, ix->dpad, ix->dpad, nq, (const float*)ix->w_ls.p,
-                             (const int32_t*)ix->w_li.p, kp, k, ix->rescore, floor, (float*)ix->w_outs.p,
-                             (int64_t*)ix->w_outl.p, st, nullptr, lmap)))
-        return rc;
+    if ((rc = rescore_to((float*)ix->w_outs.p, (int64_t*)ix->w_outl.p))) return rc;
     if ((rc = verify((const float*)ix->w_outs.p, (const int64_t*)ix->w_outl.p))) return rc;
     LDOT_HIP_CHECK(hipMemcpyAsync(out_scores, ix->w_outs.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
     LDOT_HIP_CHECK(hipMemcpyAsync(out_labels, ix->w_outl.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
@@ -1664,7 +1698,8 @@ int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dty
     // where the final top-k may be written by a kernel directly (device memory, or pinned host memory through its device mapping):
     // a few-query search then ends in ONE kernel after the scan (narrow_finish_kernel)
     DirectOut direct{nullptr, nullptr, k};
-    if (nq > 0 && ix && !ix->verify && !ix->shuffled) {   // (a shuffled index translates rows to labels in the re-score kernel)
+    if (nq > 0 && ix && !ix->verify && !ix->shuffled && !ix->result_set) {   // (a shuffled index translates rows to labels in the re-score kernel;
+                                                                            // the top-k set is decided there)
         if (out_mem == LDOT_DEVICE) {
             direct.scores = out_scores;
             direct.labels = out_labels;

@@ -9,6 +9,7 @@ constexpr int kBN = 256;           // dense chunks cover a multiple of this many
 constexpr int kBK = 64;            // the feature dimension is padded to a multiple of this
 constexpr int kMaxK = 2048;        // largest k of a search
 constexpr int kMaxKp = 3072;       // largest candidate-list length k' = k + margin: k' + 1024 keys fit a 32 KiB LDS buffer
+constexpr float kVerifyC = 4.0f;   // c of the statistical bf16 score-error bound E = c * 2^-8 * |q| * max|x| / sqrt(d) (LDOT_OPT_VERIFY, LDOT_OPT_RESULT_SET)
 constexpr int kSelThreads = 256;
 
 // fused-filter candidate pools: per query, nsubs = kPoolSubsPerSlice * (row slices) sub-pools of kPoolCap RECORDS.  A record is what
@@ -171,6 +172,11 @@ int launch_rescore(const float* q32, int64_t ldq, const float* x32, int64_t ldx,
                    const float* list_s, const int32_t* list_i, int kp, int k, int do_rescore, const float* floor,
                    float* out_s, int64_t* out_l, hipStream_t st,
                    const RescoreOut* layout = nullptr, const int32_t* label_map = nullptr);
+// LDOT_OPT_RESULT_SET (rescore.hip): the top-k SET — only the candidates within 2E of the k-th candidate score are re-scored exactly
+// (E = band_c * 2^-8 * |q| * max_norm / sqrt(d)); stats (optional, device): [0] += candidates gathered, [1] += live candidates
+int launch_rescore_set(const float* q32, int64_t ldq, const float* x32, int64_t ldx, int dpad, int d, int64_t nq, const float* list_s,
+                       const int32_t* list_i, int kp, int k, const float* max_norm, float band_c, float* out_s, int64_t* out_l,
+                       const int32_t* label_map, unsigned long long* stats, hipStream_t st);
 
 // running maximum of the L2 norms of the rows of a padded fp32 matrix (atomicMax into *out_max, a non-negative float)
 int launch_row_norm_max(const float* x32, int64_t ld, int64_t n, int d, float* out_max, hipStream_t st);

@@ -880,11 +880,26 @@ struct LossWs {
     hipStream_t stream;
     void* p;
     size_t bytes;
+    int users;   // launchers between loss_workspace() and the end of their enqueue (LossLease): never evicted while > 0
 };
 std::mutex g_loss_mu;
 std::vector<LossWs> g_loss_ws;
 
-int loss_workspace(hipStream_t st, size_t need, char** out) {
+// held by a launcher while it enqueues the kernels that use the workspace: another host thread that needs a slot must not free this one
+// before they are on the stream (afterwards the eviction's hipDeviceSynchronize covers them)
+struct LossLease {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool held = false;
+    ~LossLease() {
+        if (!held) return;
+        std::lock_guard<std::mutex> lock(g_loss_mu);
+        for (LossWs& w : g_loss_ws)
+            if (w.device == device && w.stream == stream && w.users > 0) --w.users;
+    }
+};
+
+int loss_workspace(hipStream_t st, size_t need, char** out, LossLease* lease) {
     int dev = 0;
     LDOT_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_loss_mu);
@@ -898,15 +913,15 @@ int loss_workspace(hipStream_t st, size_t need, char** out) {
         size_t mine = 0, oldest = g_loss_ws.size();
         for (size_t i = 0; i < g_loss_ws.size(); ++i)
             if (g_loss_ws[i].device == dev) {
-                if (oldest == g_loss_ws.size()) oldest = i;
+                if (oldest == g_loss_ws.size() && g_loss_ws[i].users == 0) oldest = i;   // (a workspace another thread is launching on stays)
                 ++mine;
             }
-        if (mine >= kLossWsPerDevice) {
+        if (mine >= kLossWsPerDevice && oldest < g_loss_ws.size()) {
             LDOT_HIP_CHECK(hipDeviceSynchronize());
             if (g_loss_ws[oldest].p) (void)hipFree(g_loss_ws[oldest].p);
             g_loss_ws.erase(g_loss_ws.begin() + (long)oldest);
         }
-        g_loss_ws.push_back(LossWs{dev, st, nullptr, 0});
+        g_loss_ws.push_back(LossWs{dev, st, nullptr, 0, 0});
         ws = &g_loss_ws.back();
     }
     if (ws->bytes < need) {
@@ -921,6 +936,10 @@ int loss_workspace(hipStream_t st, size_t need, char** out) {
         LDOT_HIP_CHECK(hipMemsetAsync(ws->p, 0, 256, st));   // the finish kernel's arrival counter: zero now, reset by its last workgroup
     }
     *out = (char*)ws->p;
+    ++ws->users;
+    lease->device = dev;
+    lease->stream = st;
+    lease->held = true;
     return LDOT_OK;
 }
 }  // namespace
@@ -939,7 +958,8 @@ static int launch_nll_fwd_fused(const float* q, const float* ctx, const float* c
     const size_t b_cnt = 256, b_st = (size_t)round_up(n1 * ntn * 16, 256), b_spos = (size_t)round_up(n1 * 4, 256),
                  b_ps = (size_t)round_up(nfin * 8, 256), b_po = (size_t)round_up(nfin * 4, 256);
     char* ws = nullptr;
-    int rc = loss_workspace(st, b_cnt + b_st + b_spos + b_ps + b_po, &ws);
+    LossLease lease;
+    int rc = loss_workspace(st, b_cnt + b_st + b_spos + b_ps + b_po, &ws, &lease);
     if (rc) return rc;
     NllFused nll{};
     nll.pos = pos;
@@ -977,7 +997,8 @@ int ldot_inbatch_nll_bidir_fwd(const float* img, const float* txt, const int32_t
         // shapes beyond the direct kernel (or ragged K): the two directions one after the other on the staged kernels
         const size_t b_small = 256;
         char* ws = nullptr;
-        int rc = loss_workspace(st, 256 + b_small, &ws);
+        LossLease lease;
+        int rc = loss_workspace(st, 256 + b_small, &ws, &lease);
         if (rc) return rc;
         float* lsum = (float*)(ws + 256);
         int32_t* corr = (int32_t*)(ws + 256 + 64);
@@ -995,7 +1016,8 @@ int ldot_inbatch_nll_bidir_fwd(const float* img, const float* txt, const int32_t
     const size_t b_cnt = 256, b_st1 = (size_t)round_up(bs * ntn1 * 16, 256), b_st2 = (size_t)round_up(bs * nt2 * 16, 256),
                  b_spos = (size_t)round_up(bs * 4, 256), b_ps = (size_t)round_up(2 * nfin * 8, 256), b_po = (size_t)round_up(2 * nfin * 4, 256);
     char* ws = nullptr;
-    int rc = loss_workspace(st, b_cnt + b_st1 + b_st2 + 2 * b_spos + b_ps + b_po, &ws);
+    LossLease lease;
+    int rc = loss_workspace(st, b_cnt + b_st1 + b_st2 + 2 * b_spos + b_ps + b_po, &ws, &lease);
     if (rc) return rc;
     uint4* stat1 = (uint4*)(ws + b_cnt);
     uint4* stat2 = (uint4*)(ws + b_cnt + b_st1);

@@ -127,6 +127,165 @@ __global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __rest
     }
 }
 
+// LDOT_OPT_RESULT_SET: the caller consumes the top-k SET (hard-negative mining keeps the ids and samples from them, dvl/hn.py:54-63), not the
+// scores and not the order.  Which candidates are among the k best by exact score is then already decided by the bf16 candidate scores for all
+// but a band around the k-th: with |exact - bf16| <= E for every candidate (E = the bound of LDOT_OPT_VERIFY: c * 2^-8 * |q| * max|x| / sqrt(d)) and
+// c_(k) the k-th largest candidate score,
+//     c_i > c_(k) + 2E  =>  every row that beats i exactly has a candidate score above c_(k): fewer than k of them  =>  i is IN,
+//     c_i < c_(k) - 2E  =>  the k rows at or above c_(k) all beat i exactly                                        =>  i is OUT,
+// and only the candidates in between are gathered from the fp32 master copy (3 KiB per row — the cost of a mining search at top-1000) and
+// ordered exactly; the k - #IN best of them complete the set.  Under that bound the labels are the set the full re-score reports (ties at
+// the boundary broken by the lower label, as there).  Output order: the IN candidates by candidate score (their reported score IS the bf16-input
+// candidate score), then the band's winners by exact score.  stats[0] += candidates gathered, stats[1] += live candidates.
+template <int kRsThreads>
+__global__ __launch_bounds__(kRsThreads) void rescore_set_kernel(const float* __restrict__ q32, int64_t ldq, const float* __restrict__ x32,
+                                                                 int64_t ldx, int dpad, int d, const float* __restrict__ list_s,
+                                                                 const int32_t* __restrict__ list_i, int kp, int k,
+                                                                 const float* __restrict__ max_norm, float band_c, float* __restrict__ out_s,
+                                                                 int64_t* __restrict__ out_l, const int32_t* __restrict__ label_map,
+                                                                 unsigned long long* __restrict__ stats, int64_t nq) {
+    __shared__ __attribute__((aligned(16))) uint64_t keys[4096];
+    __shared__ int m_sh, a_sh, b_sh;
+    __shared__ float qq_sh[kRsThreads / 64];
+    int64_t q = blockIdx.x;
+    if (gridDim.x >= 128) {   // (the block -> query map of rescore_kernel)
+        const int64_t r = q & 127;
+        q = (q - r) + (r & 7) * 16 + (r >> 3);
+    }
+    if (q >= nq) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* qrow = q32 + q * ldq;
+    if (threadIdx.x == 0) m_sh = a_sh = b_sh = 0;
+    __syncthreads();
+    // 1. live candidates -> keys[0..m) = {descending key of the candidate score, stored row}, sorted best first
+    for (int e0 = 0; e0 < kp; e0 += kRsThreads) {
+        const int e = e0 + threadIdx.x;
+        int32_t r = -1;
+        float cs = 0.f;
+        if (e < kp) {
+            r = list_i[q * kp + e];
+            cs = list_s[q * kp + e];
+        }
+        const bool live = r >= 0;
+        const unsigned long long mask = __ballot(live);
+        int base = 0;
+        if (lane == 0 && mask) base = atomicAdd(&m_sh, __popcll(mask));
+        base = __shfl(base, 0);
+        if (live) keys[base + __popcll(mask & ((1ull << lane) - 1ull))] = ((uint64_t)desc_key(cs) << 32) | (uint32_t)r;
+    }
+    // |q|^2 (the band is relative to the query's norm)
+    float qq = 0.f;
+    for (int c = threadIdx.x; c < d; c += kRsThreads) qq = fmaf(qrow[c], qrow[c], qq);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) qq += __shfl_xor(qq, o);
+    if (lane == 0) qq_sh[wave] = qq;
+    __syncthreads();
+    const int m = m_sh;
+    int P = 2;
+    while (P < m) P <<= 1;
+    for (int e = m + threadIdx.x; e < P; e += kRsThreads) keys[e] = ~0ull;
+    __syncthreads();
+    bitonic_sort_lds(keys, P);
+    float* os = out_s + q * k;
+    int64_t* ol = out_l + q * k;
+    if (m <= k) {   // everything there is belongs to the set
+        for (int e = threadIdx.x; e < k; e += kRsThreads) {
+            const uint64_t key = (e < m) ? keys[e] : ~0ull;
+            if (key != ~0ull) {
+                const int32_t r = (int32_t)(uint32_t)key;
+                os[e] = desc_key_to_float((uint32_t)(key >> 32));
+                ol[e] = label_map ? label_map[r] : r;
+            } else {
+                os[e] = LDOT_PAD_SCORE;
+                ol[e] = LDOT_PAD_LABEL;
+            }
+        }
+        if (threadIdx.x == 0 && stats) atomicAdd(stats + 1, (unsigned long long)m);
+        return;
+    }
+    // 2. the band [a, b) of the sorted list around the k-th candidate score
+    qq = 0.f;
+#pragma unroll
+    for (int w = 0; w < kRsThreads / 64; ++w) qq += qq_sh[w];
+    const float ck = desc_key_to_float((uint32_t)(keys[k - 1] >> 32));
+    const float band = 2.f * band_c * 0.00390625f * sqrtf(qq) * max_norm[0] * rsqrtf((float)d);
+    const float hi = ck + band, lo = ck - band;
+    int na = 0, nb = 0;
+    for (int e = threadIdx.x; e < m; e += kRsThreads) {
+        const float c = desc_key_to_float((uint32_t)(keys[e] >> 32));
+        na += c > hi;
+        nb += !(c < lo);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        na += __shfl_xor(na, o);
+        nb += __shfl_xor(nb, o);
+    }
+    if (lane == 0) {
+        if (na) atomicAdd(&a_sh, na);
+        if (nb) atomicAdd(&b_sh, nb);
+    }
+    __syncthreads();
+    const int a = a_sh, b = b_sh;   // a <= k - 1 < b
+    // 3. exact scores of the band; final keys = {class (0 IN, 1 band), descending score key, label}: one more sort orders the IN candidates by
+    //    candidate score, then the band by exact score and label
+    constexpr int U = 4;
+    for (int e0 = a + wave * U; e0 < b; e0 += (kRsThreads / 64) * U) {
+        int32_t r[U];
+        float s[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) r[u] = (e0 + u < b) ? (int32_t)(uint32_t)keys[e0 + u] : -1;
+        float acc[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u][0] = acc[u][1] = acc[u][2] = acc[u][3] = 0.f;
+        for (int c = lane * 4; c < dpad; c += 256) {   // (the arithmetic of rescore_kernel: same exact scores bit for bit)
+            const f32x4 qv = *(const f32x4*)(qrow + c);
+            f32x4 xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                xv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (r[u] >= 0) xv[u] = *(const f32x4*)(x32 + (int64_t)r[u] * ldx + c);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc[u][0] = fmaf(xv[u][0], qv[0], acc[u][0]);
+                acc[u][1] = fmaf(xv[u][1], qv[1], acc[u][1]);
+                acc[u][2] = fmaf(xv[u][2], qv[2], acc[u][2]);
+                acc[u][3] = fmaf(xv[u][3], qv[3], acc[u][3]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            s[u] = (acc[u][0] + acc[u][1]) + (acc[u][2] + acc[u][3]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s[u] += __shfl_xor(s[u], o);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (e0 + u < b)
+                    keys[e0 + u] = (1ull << 63) | ((uint64_t)desc_key(s[u]) << 31) | (uint32_t)(label_map ? label_map[r[u]] : r[u]);
+        }
+    }
+    for (int e = threadIdx.x; e < a; e += kRsThreads) {
+        const uint64_t kv = keys[e];
+        const int32_t r = (int32_t)(uint32_t)kv;
+        keys[e] = ((kv >> 32) << 31) | (uint32_t)(label_map ? label_map[r] : r);
+    }
+    for (int e = b + threadIdx.x; e < m; e += kRsThreads) keys[e] = ~0ull;
+    __syncthreads();
+    bitonic_sort_lds(keys, P);
+    for (int e = threadIdx.x; e < k; e += kRsThreads) {
+        const uint64_t key = keys[e];
+        os[e] = desc_key_to_float((uint32_t)(key >> 31));
+        ol[e] = (int64_t)(key & 0x7fffffffull);
+    }
+    if (threadIdx.x == 0 && stats) {
+        atomicAdd(stats, (unsigned long long)(b - a));
+        atomicAdd(stats + 1, (unsigned long long)m);
+    }
+}
+
 // ---- approximate (IVF) search: exact fp32 scores of a query against the rows of its probed lists ---------------------------------
 // The reference's approximate alternative is faiss.IndexHNSWFlat (dvl/indexer/faiss_indexers.py:90-154); a graph walk is a poor fit
 // for a wide machine, an inverted-file scan is not: the rows are stored sorted by list, a query reads nprobe contiguous row ranges of
@@ -253,7 +412,21 @@ int launch_verify_exact(const float* q32, int64_t ldq, int d, int64_t nq, const 
                         const float* tau, const float* max_norm, int32_t* flags, int32_t* count, hipStream_t st) {
     if (nq <= 0) return LDOT_OK;
     hipLaunchKernelGGL(verify_exact_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, q32, ldq, d, nq, out_s, out_l, k,
-                       tau, max_norm, 4.0f, flags, count);
+                       tau, max_norm, kVerifyC, flags, count);
+    LDOT_HIP_CHECK(hipGetLastError());
+    return LDOT_OK;
+}
+
+int launch_rescore_set(const float* q32, int64_t ldq, const float* x32, int64_t ldx, int dpad, int d, int64_t nq, const float* list_s,
+                       const int32_t* list_i, int kp, int k, const float* max_norm, float band_c, float* out_s, int64_t* out_l,
+                       const int32_t* label_map, unsigned long long* stats, hipStream_t st) {
+    if (nq <= 0) return LDOT_OK;
+    if (nq <= 128)
+        hipLaunchKernelGGL(rescore_set_kernel<1024>, dim3((unsigned)nq), dim3(1024), 0, st, q32, ldq, x32, ldx, dpad, d, list_s, list_i, kp, k,
+                           max_norm, band_c, out_s, out_l, label_map, stats, nq);
+    else
+        hipLaunchKernelGGL(rescore_set_kernel<256>, dim3((unsigned)round_up(nq, 128)), dim3(256), 0, st, q32, ldq, x32, ldx, dpad, d, list_s,
+                           list_i, kp, k, max_norm, band_c, out_s, out_l, label_map, stats, nq);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

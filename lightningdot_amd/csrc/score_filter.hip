@@ -17,8 +17,8 @@
 //     ("T16B") the slab loop carries 67.3-67.5 % of the peak against 64.8-65.2 % on the same box (profiles/r04_mfma_ceiling_t16b.txt);
 //   * a fragment (16 rows x 32 k) is one 1-KiB block of the ring image: lane l reads row l & 15, 16-byte chunk (l >> 4) ^ ((row >> 1) & 3)
 //     (the swizzle is applied on the per-lane SOURCE address of the direct-to-LDS loads, conflict-free ds_read_b128);
-//   * A fragments live in a ring of THREE register quads (row block i uses a[i % 3], refilled with block i + 3 right after its eight
-//     MFMAs); the EIGHT B fragments are single-buffered and refilled in place during the last row block of a slab (b[j] right after its
+//   * A fragments live in a ring of TWO register quads (kARing: row block i uses a[i % 2], refilled with block i + 2 right after its eight
+//     MFMAs; three quads — round 4 — cost four registers the filter's rare path needed); the EIGHT B fragments are single-buffered and refilled in place during the last row block of a slab (b[j] right after its
 //     last MFMA: seven MFMAs = 112 cycles before its first use in the next slab);
 //   * slabs are issued 3 ahead and retired by a counted s_waitcnt vmcnt + one raw s_barrier per slab, placed before row block 3: by
 //     then every fragment of the current stage is in registers (the stage is free for the slab 4 ahead) and the next stage is about

@@ -46,6 +46,10 @@ class RankDict(Mapping):
         self.db_ids = db_ids
         self._host = None
 
+    def keys_in_row_order(self):
+        """the query ids, key i <-> row i of ``labels`` (dicts keep insertion order)"""
+        return list(self._pos)
+
     def last_rows(self, query_ids):
         """result row of every id in ``query_ids`` (the result of the id's last occurrence in the query stream)"""
         return [self._pos[q] for q in query_ids]
@@ -87,7 +91,10 @@ def get_indexer(bi_encoder, eval_dataloader, args, hnsw_index, img_retrieval=Tru
 
 
 def eval_model_on_dataloader(bi_encoder, eval_dataloader, args, img2txt: Optional[Dict] = None, num_tops=100,
-                             no_eval=False):
+                             no_eval=False, rank_sets_only=False):
+    """dvl/trainer.py:113-190.  ``rank_sets_only`` (not in the reference; what the mining of dvl/hn.py:54-63 needs): the rank dicts hold
+    the top-``num_tops`` SETS — the searches re-score only their boundary candidates (LDOT_OPT_RESULT_SET) and the order inside a list is
+    approximate, so Recall@{1,5,10} is not computed: the recall pair comes back as (None, None)."""
     total_loss = 0.0
     bi_encoder.eval()
     total_correct_predictions = 0
@@ -138,10 +145,12 @@ def eval_model_on_dataloader(bi_encoder, eval_dataloader, args, img2txt: Optiona
     # Only the LAST occurrence of every query id is searched: the reference's dict comprehensions (:168,171) keep exactly that
     # result, so its 5x duplicated image queries (:138-139) cost 5x the work for the same rank dict.  The de-duplicated query
     # rows are the rows just indexed on the other side (same id stream, same last-write-wins rule).
-    _, lab_txt = indexer_img.search_knn_tensors(txt_vecs, num_tops)     # text query -> image rows
-    _, lab_img = indexer_txt.search_knn_tensors(img_vecs, num_tops)     # image query -> text rows
+    _, lab_txt = indexer_img.search_knn_tensors(txt_vecs, num_tops, ids_only=rank_sets_only)     # text query -> image rows
+    _, lab_img = indexer_txt.search_knn_tensors(img_vecs, num_tops, ids_only=rank_sets_only)     # image query -> text rows
     rank_txt_res = RankDict(txt_keys, lab_txt, indexer_img.index_id_to_db_id)
     rank_img_res = RankDict(img_keys, lab_img, indexer_txt.index_id_to_db_id)
+    if rank_sets_only:
+        return total_loss, correct_ratio, (indexer_img, indexer_txt), (None, None), (rank_txt_res, rank_img_res)
 
     # Recall@{1,5,10} (:173-188) as device reductions over the label tensors.  A result list belongs to a query ID (dict
     # semantics, last occurrence wins); ids are unique per index, so "id in list[:top]" is "row label in labels[:, :top]"; a padding

@@ -192,18 +192,36 @@ class FlatIPIndex:
         del keep
         return out_scores, out_labels
 
-    def search_tensors(self, queries, k: int):
-        """Device-resident variant: queries is a CUDA tensor; returns (scores, labels) CUDA tensors."""
+    def search_tensors(self, queries, k: int, ids_only: bool = False):
+        """Device-resident variant: queries is a CUDA tensor; returns (scores, labels) CUDA tensors.
+
+        ``ids_only=True`` (LDOT_OPT_RESULT_SET): for consumers that keep the labels and drop scores and order (hard-negative mining,
+        dvl/hn.py:54-63).  ``labels`` hold the same top-k SET; only the candidates whose bf16 score lies within the verify bound of
+        the k-th are re-scored from the fp32 rows.  Order: the certain ones by bf16 candidate score (that IS their reported
+        score), then the boundary's winners by exact score."""
         import torch
         keep, ptr, nq, dt, mem = _describe(queries, self.d, self.device)
         if mem != L.DEVICE:
             raise ValueError('search_tensors expects a CUDA tensor')
         scores = torch.empty((nq, k), dtype=torch.float32, device=keep.device)
         labels = torch.empty((nq, k), dtype=torch.int64, device=keep.device)
-        L.check(self._lib.ldot_index_search(self._h, ptr, nq, dt, mem, int(self.normalize), int(k),
-                                            ctypes.c_void_p(scores.data_ptr()), ctypes.c_void_p(labels.data_ptr()),
-                                            L.DEVICE, _stream_ptr(self.device)))
+        was = bool(self._opts.get(L.OPT_RESULT_SET, 0))
+        if was != bool(ids_only):
+            self.set_option(L.OPT_RESULT_SET, int(bool(ids_only)))
+        try:
+            L.check(self._lib.ldot_index_search(self._h, ptr, nq, dt, mem, int(self.normalize), int(k),
+                                                ctypes.c_void_p(scores.data_ptr()), ctypes.c_void_p(labels.data_ptr()),
+                                                L.DEVICE, _stream_ptr(self.device)))
+        finally:
+            if was != bool(ids_only):
+                self.set_option(L.OPT_RESULT_SET, int(was))
         return scores, labels
+
+    def last_set_stats(self):
+        """(candidates re-scored exactly, live candidates) of the last ``ids_only`` search (drains the device)."""
+        a = (ctypes.c_int64 * 2)()
+        L.check(self._lib.ldot_index_last_set_stats(self._h, a))
+        return dict(rescored=int(a[0]), candidates=int(a[1]))
 
     def search_begin(self, queries, k: int):
         """First half of a sharded search (CUDA tensors): generates this shard's candidates and returns their thresholds,
@@ -459,9 +477,10 @@ class DenseFlatIndexer(DenseIndexer):
         result = [(db_ids[i], scores[i]) for i in range(len(db_ids))]
         return result
 
-    def search_knn_tensors(self, query_vectors, top_docs: int):
-        """(scores [nq, k], row labels [nq, k]) as device tensors; map labels with ``index_id_to_db_id``."""
-        return self.index.search_tensors(query_vectors, top_docs)
+    def search_knn_tensors(self, query_vectors, top_docs: int, ids_only: bool = False):
+        """(scores [nq, k], row labels [nq, k]) as device tensors; map labels with ``index_id_to_db_id``.  ``ids_only``: the top-k SET
+        for consumers that drop scores and order (FlatIPIndex.search_tensors)."""
+        return self.index.search_tensors(query_vectors, top_docs, ids_only=ids_only)
 
 
 class DenseHNSWFlatIndexer(DenseIndexer):
@@ -535,9 +554,10 @@ class DenseHNSWFlatIndexer(DenseIndexer):
         self._update_id_mapping(list(db_ids))
         self.index.add(vectors)
 
-    def search_knn_tensors(self, query_vectors, top_docs: int):
+    def search_knn_tensors(self, query_vectors, top_docs: int, ids_only: bool = False):
         """(squared L2 distances of the augmented vectors [nq, k] ascending, row labels [nq, k]) as CUDA tensors: the neighbours
-        of ``search_knn`` without the per-result Python objects.  Padding: label -1, distance FLT_MAX (what faiss pads with)."""
+        of ``search_knn`` without the per-result Python objects.  Padding: label -1, distance FLT_MAX (what faiss pads with).
+        ``ids_only`` (exact-backed index only): the neighbour SET, order and distances approximate (FlatIPIndex.search_tensors)."""
         import torch
         if _is_tensor(query_vectors):
             qt = query_vectors.detach()
@@ -550,7 +570,7 @@ class DenseHNSWFlatIndexer(DenseIndexer):
         if self._ivf is not None:
             ip, labels = self._ivf.search_knn_tensors(qt, top_docs)
         else:
-            ip, labels = self.index.search_tensors(qt, top_docs)
+            ip, labels = self.index.search_tensors(qt, top_docs, ids_only=ids_only)
         qn = (qt.float() ** 2).sum(dim=1)                                  # fp32 like the reference's numpy arithmetic
         dist = qn[:, None] + torch.tensor(self._phi_value, dtype=torch.float32, device=ip.device) - 2.0 * ip
         dist = torch.where(labels >= 0, dist, dist.new_full((), 3.4028234663852886e38))

@@ -171,6 +171,7 @@ class DenseIVFFlatIndexer(DenseIndexer):
         import torch
         self._centroids = cent
         self.coarse = FlatIPIndex(cent.shape[1] + 1)
+        self.coarse.set_option(L.OPT_ROW_SHUFFLE, 2)     # ldot_ivf_search takes the probes as stored rows: the centroids must never be re-ordered
         self.coarse.add(torch.cat([cent, -0.5 * (cent * cent).sum(1, keepdim=True)], 1))
 
     # ---- search ------------------------------------------------------------------------------------------------------------------

@@ -144,6 +144,8 @@ def _positive_tensor(positive_idx: list, n2: int, device) -> T:
     """int32 device tensor of the positives.  The reference uploads the list on every call (torch.tensor(list).to(device),
     bi_encoder.py:651,655: a pageable host-to-device copy, i.e. a synchronisation); the in-batch positives are always range(bs)
     (dvl/data/itm.py:189,283), so that tensor is built once per (length, device).  Other lists are validated and uploaded."""
+    if not isinstance(positive_idx, list):          # (tensors / arrays / ranges: the reference's torch.tensor(...) takes them too)
+        positive_idx = [int(v) for v in positive_idx]
     n = len(positive_idx)
     rl = _range_lists.get(n)
     if rl is None:
@@ -241,6 +243,7 @@ class _BidirNll(torch.autograd.Function):
         ctx.in_dtypes = (txt.dtype, img.dtype)
         ctx.set_materialize_grads(False)
         loss_txt, loss_img, loss_nce, is_correct = buf[o_small + 4 * bs:o_small + 4 * bs + 4].unbind(0)
+        is_correct = is_correct.clone()      # (not a view: a caller that keeps it — a history list — must not pin the whole workspace)
         ctx.mark_non_differentiable(is_correct)
         return loss_nce, loss_txt, loss_img, is_correct, (buf[2 * bs * n:3 * bs * n].view(bs, n) if want_scores else None)
 
@@ -341,7 +344,9 @@ def _calc_loss(args, loss_function, local_q_vector, local_ctx_vectors, local_cap
 def train_step_loss(args, txt_vector: T, img_vectors: T, caption_vectors: Optional[T], batch: dict, experiment=None,
                     loss_function=None):
     """The loss composition of one fine-tuning step — train_itm.py:195-222 (both directions, averaged).
-    Returns (loss_nce, is_correct, scores, (loss_nce_txt, loss_nce_img)).  ``loss_function`` (an object with the reference's
+    Returns (loss_nce, is_correct, scores, (loss_nce_txt, loss_nce_img)); ``is_correct`` is a Python float on the two-call path (the
+    reference's .item() arithmetic, train_itm.py:211) and a detached 0-dim DEVICE tensor on the one-call fast path (world size 1, no
+    caption mixing, no experiment): ``float(is_correct)`` gives the reference's number on both.  ``loss_function`` (an object with the reference's
     ``calc``) defaults to the HIP ``BiEncoderNllLoss``, as train_itm.py:193 constructs it."""
     bs = batch['sample_size']
     ws = int(getattr(args, 'distributed_world_size', 1) or 1)

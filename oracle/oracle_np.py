@@ -394,7 +394,8 @@ def num_hard_sampled(num_hard_negatives: int) -> int:
 
 
 def hard_negative_postprocess(hard_neg_img: Dict, hard_neg_txt: Dict, train_txt2img: Dict,
-                              train_img2txt: Dict, num_hard_negatives: int, rng: Optional[_random.Random] = None):
+                              train_img2txt: Dict, num_hard_negatives: int, rng: Optional[_random.Random] = None,
+                              sample=None):
     """dvl/hn.py:57-63.  ``hard_neg_img`` = {txt_id: [img ids]} (rank_txt_res), ``hard_neg_txt`` =
     {img_id: [txt ids]} (rank_img_res).  :57 removes the positive image from each text's list in place
     (first occurrence); :58 replaces each image's list by list(set(v) - set(own captions)) — NOTE the
@@ -407,8 +408,9 @@ def hard_negative_postprocess(hard_neg_img: Dict, hard_neg_txt: Dict, train_txt2
             v.remove(train_txt2img[k])
     hn_txt = {k: set(v) - set(train_img2txt[k]) for k, v in hard_neg_txt.items()}
     rng = rng or _random.Random(0)
-    sampled_txt = {k: rng.sample(sorted(v), num_hard_negatives) for k, v in hn_txt.items()}
-    sampled_img = {k: rng.sample(v, num_hard_negatives) for k, v in hn_img.items()}
+    sample = sample or rng.sample        # (``sample``: a deterministic stand-in for random.sample of :62-63, for output-level comparisons)
+    sampled_txt = {k: sample(sorted(v), num_hard_negatives) for k, v in hn_txt.items()}
+    sampled_img = {k: sample(v, num_hard_negatives) for k, v in hn_img.items()}
     return hn_img, hn_txt, sampled_txt, sampled_img
 
 
@@ -447,3 +449,56 @@ class DenseHNSWFlatIndexerOracle:
         order = np.argsort(d2, axis=1, kind='stable')[:, :top_docs]
         scores = np.take_along_axis(d2, order, axis=1).astype(np.float32)
         return [([self.index_id_to_db_id[i] for i in row], scores[j]) for j, row in enumerate(order.tolist())]
+
+
+# --------------------------------------------------------------------------------------
+# re-ranker hook  (rerank.py:160-204 first stage, :256-290 re-ranking; a flat script in the reference, so there is no
+# function to import and no golden vector: this restatement is the checker of lightningdot_amd/rerank.py)
+# --------------------------------------------------------------------------------------
+RERANK_RECALL_TOPS = (1, 5, 10, 20, 50, 100)     # rerank.py:160-161
+RERANK_THRESHOLDS = (10, 20, 50, 100)            # rerank.py:257,273
+
+
+def rerank_first_stage(batches: Iterable[dict], indexer_img, indexer_txt, img2txt: Dict, txt2img: Dict):
+    """rerank.py:168-204 with the towers factored out (batches as in ``eval_on_stream``: 'txt_index', 'img_fname', 'q' text vectors,
+    'ctx' image vectors): top-max(RECALL_TOPS) ids per text query / image query from the oracle indexers (:189-190), the dicts keep the
+    result of an id's last occurrence (:195,200), hits are counted over every occurrence (:196-197,201-202).
+    -> (ranking_res_img {txt_id: [img ids]}, ranking_res_txt {img_id: [txt ids]}, recall_img2, recall_txt2, total_len)"""
+    recall_img2 = {t: 0 for t in RERANK_RECALL_TOPS}
+    recall_txt2 = {t: 0 for t in RERANK_RECALL_TOPS}
+    ranking_res_img, ranking_res_txt = {}, {}
+    total_len = 0
+    n_top = max(RERANK_RECALL_TOPS)
+    for b in batches:
+        res_img = [r[0] for r in indexer_img.search_knn(np.asarray(b['q'], np.float32), n_top)]
+        res_txt = [r[0] for r in indexer_txt.search_knn(np.asarray(b['ctx'], np.float32), n_top)]
+        total_len += len(res_img)
+        for r, txt_index in zip(res_img, b['txt_index']):
+            ranking_res_img[txt_index] = r
+            for top in recall_img2:
+                recall_img2[top] += txt2img[txt_index] in r[:top]
+        for r, img_index in zip(res_txt, b['img_fname']):
+            ranking_res_txt[img_index] = r
+            for top in recall_txt2:
+                recall_txt2[top] += any([txt_id in r[:top] for txt_id in img2txt[img_index]])
+    return ranking_res_img, ranking_res_txt, recall_img2, recall_txt2, total_len
+
+
+def rerank_recall(rankings: Dict, query_ids: Sequence, score, is_hit, denominator: int,
+                  thresholds: Sequence[int] = RERANK_THRESHOLDS):
+    """rerank.py:256-270 (image retrieval: query_ids = txt_ids, is_hit = txt2img[q] in ids, denominator = total_len) and :272-290
+    (text retrieval: query_ids = img_ids, is_hit = any own caption in ids, denominator = len(img_ids)): for every threshold the external
+    scorer's top 10 (``scores.topk(10, 0)``: descending, :263,280) of the first ``threshold`` first-stage candidates, Recall@{1,5,10}.
+    ``score(query_id, candidate_id)`` is the external scorer (scores_mat[...] of :262, or scores_ir[...].get(id, -1000) of :260)."""
+    out = {}
+    for threshold in thresholds:
+        recall_rerank = {1: 0, 5: 0, 10: 0}
+        for qid in query_ids:
+            cands = rankings[qid][:threshold]
+            scores = np.asarray([score(qid, c) for c in cands], dtype=np.float32)
+            idx = np.argsort(-scores, kind='stable')[:10]
+            kept = [cands[i] for i in idx]
+            for top in recall_rerank:
+                recall_rerank[top] += bool(is_hit(qid, kept[:top]))
+        out[threshold] = {t: v / float(denominator) for t, v in recall_rerank.items()}
+    return out

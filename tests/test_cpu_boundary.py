@@ -25,7 +25,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert sorted(_lib.SYMBOLS) == declared, set(_lib.SYMBOLS) ^ set(declared)
     for name in declared:
         assert hasattr(lib, name), f'{name} not exported by libldot.so'
-    assert lib.ldot_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.ldot_abi_version() == _lib.ABI_VERSION == 7
     out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.lib_path()]).decode()
     exported = set(re.findall(r'\bT (ldot_[a-z0-9_]+)', out))
     assert set(declared) <= exported
