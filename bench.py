@@ -57,6 +57,7 @@ def main():
     ap.add_argument('--growth', type=int, default=0, help='fused launch growth percent (0 = library default)')
     ap.add_argument('--warm', type=int, default=0, help='dense warm-up rows (0 = library default)')
     ap.add_argument('--force-sharded', action='store_true', help='run the sharded code path even with one rank')
+    ap.add_argument('--force-repeat', action='store_true', help='sharded path: every search runs the verdict + repeat path of the pooled scheme (what a failed pooled search costs; measurement aid)')
     ap.add_argument('--split-bf16', action='store_true',
                     help='LDOT_OPT_PRECISION=1: split-bf16 candidate pass (3 MFMA products per element); not the headline')
     ap.add_argument('--no-optimistic', action='store_true', help='LDOT_OPT_OPTIMISTIC = 0: guaranteed thresholds only (measurement aid; not the headline)')
@@ -166,6 +167,7 @@ def main():
         sh.local.index.set_option(L.OPT_MODE, mode)
         sh.local.index.set_option(L.OPT_PROFILE, 1)
         sh.profile_phases = True       # device time of every phase of the exchange (events on the search stream)
+        sh.force_repeat = bool(args.force_repeat)
         if args.split_bf16:
             sh.local.index.set_option(L.OPT_PRECISION, 1)
         sh.index_local_shard(list(range(lo, hi)), x_local)
@@ -216,6 +218,16 @@ def main():
         ones = torch.ones(1, device=dev, dtype=torch.int32)
         dist.all_reduce(ones)                      # every rank that took part in the timed collectives counts itself
         ranks_seen = int(ones.item())
+        # every phase's SLOWEST rank (the step waits for it), beside rank 0's own times
+        pkeys = sorted(phases)
+        pt = torch.tensor([phases[k_] for k_ in pkeys], device=dev, dtype=torch.float64)
+        dist.all_reduce(pt, op=dist.ReduceOp.MAX)
+        phases_max = dict(zip(pkeys, pt.tolist()))
+        if ranks_seen != world:                    # a line measured on fewer ranks than asked for is not a line
+            if rank == 0:
+                print(f'bench.py: {ranks_seen} ranks took part in the timed collectives, --gpus {world} asked for: no result line', file=sys.stderr, flush=True)
+            dist.destroy_process_group()
+            sys.exit(2)
 
     # ---- quality on the last step's results: Recall@1/5/10 against the planted ground truth ----------------
     s_np, l_np = host_s.numpy(), host_l.numpy()
@@ -267,6 +279,10 @@ def main():
         # rank 0's device time per phase and step (the phases follow each other on one stream: they add up to `total`, which is the
         # step minus the host's share — enqueue, the end-of-search synchronisation, Python)
         out['phases_ms_per_step'] = {k_: v / max(args.steps, 1) for k_, v in phases.items()}
+        out['phases_ms_per_step_slowest_rank'] = {k_: v / max(args.steps, 1) for k_, v in phases_max.items()}
+        if args.force_repeat:
+            out['forced_repeat'] = ('every step ran the pooled scheme\'s verdict (all-reduce SUM of the counts + one host read) and then the whole search again on '
+                                    'the shard\'s own thresholds: phases `verdict` and `repeat` are what a failed pooled search adds')
         out['phases_note'] = ('rank 0, HIP events on the search stream; backend %s%s' %
                               (args.backend, '' if args.backend == 'nccl' else ' (collectives bounce through host copies: exchange phases include them)'))
     if args.no_kernel_events:

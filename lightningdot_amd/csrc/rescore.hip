@@ -135,110 +135,167 @@ __global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __rest
 //     c_i < c_(k) - 2E  =>  the k rows at or above c_(k) all beat i exactly                                        =>  i is OUT,
 // and only the candidates in between are gathered from the fp32 master copy (3 KiB per row — the cost of a mining search at top-1000) and
 // ordered exactly; the k - #IN best of them complete the set.  Under that bound the labels are the set the full re-score reports (ties at
-// the boundary broken by the lower label, as there).  Output order: the IN candidates by candidate score (their reported score IS the bf16-input
-// candidate score), then the band's winners by exact score.  stats[0] += candidates gathered, stats[1] += live candidates.
-template <int kRsThreads>
-__global__ __launch_bounds__(kRsThreads) void rescore_set_kernel(const float* __restrict__ q32, int64_t ldq, const float* __restrict__ x32,
-                                                                 int64_t ldx, int dpad, int d, const float* __restrict__ list_s,
-                                                                 const int32_t* __restrict__ list_i, int kp, int k,
-                                                                 const float* __restrict__ max_norm, float band_c, float* __restrict__ out_s,
-                                                                 int64_t* __restrict__ out_l, const int32_t* __restrict__ label_map,
-                                                                 unsigned long long* __restrict__ stats, int64_t nq) {
-    __shared__ __attribute__((aligned(16))) uint64_t keys[4096];
-    __shared__ int m_sh, a_sh, b_sh;
-    __shared__ float qq_sh[kRsThreads / 64];
+// the boundary broken by the lower label, as there).  The ORDER of the k outputs is unspecified: the IN candidates (reported score = their
+// bf16-input candidate score) in list order, then the band's winners by exact score.  stats[0] += candidates gathered, stats[1] += live candidates.
+//
+// No sort anywhere: a workgroup (ONE wave for k' <= 256: no barriers, 32 queries in flight per CU; four waves beyond) holds the k' candidates in
+// registers, finds c_(k) by a bit search over their descending keys (count-and-reduce per bit), classifies, gathers the band's rows and
+// ranks the band by counting.  (The first version sorted the list twice in a 32-KiB key buffer: 4.2 ms for 145 000 queries at k' = 96,
+// as long as the full re-score — LDS occupancy, not the 12 % of the rows it gathered: profiles/r06_mining_kernels_first.txt.)
+template <int T>
+__device__ __forceinline__ int set_block_sum(int v, int* red, int slot) {
+    // sum over the workgroup; `slot` alternates between calls so that ONE barrier per call is enough
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (T == 64) return v;
+    if ((threadIdx.x & 63) == 0) red[slot * (T / 64) + (threadIdx.x >> 6)] = v;
+    __syncthreads();
+    int s = 0;
+#pragma unroll
+    for (int w = 0; w < T / 64; ++w) s += red[slot * (T / 64) + w];
+    return s;
+}
+
+template <int T, int VP>   // VP = candidates per thread: k' <= T * VP
+__global__ __launch_bounds__(T) void rescore_set_kernel(const float* __restrict__ q32, int64_t ldq, const float* __restrict__ x32,
+                                                        int64_t ldx, int dpad, int d, const float* __restrict__ list_s,
+                                                        const int32_t* __restrict__ list_i, int kp, int k,
+                                                        const float* __restrict__ max_norm, float band_c, float* __restrict__ out_s,
+                                                        int64_t* __restrict__ out_l, const int32_t* __restrict__ label_map,
+                                                        unsigned long long* __restrict__ stats, int64_t nq) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t band[];   // [next power of two >= k']: {stored row} -> {exact key, label}
+    __shared__ int red[2 * (T / 64) + 1];
+    __shared__ int cnt_in, cnt_band;
+    __shared__ float qq_sh[T / 64];
     int64_t q = blockIdx.x;
-    if (gridDim.x >= 128) {   // (the block -> query map of rescore_kernel)
+    if (T > 64 && gridDim.x >= 128) {   // (the block -> query map of rescore_kernel: sixteen consecutive queries on one XCD)
         const int64_t r = q & 127;
         q = (q - r) + (r & 7) * 16 + (r >> 3);
     }
     if (q >= nq) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* qrow = q32 + q * ldq;
-    if (threadIdx.x == 0) m_sh = a_sh = b_sh = 0;
-    __syncthreads();
-    // 1. live candidates -> keys[0..m) = {descending key of the candidate score, stored row}, sorted best first
-    for (int e0 = 0; e0 < kp; e0 += kRsThreads) {
-        const int e = e0 + threadIdx.x;
-        int32_t r = -1;
-        float cs = 0.f;
-        if (e < kp) {
-            r = list_i[q * kp + e];
-            cs = list_s[q * kp + e];
-        }
-        const bool live = r >= 0;
-        const unsigned long long mask = __ballot(live);
-        int base = 0;
-        if (lane == 0 && mask) base = atomicAdd(&m_sh, __popcll(mask));
-        base = __shfl(base, 0);
-        if (live) keys[base + __popcll(mask & ((1ull << lane) - 1ull))] = ((uint64_t)desc_key(cs) << 32) | (uint32_t)r;
+    if (threadIdx.x == 0) cnt_in = cnt_band = 0;
+    // candidates -> registers (descending key of the candidate score; 0xffffffff = not a candidate)
+    uint32_t key[VP];
+    int32_t row[VP];
+    int mine = 0;
+#pragma unroll
+    for (int v = 0; v < VP; ++v) {
+        const int e = v * T + threadIdx.x;
+        row[v] = e < kp ? list_i[q * kp + e] : -1;
+        key[v] = row[v] >= 0 ? desc_key(list_s[q * kp + e]) : 0xffffffffu;
+        mine += row[v] >= 0;
     }
-    // |q|^2 (the band is relative to the query's norm)
-    float qq = 0.f;
-    for (int c = threadIdx.x; c < d; c += kRsThreads) qq = fmaf(qrow[c], qrow[c], qq);
+    float qq = 0.f;   // |q|^2 (the band is relative to the query's norm)
+    for (int c = threadIdx.x; c < d; c += T) qq = fmaf(qrow[c], qrow[c], qq);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) qq += __shfl_xor(qq, o);
     if (lane == 0) qq_sh[wave] = qq;
-    __syncthreads();
-    const int m = m_sh;
-    int P = 2;
-    while (P < m) P <<= 1;
-    for (int e = m + threadIdx.x; e < P; e += kRsThreads) keys[e] = ~0ull;
-    __syncthreads();
-    bitonic_sort_lds(keys, P);
+    const int m = set_block_sum<T>(mine, red, 0);   // (its barrier also publishes cnt_* and qq_sh)
     float* os = out_s + q * k;
     int64_t* ol = out_l + q * k;
     if (m <= k) {   // everything there is belongs to the set
-        for (int e = threadIdx.x; e < k; e += kRsThreads) {
-            const uint64_t key = (e < m) ? keys[e] : ~0ull;
-            if (key != ~0ull) {
-                const int32_t r = (int32_t)(uint32_t)key;
-                os[e] = desc_key_to_float((uint32_t)(key >> 32));
-                ol[e] = label_map ? label_map[r] : r;
-            } else {
-                os[e] = LDOT_PAD_SCORE;
-                ol[e] = LDOT_PAD_LABEL;
+#pragma unroll
+        for (int v = 0; v < VP; ++v) {
+            const bool have = row[v] >= 0;
+            const unsigned long long hm = __ballot(have);
+            int base = 0;
+            if (lane == 0 && hm) base = atomicAdd(&cnt_in, __popcll(hm));
+            base = __shfl(base, 0);
+            if (have) {
+                const int pos = base + __popcll(hm & ((1ull << lane) - 1ull));
+                os[pos] = desc_key_to_float(key[v]);
+                ol[pos] = label_map ? label_map[row[v]] : row[v];
             }
+        }
+        for (int e = m + threadIdx.x; e < k; e += T) {
+            os[e] = LDOT_PAD_SCORE;
+            ol[e] = LDOT_PAD_LABEL;
         }
         if (threadIdx.x == 0 && stats) atomicAdd(stats + 1, (unsigned long long)m);
         return;
     }
-    // 2. the band [a, b) of the sorted list around the k-th candidate score
+    // ---- c_(k): the k-th smallest descending key, by bit search (the bits all candidates share are skipped) ---------------------
+    uint32_t kth = 0;
+    {
+        uint32_t all_and = 0xffffffffu, all_or = 0u;
+#pragma unroll
+        for (int v = 0; v < VP; ++v) {
+            all_and &= key[v];                        // (a non-candidate is all ones: neutral)
+            all_or |= row[v] >= 0 ? key[v] : 0u;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            all_and &= __shfl_xor(all_and, o);
+            all_or |= __shfl_xor(all_or, o);
+        }
+        if (T > 64) {
+            __shared__ uint32_t ru[2 * (T / 64)];   // (not `red`: a slow wave may still be reading the sum above)
+            if (lane == 0) {
+                ru[wave] = all_and;
+                ru[T / 64 + wave] = all_or;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < T / 64; ++w) {
+                all_and &= ru[w];
+                all_or |= ru[T / 64 + w];
+            }
+        }
+        const uint32_t diff = all_and ^ all_or;
+        const int hb = diff ? 31 - __clz((int)diff) : -1;      // highest bit in which two candidates differ
+        kth = hb >= 31 ? 0u : hb < 0 ? all_or : (all_or & ~((2u << hb) - 1u));    // the shared prefix (hb = -1: all keys equal)
+        int slot = 1;
+        for (int bit = hb; bit >= 0; --bit) {
+            const uint32_t test = kth | ((1u << bit) - 1u);
+            int c = 0;
+#pragma unroll
+            for (int v = 0; v < VP; ++v) c += key[v] <= test ? 1 : 0;   // (non-candidates never count: test < 0xffffffff here)
+            if (set_block_sum<T>(c, red, slot) < k) kth |= 1u << bit;
+            slot ^= 1;
+        }
+    }
     qq = 0.f;
 #pragma unroll
-    for (int w = 0; w < kRsThreads / 64; ++w) qq += qq_sh[w];
-    const float ck = desc_key_to_float((uint32_t)(keys[k - 1] >> 32));
-    const float band = 2.f * band_c * 0.00390625f * sqrtf(qq) * max_norm[0] * rsqrtf((float)d);
-    const float hi = ck + band, lo = ck - band;
-    int na = 0, nb = 0;
-    for (int e = threadIdx.x; e < m; e += kRsThreads) {
-        const float c = desc_key_to_float((uint32_t)(keys[e] >> 32));
-        na += c > hi;
-        nb += !(c < lo);
-    }
+    for (int w = 0; w < T / 64; ++w) qq += qq_sh[w];
+    const float ck = desc_key_to_float(kth);
+    const float bw = 2.f * band_c * 0.00390625f * sqrtf(qq) * max_norm[0] * rsqrtf((float)d);
+    const float hi = ck + bw, lo = ck - bw;
+    // ---- classify: IN -> output now; band -> LDS ------------------------------------------------------------------------------------
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        na += __shfl_xor(na, o);
-        nb += __shfl_xor(nb, o);
-    }
-    if (lane == 0) {
-        if (na) atomicAdd(&a_sh, na);
-        if (nb) atomicAdd(&b_sh, nb);
+    for (int v = 0; v < VP; ++v) {
+        const float c = desc_key_to_float(key[v]);
+        const bool have = row[v] >= 0;
+        const bool is_in = have && c > hi, is_band = have && !is_in && !(c < lo);
+        const unsigned long long im = __ballot(is_in), bm = __ballot(is_band);
+        int bi = 0, bb = 0;
+        if (lane == 0) {
+            if (im) bi = atomicAdd(&cnt_in, __popcll(im));
+            if (bm) bb = atomicAdd(&cnt_band, __popcll(bm));
+        }
+        bi = __shfl(bi, 0);
+        bb = __shfl(bb, 0);
+        if (is_in) {
+            const int pos = bi + __popcll(im & ((1ull << lane) - 1ull));
+            os[pos] = c;
+            ol[pos] = label_map ? label_map[row[v]] : row[v];
+        }
+        if (is_band) band[bb + __popcll(bm & ((1ull << lane) - 1ull))] = (uint32_t)row[v];
     }
     __syncthreads();
-    const int a = a_sh, b = b_sh;   // a <= k - 1 < b
-    // 3. exact scores of the band; final keys = {class (0 IN, 1 band), descending score key, label}: one more sort orders the IN candidates by
-    //    candidate score, then the band by exact score and label
+    const int a = cnt_in, nb = cnt_band;   // a <= k - 1, a + nb >= k
+    // ---- exact scores of the band (the arithmetic of rescore_kernel: same exact scores bit for bit) ---------------------------------
     constexpr int U = 4;
-    for (int e0 = a + wave * U; e0 < b; e0 += (kRsThreads / 64) * U) {
+    for (int e0 = wave * U; e0 < nb; e0 += (T / 64) * U) {
         int32_t r[U];
         float s[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) r[u] = (e0 + u < b) ? (int32_t)(uint32_t)keys[e0 + u] : -1;
+        for (int u = 0; u < U; ++u) r[u] = (e0 + u < nb) ? (int32_t)(uint32_t)band[e0 + u] : -1;
         float acc[U][4];
 #pragma unroll
         for (int u = 0; u < U; ++u) acc[u][0] = acc[u][1] = acc[u][2] = acc[u][3] = 0.f;
-        for (int c = lane * 4; c < dpad; c += 256) {   // (the arithmetic of rescore_kernel: same exact scores bit for bit)
+        for (int c = lane * 4; c < dpad; c += 256) {
             const f32x4 qv = *(const f32x4*)(qrow + c);
             f32x4 xv[U];
 #pragma unroll
@@ -263,25 +320,23 @@ __global__ __launch_bounds__(kRsThreads) void rescore_set_kernel(const float* __
         if (lane == 0) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (e0 + u < b)
-                    keys[e0 + u] = (1ull << 63) | ((uint64_t)desc_key(s[u]) << 31) | (uint32_t)(label_map ? label_map[r[u]] : r[u]);
+                if (e0 + u < nb) band[e0 + u] = ((uint64_t)desc_key(s[u]) << 32) | (uint32_t)(label_map ? label_map[r[u]] : r[u]);
         }
     }
-    for (int e = threadIdx.x; e < a; e += kRsThreads) {
-        const uint64_t kv = keys[e];
-        const int32_t r = (int32_t)(uint32_t)kv;
-        keys[e] = ((kv >> 32) << 31) | (uint32_t)(label_map ? label_map[r] : r);
-    }
-    for (int e = b + threadIdx.x; e < m; e += kRsThreads) keys[e] = ~0ull;
     __syncthreads();
-    bitonic_sort_lds(keys, P);
-    for (int e = threadIdx.x; e < k; e += kRsThreads) {
-        const uint64_t key = keys[e];
-        os[e] = desc_key_to_float((uint32_t)(key >> 31));
-        ol[e] = (int64_t)(key & 0x7fffffffull);
+    // ---- the k - a best of the band by (exact score desc, label asc): rank counting (keys are distinct: the label is part of the key) ----
+    const int need = k - a;
+    for (int i = threadIdx.x; i < nb; i += T) {
+        const uint64_t me = band[i];
+        int rank = 0;
+        for (int j = 0; j < nb; ++j) rank += band[j] < me ? 1 : 0;
+        if (rank < need) {
+            os[a + rank] = desc_key_to_float((uint32_t)(me >> 32));
+            ol[a + rank] = (int64_t)(uint32_t)me;
+        }
     }
     if (threadIdx.x == 0 && stats) {
-        atomicAdd(stats, (unsigned long long)(b - a));
+        atomicAdd(stats, (unsigned long long)nb);
         atomicAdd(stats + 1, (unsigned long long)m);
     }
 }
@@ -421,12 +476,22 @@ int launch_rescore_set(const float* q32, int64_t ldq, const float* x32, int64_t 
                        const int32_t* list_i, int kp, int k, const float* max_norm, float band_c, float* out_s, int64_t* out_l,
                        const int32_t* label_map, unsigned long long* stats, hipStream_t st) {
     if (nq <= 0) return LDOT_OK;
-    if (nq <= 128)
-        hipLaunchKernelGGL(rescore_set_kernel<1024>, dim3((unsigned)nq), dim3(1024), 0, st, q32, ldq, x32, ldx, dpad, d, list_s, list_i, kp, k,
-                           max_norm, band_c, out_s, out_l, label_map, stats, nq);
+    int P = 2;
+    while (P < kp) P <<= 1;
+    const size_t lds = (size_t)P * 8;
+#define LDOT_SET_LAUNCH(T, VP, GRID)                                                                                                  \
+    hipLaunchKernelGGL((rescore_set_kernel<T, VP>), dim3((unsigned)(GRID)), dim3(T), lds, st, q32, ldq, x32, ldx, dpad, d, list_s, list_i, \
+                       kp, k, max_norm, band_c, out_s, out_l, label_map, stats, nq)
+    if (kp <= 128)
+        LDOT_SET_LAUNCH(64, 2, nq);
+    else if (kp <= 256)
+        LDOT_SET_LAUNCH(64, 4, nq);
+    else if (kp <= 1024)
+        LDOT_SET_LAUNCH(256, 4, round_up(nq, 128));
     else
-        hipLaunchKernelGGL(rescore_set_kernel<256>, dim3((unsigned)round_up(nq, 128)), dim3(256), 0, st, q32, ldq, x32, ldx, dpad, d, list_s,
-                           list_i, kp, k, max_norm, band_c, out_s, out_l, label_map, stats, nq);
+        LDOT_SET_LAUNCH(256, 12, round_up(nq, 128));
+#undef LDOT_SET_LAUNCH
+    static_assert(kMaxKp <= 256 * 12, "rescore_set_kernel: candidates per thread");
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;
 }

@@ -367,6 +367,215 @@ __global__ __launch_bounds__(kSelThreads) void select_dense_kernel(const float* 
     sel.finish(ls, li, tau ? tau + q : nullptr);
 }
 
+// dense source, LONG lists (k' > 512: the mining searches of dvl/hn.py:53 at num_tops up to 1000, k' up to 3072): the streaming selector
+// above compacts its 4096-key LDS buffer with a bitonic sort once per 1024-column segment — 330 us per query over a 29 000-column row.  Here
+// the workgroup holds the WHOLE row of the chunk (<= 32 768 columns: 64 per thread) and the running list in registers and finds the
+// k'-th best key by a bit search: one compare-and-count pass over the registers + one workgroup reduction per bit, no sort, no LDS
+// traffic; the k' winners are then written out as a SET (the consumers — the next chunk's call, the pool select, the re-score — take
+// lists as sets).  Key order = (score desc, row asc) as everywhere: rows break score ties by a second bit search over the tied rows, which
+// runs only when the ties straddle the k'-th place.
+constexpr int kBitsThreads = 512;
+constexpr int kBitsVPT = 64;         // row values per thread (16 x f32x4): <= 32 768 columns per chunk
+constexpr int kBitsLPT = kMaxKp / kBitsThreads;   // list entries per thread
+static_assert(kMaxKp % kBitsThreads == 0, "list entries per thread");
+
+__device__ __forceinline__ int bits_block_sum(int v, int* red, int slot) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) red[slot * (kBitsThreads / 64) + (threadIdx.x >> 6)] = v;
+    __syncthreads();
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < kBitsThreads / 64; ++w) t += red[slot * (kBitsThreads / 64) + w];
+    return t;
+}
+
+__global__ __launch_bounds__(kBitsThreads, 2) void select_dense_bits_kernel(const float* __restrict__ S, int64_t lds_elems, int64_t ncols,
+                                                                         int64_t idx_base, float* __restrict__ list_s,
+                                                                         int32_t* __restrict__ list_i, int kp, float* __restrict__ tau) {
+    __shared__ int red[2 * (kBitsThreads / 64)];
+    __shared__ uint32_t rbits[2 * (kBitsThreads / 64)];
+    const int64_t q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = S + q * lds_elems;
+    float* ls = list_s + q * kp;
+    int32_t* li = list_i + q * kp;
+    // ---- the row and the running list -> descending keys in registers (0xffffffff = nothing) -------------------------------------
+    uint32_t key[kBitsVPT], lkey[kBitsLPT];
+    int32_t lrow[kBitsLPT];
+    int mine = 0;
+    // (unconditional loads from clamped addresses, validity applied afterwards: a conditional load is a branch + a wait of its own.  The
+    // score rows are lds_elems >= round_up(ncols, 4) long; list slots past k' re-read the last one)
+#pragma unroll
+    for (int j = 0; j < kBitsVPT / 4; ++j) {
+        const int64_t c = ((int64_t)j * kBitsThreads + tid) * 4;
+        const int64_t cl = c + 3 < lds_elems ? c : (lds_elems - 4 > 0 ? lds_elems - 4 : 0);
+        const f32x4 v = *(const f32x4*)(row + cl);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = c + e < ncols && cl == c;
+            key[j * 4 + e] = ok ? desc_key(v[e]) : 0xffffffffu;
+            // (opaque from here on: otherwise every later `key != 0xffffffff` is rewritten in terms of `ok`, and 64 compare masks stay alive —
+            // spilled — from the loads to the write-out)
+            asm volatile("" : "+v"(key[j * 4 + e]));
+            mine += ok ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kBitsLPT; ++r) {
+        const int e = r * kBitsThreads + tid;
+        const int el = e < kp ? e : kp - 1;
+        const int32_t lr = li[el];
+        const float lsv = ls[el];
+        lrow[r] = e < kp ? lr : -1;
+        lkey[r] = lrow[r] >= 0 ? desc_key(lsv) : 0xffffffffu;
+        asm volatile("" : "+v"(lkey[r]), "+v"(lrow[r]));
+        mine += lkey[r] != 0xffffffffu ? 1 : 0;
+    }
+    const int n = bits_block_sum(mine, red, 0);
+    // ---- the k'-th smallest key (every element is selected when there are no more than k') -----------------------------------------
+    uint32_t kth = 0xffffffffu;
+    int need_ties = 0x7fffffff;          // how many of the elements with key == kth belong to the list (all of them unless ties straddle)
+    uint32_t row_cut = 0xffffffffu;      // ... those with row <= row_cut
+    if (n >= kp) {
+        uint32_t all_and = 0xffffffffu, all_or = 0u;
+#pragma unroll
+        for (int i = 0; i < kBitsVPT; ++i) {
+            all_and &= key[i];
+            all_or |= key[i] != 0xffffffffu ? key[i] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < kBitsLPT; ++r) {
+            all_and &= lkey[r];
+            all_or |= lkey[r] != 0xffffffffu ? lkey[r] : 0u;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            all_and &= __shfl_xor(all_and, o);
+            all_or |= __shfl_xor(all_or, o);
+        }
+        if (lane == 0) {
+            rbits[wave] = all_and;
+            rbits[kBitsThreads / 64 + wave] = all_or;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < kBitsThreads / 64; ++w) {
+            all_and &= rbits[w];
+            all_or |= rbits[kBitsThreads / 64 + w];
+        }
+        const uint32_t diff = all_and ^ all_or;
+        const int hb = diff ? 31 - __clz((int)diff) : -1;
+        kth = hb >= 31 ? 0u : hb < 0 ? all_or : (all_or & ~((2u << hb) - 1u));
+        int slot = 1;
+        for (int bit = hb; bit >= 0; --bit) {
+            const uint32_t test = kth | ((1u << bit) - 1u);
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < kBitsVPT; ++i) {
+                c += key[i] <= test ? 1 : 0;
+                if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler issues all 70 compares first and spills their masks)
+            }
+#pragma unroll
+            for (int r = 0; r < kBitsLPT; ++r) c += lkey[r] <= test ? 1 : 0;
+            if (bits_block_sum(c, red, slot) < kp) kth |= 1u << bit;
+            slot ^= 1;
+        }
+        // ties at the k'-th key: the lower rows win
+        int below = 0, ties = 0;
+#pragma unroll
+        for (int i = 0; i < kBitsVPT; ++i) {
+            below += key[i] < kth ? 1 : 0;
+            ties += key[i] == kth ? 1 : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < kBitsLPT; ++r) {
+            below += lkey[r] < kth ? 1 : 0;
+            ties += lkey[r] == kth ? 1 : 0;
+        }
+        below = bits_block_sum(below, red, slot);
+        slot ^= 1;
+        ties = bits_block_sum(ties, red, slot);
+        slot ^= 1;
+        need_ties = kp - below;
+        if (ties > need_ties) {          // (uniform) the need_ties-th smallest row among the tied elements
+            uint32_t cut = 0;
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t test = cut | ((1u << bit) - 1u);
+                int c = 0;
+                // (a rare path: its loop-invariant parts — 70 tie masks, 64 row numbers — must NOT be hoisted out of the bit loop into
+                // registers the common path then pays for: both are derived from laundered values inside the loop)
+                uint32_t kth_l = kth, row_l = (uint32_t)idx_base + (uint32_t)tid * 4u;
+                asm volatile("" : "+v"(kth_l), "+v"(row_l));
+#pragma unroll
+                for (int i = 0; i < kBitsVPT; ++i) {
+                    const uint32_t r_ = row_l + (uint32_t)((i >> 2) * kBitsThreads * 4 + (i & 3));
+                    c += (key[i] == kth_l && r_ <= test) ? 1 : 0;
+                }
+#pragma unroll
+                for (int r = 0; r < kBitsLPT; ++r) c += (lkey[r] == kth_l && (uint32_t)lrow[r] <= test) ? 1 : 0;
+                if (bits_block_sum(c, red, slot) < need_ties) cut |= 1u << bit;
+                slot ^= 1;
+            }
+            row_cut = cut;
+        }
+    }
+    // ---- write the winners (a set: thread after thread, a thread's list entries before its columns), then the empty slots ---------------
+    // (the verdict of every register is kept as one bit of a lane mask: recomputing the predicates in the write loop makes the compiler keep
+    // 70 compare results alive in scalar registers and spill them)
+    uint64_t selm = 0;
+    uint32_t lselm = 0;
+#pragma unroll
+    for (int r = 0; r < kBitsLPT; ++r)
+        lselm |= (lkey[r] != 0xffffffffu && (lkey[r] < kth || (lkey[r] == kth && (uint32_t)lrow[r] <= row_cut))) ? (1u << r) : 0u;
+#pragma unroll
+    for (int i = 0; i < kBitsVPT; ++i) {
+        const uint32_t r_ = (uint32_t)(idx_base + ((int64_t)(i >> 2) * kBitsThreads + tid) * 4 + (i & 3));
+        selm |= (key[i] != 0xffffffffu && (key[i] < kth || (key[i] == kth && r_ <= row_cut))) ? (1ull << i) : 0ull;
+    }
+    asm volatile("" : "+v"(selm), "+v"(lselm));
+    const int sel_cnt = __popcll(selm) + __popc(lselm);
+    int incl = sel_cnt;                  // inclusive scan over the wave, then over the workgroup's waves
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    __syncthreads();                     // (every thread has read its list entries: the list may be overwritten now; `red` is free again)
+    if (lane == 63) red[wave] = incl;
+    __syncthreads();
+    int pos = incl - sel_cnt;
+    int m = 0;
+#pragma unroll
+    for (int w = 0; w < kBitsThreads / 64; ++w) {
+        pos += w < wave ? red[w] : 0;
+        m += red[w];                     // = min(n, k')
+    }
+#pragma unroll
+    for (int r = 0; r < kBitsLPT; ++r) {
+        if ((lselm >> r) & 1u) {
+            ls[pos] = desc_key_to_float(lkey[r]);
+            li[pos] = lrow[r];
+            ++pos;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < kBitsVPT; ++i) {
+        if ((selm >> i) & 1ull) {
+            ls[pos] = desc_key_to_float(key[i]);
+            li[pos] = (int32_t)(uint32_t)(idx_base + ((int64_t)(i >> 2) * kBitsThreads + tid) * 4 + (i & 3));
+            ++pos;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int e = m + tid; e < kp; e += kBitsThreads) {
+        ls[e] = LDOT_PAD_SCORE;
+        li[e] = -1;
+    }
+    if (tau && tid == 0) tau[q] = n >= kp ? desc_key_to_float(kth) : -INFINITY;
+}
+
 // dense source, wave-per-query variant (k' <= 512): the same register selection as the pool select instead of LDS bitonic
 // compactions (which are LDS-bandwidth bound at ~1.3 MB of LDS traffic per query).  QPW independent query-waves per WG.
 template <int QPW>
@@ -1260,6 +1469,12 @@ int launch_select_dense(const float* S, int64_t lds_elems, int64_t nq, int64_t n
         const int wcap = WaveSelector::kRegKeys * 64;
         hipLaunchKernelGGL((select_dense_wave_kernel<QPW>), dim3((unsigned)((nq + QPW - 1) / QPW)), dim3(64 * QPW),
                            (size_t)wcap * 8 * QPW, st, S, lds_elems, nq, ncols, idx_base, list_s, list_i, kp, wcap, tau);
+        LDOT_HIP_CHECK(hipGetLastError());
+        return LDOT_OK;
+    }
+    if (kp > 512 && ncols <= (int64_t)kBitsThreads * kBitsVPT && idx_base + ncols < ((int64_t)1 << 31)) {   // long lists: bit search in registers
+        hipLaunchKernelGGL(select_dense_bits_kernel, dim3((unsigned)nq), dim3(kBitsThreads), 0, st, S, lds_elems, ncols, idx_base, list_s,
+                           list_i, kp, tau);
         LDOT_HIP_CHECK(hipGetLastError());
         return LDOT_OK;
     }

@@ -123,6 +123,12 @@ def sampled_hard_negatives(train_dataloaders_hn: Iterable, args, bi_encoder, tra
                                                         args.num_hard_negatives, sample=sample)
         hard_negs_txt_all.append(hn_txt)
         hard_negs_img_all.append(hn_img)
-    hard_negs_txt_all = dict(collections.ChainMap(*hard_negs_txt_all))
-    hard_negs_img_all = dict(collections.ChainMap(*hard_negs_img_all))
-    return hard_negs_txt_all, hard_negs_img_all
+    def merged(maps):
+        # dict(collections.ChainMap(*maps)) of :65-66 — the FIRST map that holds a key wins — without ChainMap's per-key Python lookups
+        if len(maps) == 1:
+            return maps[0] if type(maps[0]) is dict else dict(maps[0])
+        out = {}
+        for m in reversed(maps):
+            out.update(m)
+        return out
+    return merged(hard_negs_txt_all), merged(hard_negs_img_all)

@@ -79,6 +79,8 @@ class ShardedFlatIndexer:
         # the pooled statistics are skipped for `_pooled_backoff` searches (16, doubling up to 1024 while searches keep failing).
         # Every rank sees the same all-reduced numbers, so all of them take the same decisions.
         self.pooled_statistics = pooled_statistics
+        self.force_repeat = False      # measurement aid: every search runs the verdict + repeat path of the pooled scheme (search())
+        self._want_verdict = False
         self._pooled_backoff, self._pooled_penalty = 0, 16
         self.last_search = {}                    # diagnostics of the last search (pooled / repeated)
         self._bad_host = None                    # pinned int32: the check's verdict
@@ -309,6 +311,7 @@ class ShardedFlatIndexer:
         re-create the indexers), do not catch it and retry."""
         pooled = (not self._custom and self.world > 1 and self.pooled_statistics and not self.exchange_warmup
                   and local_queries.is_cuda)
+        force = bool(self.force_repeat) and not self._custom and local_queries.is_cuda and not self.exchange_warmup
         if pooled and self._pooled_backoff > 0:
             self._pooled_backoff -= 1
             pooled = False
@@ -316,10 +319,12 @@ class ShardedFlatIndexer:
         self._verdict = None
         self._marks = []
         self._mark('start')
+        self._want_verdict = pooled or force      # (force_repeat, a measurement aid: the verdict + repeat path of the pooled scheme, whatever the
+                                                  # verdict says and also with one rank — what a failed pooled search costs, bench.py --force-repeat)
         res = self._search(local_queries, k, out, pooled)
-        if not (pooled and self._verdict is not None):
+        if not (self._want_verdict and self._verdict is not None):
             self._collect_phases()
-        if pooled and self._verdict is not None:
+        if self._want_verdict and self._verdict is not None:
             # the counts were all-reduced (SUM) while the re-score, the list exchange and the merge ran
             work, count, kp = self._verdict
             if work is not None:
@@ -330,11 +335,13 @@ class ShardedFlatIndexer:
             self._mark('verdict')
             torch.cuda.current_stream().synchronize()
             self._collect_phases()
-            if int(self._bad_host[0]) > 0:       # the same number on every rank: all of them repeat the search
+            if int(self._bad_host[0]) > 0 or force:       # the same number on every rank: all of them repeat the search
                 self.last_search['repeated'] = True
-                self._pooled_backoff = self._pooled_penalty
-                self._pooled_penalty = min(2 * self._pooled_penalty, 1024)
+                if not force:
+                    self._pooled_backoff = self._pooled_penalty
+                    self._pooled_penalty = min(2 * self._pooled_penalty, 1024)
                 self._verdict = None
+                self._want_verdict = False
                 res = self._search(local_queries, k, out, False)
                 self._mark('repeat')
                 self._collect_phases()
@@ -375,7 +382,7 @@ class ShardedFlatIndexer:
                 self._mark('all_reduce_statistics')
                 tau, count, kp = ix.shard_floor(stat)
                 self._mark('floor')
-                if pooled:
+                if pooled or self._want_verdict:
                     # the verdict (off the critical path): k' rows at or above the largest level of any shard, all ranks together
                     self._verdict = (self._all_reduce_sum_async(count), count, kp)
             else:
