@@ -144,22 +144,6 @@ int reshuffle_rows(ldot_index* ix, hipStream_t st) {
 }
 
 
-// Host waits.  The HIP runtime's default wait (hipStreamSynchronize, and the waits hidden inside hipLaunchKernel when a kernel-argument
-// chunk is recycled) spins for ~100 us and then sleeps on an interrupt; on this platform that wake-up arrives 30-80 ms late once in a few
-// hundred calls (profiles/r06_stall_trace.txt: hipStreamSynchronize 55 ms / hipLaunchKernel 32 ms with the device idle after 2 ms) — the
-// "random host stalls" of a retrieval evaluation whose median is 0.36 ms.  A latency-bound caller wants the spin: the first index created
-// on a device switches the device to hipDeviceScheduleSpin (what cudaDeviceScheduleSpin is; process-wide for that device, one core
-// busy while a wait lasts).  LDOT_HOST_WAIT=runtime in the environment leaves the runtime's policy alone.
-static void host_wait_policy_once(int dev) {
-    static bool done[ldot::kAttrDevices];
-    if (dev < 0 || dev >= ldot::kAttrDevices || done[dev]) return;
-    done[dev] = true;
-    const char* e = getenv("LDOT_HOST_WAIT");
-    if (e && strcmp(e, "runtime") == 0) return;
-    (void)hipSetDeviceFlags(hipDeviceScheduleSpin);   // (a runtime that refuses — flags already fixed — keeps its own policy)
-    (void)hipGetLastError();
-}
-
 extern "C" {
 
 const char* ldot_last_error(void) { return g_err; }
@@ -186,7 +170,6 @@ int ldot_index_create(int d, ldot_index_t** out) {
     ix->d = d;
     ix->dpad = (int)round_up(d, kBK);
     (void)hipGetDevice(&ix->device);
-    host_wait_policy_once(ix->device);
     *out = ix;
     return LDOT_OK;
 }
@@ -227,6 +210,7 @@ int ldot_index_destroy(ldot_index_t* ix) {
     }
     for (hipEvent_t e : ix->prof_pool) (void)hipEventDestroy(e);
     if (ix->h_over_sum) (void)hipHostFree(ix->h_over_sum);
+    if (ix->h_stamp) (void)hipHostFree(ix->h_stamp);
     if (ix->h_nover) (void)hipHostFree(ix->h_nover);
     delete ix;
     return LDOT_OK;
@@ -471,10 +455,12 @@ int ldot_index_last_set_stats(ldot_index_t* ix, int64_t out[2]) {
     out[0] = out[1] = 0;
     if (!ix->set_stats_valid || ix->w_set_stats.p == nullptr) return LDOT_OK;
     DeviceGuard guard(ix->device);
-    unsigned long long h[2] = {0, 0};
-    LDOT_HIP_CHECK(hipMemcpy(h, ix->w_set_stats.p, 16, hipMemcpyDeviceToHost));   // (drains the device: a measurement aid)
-    out[0] = (int64_t)h[0];
-    out[1] = (int64_t)h[1];
+    unsigned long long h[2 * kSetStatSlots];
+    LDOT_HIP_CHECK(hipMemcpy(h, ix->w_set_stats.p, sizeof(h), hipMemcpyDeviceToHost));   // (drains the device: a measurement aid)
+    for (int s = 0; s < kSetStatSlots; ++s) {
+        out[0] += (int64_t)h[2 * s];
+        out[1] += (int64_t)h[2 * s + 1];
+    }
     return LDOT_OK;
 }
 

@@ -95,6 +95,10 @@ struct ldot_index {
     // 4-byte copy per search
     DevBuf w_over_sum;
     int32_t* h_over_sum = nullptr;
+    // completion stamp of stream_wait (scan.hip): one pinned, device-mapped word the stream writes when everything before it is done
+    uint32_t* h_stamp = nullptr;
+    void* d_stamp = nullptr;
+    uint32_t stamp_seq = 0;
     bool overflow_pending = false;   // a fused scan ran and its overflow summary has not been looked at yet
     // stats[0] (records appended by the fused filter): per-query counts accumulated on the device by the pool selects, summed on
     // the host only when ldot_index_last_stats is called
@@ -200,6 +204,13 @@ bool fused_overflow_check(ldot_index* ix);
 int redo_flagged(ldot_index* ix, int64_t nq, int64_t nq_pad, int kp, hipStream_t st, int level = 0);
 int stage_unstaged_queries(ldot_index* ix, int64_t nq, hipStream_t st);
 bool auto_fused(const ldot_index* ix, int64_t nq);
+// Wait until everything enqueued on `st` so far is done — without the runtime's wait.  hipStreamSynchronize spins ~100 us and then sleeps
+// until the runtime's event thread has handled the completion interrupt: with other work on the host's cores that thread — and with it the
+// waiter — gets the CPU tens of milliseconds late (profiles/r06_stall_trace.txt, r06_host_stall_probe.txt: 30-90 ms stalls of a 0.36-ms
+// evaluation with the device idle after 2 ms, the waiting thread runnable-but-not-running; a torch-only loop shows them too).  Here the
+// stream writes a sequence number into a pinned word (hipStreamWriteValue32) and the calling thread polls it: no second thread, no sleep.
+// LDOT_HOST_WAIT=runtime in the environment (or a runtime without the stream operation) falls back to hipStreamSynchronize.
+int stream_wait(ldot_index* ix, hipStream_t st);
 // search.hip
 int search_finish_impl(ldot_index_t* ix, const float* floor, float* out_scores, int64_t* out_labels, int out_mem,
                               bool keep_pending, hipStream_t st);

@@ -173,7 +173,9 @@ int launch_rescore(const float* q32, int64_t ldq, const float* x32, int64_t ldx,
                    float* out_s, int64_t* out_l, hipStream_t st,
                    const RescoreOut* layout = nullptr, const int32_t* label_map = nullptr);
 // LDOT_OPT_RESULT_SET (rescore.hip): the top-k SET — only the candidates within 2E of the k-th candidate score are re-scored exactly
-// (E = band_c * 2^-8 * |q| * max_norm / sqrt(d)); stats (optional, device): [0] += candidates gathered, [1] += live candidates
+// (E = band_c * 2^-8 * |q| * max_norm / sqrt(d)); stats (optional, device, 2 * kSetStatSlots counters): [2 s] += candidates gathered,
+// [2 s + 1] += live candidates, slot s = workgroup mod kSetStatSlots
+constexpr int kSetStatSlots = 64;
 int launch_rescore_set(const float* q32, int64_t ldq, const float* x32, int64_t ldx, int dpad, int d, int64_t nq, const float* list_s,
                        const int32_t* list_i, int kp, int k, const float* max_norm, float band_c, float* out_s, int64_t* out_l,
                        const int32_t* label_map, unsigned long long* stats, hipStream_t st);

@@ -60,6 +60,18 @@ __host__ __device__ inline float desc_key_to_float(uint32_t k) {
     return v.f;
 }
 
+// wave-wide integer sum in 7 DPP adds + one readlane (quad swaps, row mirrors, row broadcasts: the total lands in lane 63): pure VALU —
+// counting with ballots costs scalar-unit issue slots, which the waves of a CU share, and a bpermute-based __shfl_xor reduction ~600 cycles
+__device__ __forceinline__ int wave_sum_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);   // row_mirror  -> every lane: its row's sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 __host__ __device__ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 void set_error(const char* fmt, ...);

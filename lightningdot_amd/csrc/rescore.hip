@@ -17,7 +17,9 @@ __global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __rest
                                                              int do_rescore, const float* __restrict__ floor,
                                                              float* __restrict__ out_s,
                                                              int64_t* __restrict__ out_l, RescoreOut lay, int64_t nq) {
-    __shared__ __attribute__((aligned(16))) uint64_t keys[4096];   // next power of two >= kMaxKp
+    // [next power of two >= k']: sized per launch — a fixed 32-KiB buffer (kMaxKp keys) held a CU to five workgroups whatever k' was, and the
+    // gather of a cache-resident index (Flickr / COCO sized, the mining searches) lives on loads in flight
+    extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
     static_assert(kMaxKp <= 4096, "re-score key buffer");
     // Block b is observed on XCD b % 8 (speed only).  Neighbouring queries of a retrieval evaluation are captions of the same image
     // (dvl/trainer.py:130-154 walks the dataset in order) and share most of their candidate rows: sixteen consecutive queries go to ONE XCD,
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __rest
 // and only the candidates in between are gathered from the fp32 master copy (3 KiB per row — the cost of a mining search at top-1000) and
 // ordered exactly; the k - #IN best of them complete the set.  Under that bound the labels are the set the full re-score reports (ties at
 // the boundary broken by the lower label, as there).  The ORDER of the k outputs is unspecified: the IN candidates (reported score = their
-// bf16-input candidate score) in list order, then the band's winners by exact score.  stats[0] += candidates gathered, stats[1] += live candidates.
+// bf16-input candidate score) in list order, then the band's winners by exact score.  stats[2 s] += candidates gathered, stats[2 s + 1] += live candidates (kSetStatSlots slots s).
 //
 // No sort anywhere: a workgroup (ONE wave for k' <= 256: no barriers, 32 queries in flight per CU; four waves beyond) holds the k' candidates in
 // registers, finds c_(k) by a bit search over their descending keys (count-and-reduce per bit), classifies, gathers the band's rows and
@@ -144,9 +146,9 @@ __global__ __launch_bounds__(kRsThreads) void rescore_kernel(const float* __rest
 // as long as the full re-score — LDS occupancy, not the 12 % of the rows it gathered: profiles/r06_mining_kernels_first.txt.)
 template <int T>
 __device__ __forceinline__ int set_block_sum(int v, int* red, int slot) {
-    // sum over the workgroup; `slot` alternates between calls so that ONE barrier per call is enough
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    // sum over the workgroup; `slot` alternates between calls so that ONE barrier per call is enough.  (DPP wave sum: ~50 cycles of VALU; six
+    // ds_bpermute round trips per bit of the search were most of a one-wave workgroup's time)
+    v = wave_sum_dpp(v);
     if (T == 64) return v;
     if ((threadIdx.x & 63) == 0) red[slot * (T / 64) + (threadIdx.x >> 6)] = v;
     __syncthreads();
@@ -183,12 +185,18 @@ __global__ __launch_bounds__(T) void rescore_set_kernel(const float* __restrict_
 #pragma unroll
     for (int v = 0; v < VP; ++v) {
         const int e = v * T + threadIdx.x;
-        row[v] = e < kp ? list_i[q * kp + e] : -1;
-        key[v] = row[v] >= 0 ? desc_key(list_s[q * kp + e]) : 0xffffffffu;
+        const int el = e < kp ? e : kp - 1;          // (both loads unconditional: a load that depends on the other one's result is a second round trip)
+        const int32_t lr = list_i[q * kp + el];
+        const float lsv = list_s[q * kp + el];
+        row[v] = e < kp ? lr : -1;
+        key[v] = row[v] >= 0 ? desc_key(lsv) : 0xffffffffu;
         mine += row[v] >= 0;
     }
-    float qq = 0.f;   // |q|^2 (the band is relative to the query's norm)
-    for (int c = threadIdx.x; c < d; c += T) qq = fmaf(qrow[c], qrow[c], qq);
+    float qq = 0.f;   // |q|^2 (the band is relative to the query's norm; rows are zero-padded to dpad, a multiple of 4)
+    for (int c = threadIdx.x * 4; c < dpad; c += T * 4) {
+        const f32x4 v4 = *(const f32x4*)(qrow + c);
+        qq += (v4[0] * v4[0] + v4[1] * v4[1]) + (v4[2] * v4[2] + v4[3] * v4[3]);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) qq += __shfl_xor(qq, o);
     if (lane == 0) qq_sh[wave] = qq;
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(T) void rescore_set_kernel(const float* __restrict_
             os[e] = LDOT_PAD_SCORE;
             ol[e] = LDOT_PAD_LABEL;
         }
-        if (threadIdx.x == 0 && stats) atomicAdd(stats + 1, (unsigned long long)m);
+        if (threadIdx.x == 0 && stats) atomicAdd(stats + 2 * (blockIdx.x & (kSetStatSlots - 1)) + 1, (unsigned long long)m);
         return;
     }
     // ---- c_(k): the k-th smallest descending key, by bit search (the bits all candidates share are skipped) ---------------------
@@ -335,9 +343,9 @@ __global__ __launch_bounds__(T) void rescore_set_kernel(const float* __restrict_
             ol[a + rank] = (int64_t)(uint32_t)me;
         }
     }
-    if (threadIdx.x == 0 && stats) {
-        atomicAdd(stats, (unsigned long long)nb);
-        atomicAdd(stats + 1, (unsigned long long)m);
+    if (threadIdx.x == 0 && stats) {   // (kSetStatSlots counter pairs: 290 000 atomics on ONE pair of addresses took longer than the kernel's work)
+        atomicAdd(stats + 2 * (blockIdx.x & (kSetStatSlots - 1)), (unsigned long long)nb);
+        atomicAdd(stats + 2 * (blockIdx.x & (kSetStatSlots - 1)) + 1, (unsigned long long)m);
     }
 }
 
@@ -502,11 +510,14 @@ int launch_rescore(const float* q32, int64_t ldq, const float* x32, int64_t ldx,
     if (nq <= 0) return LDOT_OK;
     RescoreOut lay = layout ? *layout : RescoreOut{0, 0, 0, 0, nullptr};
     if (label_map) lay.label_map = label_map;
+    int P = 2;
+    while (P < kp) P <<= 1;
+    const size_t lds = (size_t)P * 8;
     if (nq <= 128)
-        hipLaunchKernelGGL(rescore_kernel<1024>, dim3((unsigned)nq), dim3(1024), 0, st, q32, ldq, x32, ldx, dpad, list_s,
+        hipLaunchKernelGGL(rescore_kernel<1024>, dim3((unsigned)nq), dim3(1024), lds, st, q32, ldq, x32, ldx, dpad, list_s,
                            list_i, kp, k, do_rescore, floor, out_s, out_l, lay, nq);
     else   // (whole groups of 128 blocks: the kernel deals sixteen consecutive queries to one XCD)
-        hipLaunchKernelGGL(rescore_kernel<256>, dim3((unsigned)round_up(nq, 128)), dim3(256), 0, st, q32, ldq, x32, ldx, dpad, list_s,
+        hipLaunchKernelGGL(rescore_kernel<256>, dim3((unsigned)round_up(nq, 128)), dim3(256), lds, st, q32, ldq, x32, ldx, dpad, list_s,
                            list_i, kp, k, do_rescore, floor, out_s, out_l, lay, nq);
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;

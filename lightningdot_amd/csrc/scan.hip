@@ -2,6 +2,48 @@
 // warm-up, growth schedule, optimistic / pooled thresholds and scan order, the overflow check and the recovery of flagged queries.
 #include "index_state.h"
 
+#include <chrono>
+
+int stream_wait(ldot_index* ix, hipStream_t st) {
+    static int mode = -1;   // 0: the runtime's wait, 1: poll the stamp
+    if (mode < 0) {
+        const char* e = getenv("LDOT_HOST_WAIT");
+        mode = (e && strcmp(e, "runtime") == 0) ? 0 : 1;
+    }
+    if (mode == 1 && !ix->h_stamp) {
+        if (hipHostMalloc((void**)&ix->h_stamp, 64, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer(&ix->d_stamp, ix->h_stamp, 0) != hipSuccess || ix->d_stamp == nullptr) {
+            (void)hipGetLastError();
+            if (ix->h_stamp) (void)hipHostFree(ix->h_stamp);
+            ix->h_stamp = nullptr;
+            mode = 0;
+        } else {
+            *(volatile uint32_t*)ix->h_stamp = 0;
+            ix->stamp_seq = 0;
+        }
+    }
+    if (mode == 1) {
+        const uint32_t seq = ++ix->stamp_seq;
+        if (hipStreamWriteValue32(st, ix->d_stamp, seq, 0) == hipSuccess) {
+            volatile uint32_t* w = (volatile uint32_t*)ix->h_stamp;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (uint64_t spins = 0; *w != seq; ++spins) {
+                __builtin_ia32_pause();
+                if ((spins & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;   // (a lost write: let the runtime decide)
+            }
+            if (*w == seq) {
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                return LDOT_OK;
+            }
+        } else {
+            (void)hipGetLastError();
+            mode = 0;   // this runtime does not do stream writes: its own wait from now on
+        }
+    }
+    LDOT_HIP_CHECK(hipStreamSynchronize(st));
+    return LDOT_OK;
+}
+
 int candidate_len(const ldot_index* ix, int k) {
     int margin = ix->margin >= 0 ? ix->margin : std::max(28, k / 4);
     if (!ix->rescore) margin = 0;

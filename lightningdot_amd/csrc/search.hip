@@ -101,7 +101,7 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
         ix->last_path = 1;
         if ((rc = narrow_search(ix, nq, kp, st, direct))) return rc;
         if (!defer_check) {
-            LDOT_HIP_CHECK(hipStreamSynchronize(st));
+            if ((rc = stream_wait(ix, st))) return rc;
             if (fused_overflow_check(ix)) {
                 if ((rc = stage_unstaged_queries(ix, nq, st))) return rc;
                 if ((rc = redo_flagged(ix, nq, nq_pad, kp, st))) return rc;
@@ -120,7 +120,7 @@ static int search_begin_impl(ldot_index_t* ix, const void* queries, int64_t nq, 
             ix->last_thresholds = ix->pooled_used ? 3 : ix->opt_used ? 2 : 1;
             ix->last_order = ix->scrambled_now ? 2 : 1;
             if (!defer_check) {
-                LDOT_HIP_CHECK(hipStreamSynchronize(st));
+                if ((rc = stream_wait(ix, st))) return rc;
                 if (fused_overflow_check(ix) && (rc = redo_flagged(ix, nq, nq_pad, kp, st))) return rc;
             }
         } else if ((rc = dense_scan_all(ix, nq, 0, ix->ntotal, kp, tau, true, st))) {
@@ -199,14 +199,14 @@ int ldot_index_search_scan(ldot_index_t* ix, const float* stat_in, float* tau_ou
     int rc;
     if (path == 1) {   // (the small-batch and small-index paths do not use the agreed thresholds: their scan is one pass anyway)
         if ((rc = narrow_search(ix, nq, kp, st, nullptr))) return rc;
-        LDOT_HIP_CHECK(hipStreamSynchronize(st));
+        if ((rc = stream_wait(ix, st))) return rc;
         if (fused_overflow_check(ix) && (rc = redo_flagged(ix, nq, nq_pad, kp, st))) return rc;
     } else if (path == 2) {
         if (ix->ntotal > 0 && (rc = dense_scan_all(ix, nq, 0, ix->ntotal, kp, tau, true, st))) return rc;
     } else {
         if (stat_in && (rc = launch_apply_stats(nq, stat_in, tau, st))) return rc;
         if ((rc = fused_scan(ix, nq, nq_pad, kp, st, 2, stat_in ? ix->split_parts : 1))) return rc;
-        LDOT_HIP_CHECK(hipStreamSynchronize(st));
+        if ((rc = stream_wait(ix, st))) return rc;
         if (fused_overflow_check(ix) && (rc = redo_flagged(ix, nq, nq_pad, kp, st))) return rc;
     }
     if (tau_out) LDOT_HIP_CHECK(hipMemcpyAsync(tau_out, tau, (size_t)nq * 4, hipMemcpyDeviceToDevice, st));
@@ -242,8 +242,8 @@ int search_finish_impl(ldot_index_t* ix, const float* floor, float* out_scores, 
     const bool as_set = ix->result_set && floor == nullptr && ix->rescore && ix->w_norm.p != nullptr;
     ix->set_stats_valid = false;
     if (as_set) {
-        if ((rc = ix->w_set_stats.ensure(16))) return rc;
-        LDOT_HIP_CHECK(hipMemsetAsync(ix->w_set_stats.p, 0, 16, st));
+        if ((rc = ix->w_set_stats.ensure(16 * kSetStatSlots))) return rc;
+        LDOT_HIP_CHECK(hipMemsetAsync(ix->w_set_stats.p, 0, 16 * kSetStatSlots, st));
         ix->set_stats_valid = true;
     }
     auto rescore_to = [&](float* os, int64_t* ol) -> int {
@@ -272,7 +272,7 @@ int search_finish_impl(ldot_index_t* ix, const float* floor, float* out_scores, 
         // LDOT_OPT_DEFER_SYNC: the caller synchronises (everything this search used stays alive until the handle's next call on this
         // stream).  Profiling events are read on the host and the verify flags are the caller's to read: both keep the synchronisation.
         if (ix->defer_sync && !ix->profile && !ix->verify && floor == nullptr && !keep_pending) return LDOT_OK;
-        LDOT_HIP_CHECK(hipStreamSynchronize(st));
+        if ((rc = stream_wait(ix, st))) return rc;
         prof_collect(ix, st);
         return LDOT_OK;
     }
@@ -349,7 +349,7 @@ int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dty
     if (ix->pend_done) {   // the results are on their way already; the one synchronisation of the search + the buffer-full check
         ix->pend_done = false;
         if (ix->chain_defer_sync) return LDOT_OK;   // (internal chain: the caller synchronises and checks, see ldot_ivf_search)
-        LDOT_HIP_CHECK(hipStreamSynchronize(st));
+        if ((rc = stream_wait(ix, st))) return rc;
         prof_collect(ix, st);
         if (fused_overflow_check(ix)) {
             if ((rc = stage_unstaged_queries(ix, nq, st))) return rc;
@@ -362,7 +362,7 @@ int ldot_index_search(ldot_index_t* ix, const void* queries, int64_t nq, int dty
     const bool check = ix->overflow_pending;
     if ((rc = search_finish_impl(ix, nullptr, out_scores, out_labels, out_mem, check, st))) return rc;
     if (!check) return LDOT_OK;
-    if (out_mem == LDOT_DEVICE) LDOT_HIP_CHECK(hipStreamSynchronize(st));
+    if (out_mem == LDOT_DEVICE && (rc = stream_wait(ix, st))) return rc;
     if (fused_overflow_check(ix)) {   // unfriendly row order: the flagged queries are searched again (redo_flagged), the rest re-scored as is
         if ((rc = redo_flagged(ix, nq, round_up(nq, kBM), ix->pend_kp, st))) return rc;
         return search_finish_impl(ix, nullptr, out_scores, out_labels, out_mem, false, st);

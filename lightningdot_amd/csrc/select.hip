@@ -369,43 +369,51 @@ __global__ __launch_bounds__(kSelThreads) void select_dense_kernel(const float* 
 
 // dense source, LONG lists (k' > 512: the mining searches of dvl/hn.py:53 at num_tops up to 1000, k' up to 3072): the streaming selector
 // above compacts its 4096-key LDS buffer with a bitonic sort once per 1024-column segment — 330 us per query over a 29 000-column row.  Here
-// the workgroup holds the WHOLE row of the chunk (<= 32 768 columns: 64 per thread) and the running list in registers and finds the
-// k'-th best key by a bit search: one compare-and-count pass over the registers + one workgroup reduction per bit, no sort, no LDS
-// traffic; the k' winners are then written out as a SET (the consumers — the next chunk's call, the pool select, the re-score — take
-// lists as sets).  Key order = (score desc, row asc) as everywhere: rows break score ties by a second bit search over the tied rows, which
-// runs only when the ties straddle the k'-th place.
-constexpr int kBitsThreads = 512;
-constexpr int kBitsVPT = 64;         // row values per thread (16 x f32x4): <= 32 768 columns per chunk
+// the workgroup holds the WHOLE row of the chunk (<= 32 768 columns: 32 per thread) and the running list in registers and finds the
+// k'-th best key by a bit search: one compare-and-count pass over the registers + one workgroup reduction per bit, no sort; the k'
+// winners are then written out as a SET (the consumers — the next chunk's call, the pool select, the re-score — take lists as sets).
+// Two phases: the first bits are decided over all registers while the count of still undecided elements (those that share the decided
+// prefix) is tracked for free; as soon as they fit kBitsCap — after the sign, the exponent and a mantissa bit or two for scores of one
+// row: ~10 of 32 bits — they are compacted into LDS, four per thread, and the remaining bits cost 4 compares per thread instead of 35.
+// Key order = (score desc, row asc) as everywhere: rows break score ties by a second bit search over the tied rows, which runs only when the
+// ties straddle the k'-th place.  (First version, one phase, shuffle-based sums, 512 threads x 64 values: 59 us per query,
+// profiles/r06_mining_kernels_second.txt.)
+constexpr int kBitsThreads = 1024;
+constexpr int kBitsVPT = 32;                      // row values per thread (8 x f32x4): <= 32 768 columns per chunk
 constexpr int kBitsLPT = kMaxKp / kBitsThreads;   // list entries per thread
+constexpr int kBitsAPT = 4;                       // undecided elements per thread in the second phase
+constexpr int kBitsCap = kBitsAPT * kBitsThreads;
+constexpr int kBitsWaves = kBitsThreads / 64;
 static_assert(kMaxKp % kBitsThreads == 0, "list entries per thread");
 
+// sum over the workgroup: DPP wave sums, one LDS word per wave, ONE barrier (`slot` alternates between calls)
 __device__ __forceinline__ int bits_block_sum(int v, int* red, int slot) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) == 0) red[slot * (kBitsThreads / 64) + (threadIdx.x >> 6)] = v;
+    const int w = wave_sum_dpp(v);
+    if ((threadIdx.x & 63) == 0) red[slot * kBitsWaves + (threadIdx.x >> 6)] = w;
     __syncthreads();
     int t = 0;
 #pragma unroll
-    for (int w = 0; w < kBitsThreads / 64; ++w) t += red[slot * (kBitsThreads / 64) + w];
+    for (int i = 0; i < kBitsWaves; ++i) t += red[slot * kBitsWaves + i];
     return t;
 }
 
-__global__ __launch_bounds__(kBitsThreads, 2) void select_dense_bits_kernel(const float* __restrict__ S, int64_t lds_elems, int64_t ncols,
+__global__ __launch_bounds__(kBitsThreads) void select_dense_bits_kernel(const float* __restrict__ S, int64_t lds_elems, int64_t ncols,
                                                                          int64_t idx_base, float* __restrict__ list_s,
                                                                          int32_t* __restrict__ list_i, int kp, float* __restrict__ tau) {
-    __shared__ int red[2 * (kBitsThreads / 64)];
-    __shared__ uint32_t rbits[2 * (kBitsThreads / 64)];
+    __shared__ int red[2 * kBitsWaves];
+    __shared__ uint32_t rbits[2 * kBitsWaves];
+    __shared__ uint32_t akey[kBitsCap], arow[kBitsCap];
     const int64_t q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* row = S + q * lds_elems;
     float* ls = list_s + q * kp;
     int32_t* li = list_i + q * kp;
     // ---- the row and the running list -> descending keys in registers (0xffffffff = nothing) -------------------------------------
+    // (unconditional loads from clamped addresses, validity applied afterwards: a conditional load is a branch + a wait of its own.  The
+    // score rows are lds_elems >= round_up(ncols, 4) long; list slots past k' re-read the last one)
     uint32_t key[kBitsVPT], lkey[kBitsLPT];
     int32_t lrow[kBitsLPT];
     int mine = 0;
-    // (unconditional loads from clamped addresses, validity applied afterwards: a conditional load is a branch + a wait of its own.  The
-    // score rows are lds_elems >= round_up(ncols, 4) long; list slots past k' re-read the last one)
 #pragma unroll
     for (int j = 0; j < kBitsVPT / 4; ++j) {
         const int64_t c = ((int64_t)j * kBitsThreads + tid) * 4;
@@ -415,8 +423,8 @@ __global__ __launch_bounds__(kBitsThreads, 2) void select_dense_bits_kernel(cons
         for (int e = 0; e < 4; ++e) {
             const bool ok = c + e < ncols && cl == c;
             key[j * 4 + e] = ok ? desc_key(v[e]) : 0xffffffffu;
-            // (opaque from here on: otherwise every later `key != 0xffffffff` is rewritten in terms of `ok`, and 64 compare masks stay alive —
-            // spilled — from the loads to the write-out)
+            // (opaque from here on: otherwise every later `key != 0xffffffff` is rewritten in terms of `ok`, and the compare masks of all
+            // registers stay alive — spilled — from the loads to the write-out)
             asm volatile("" : "+v"(key[j * 4 + e]));
             mine += ok ? 1 : 0;
         }
@@ -433,10 +441,10 @@ __global__ __launch_bounds__(kBitsThreads, 2) void select_dense_bits_kernel(cons
         mine += lkey[r] != 0xffffffffu ? 1 : 0;
     }
     const int n = bits_block_sum(mine, red, 0);
+    auto col_row = [&](int i) { return (uint32_t)idx_base + (uint32_t)(((i >> 2) * kBitsThreads + tid) * 4 + (i & 3)); };
     // ---- the k'-th smallest key (every element is selected when there are no more than k') -----------------------------------------
     uint32_t kth = 0xffffffffu;
-    int need_ties = 0x7fffffff;          // how many of the elements with key == kth belong to the list (all of them unless ties straddle)
-    uint32_t row_cut = 0xffffffffu;      // ... those with row <= row_cut
+    uint32_t row_cut = 0xffffffffu;      // of the elements with key == kth those with row <= row_cut belong to the list
     if (n >= kp) {
         uint32_t all_and = 0xffffffffu, all_or = 0u;
 #pragma unroll
@@ -456,85 +464,178 @@ __global__ __launch_bounds__(kBitsThreads, 2) void select_dense_bits_kernel(cons
         }
         if (lane == 0) {
             rbits[wave] = all_and;
-            rbits[kBitsThreads / 64 + wave] = all_or;
+            rbits[kBitsWaves + wave] = all_or;
         }
         __syncthreads();
 #pragma unroll
-        for (int w = 0; w < kBitsThreads / 64; ++w) {
+        for (int w = 0; w < kBitsWaves; ++w) {
             all_and &= rbits[w];
-            all_or |= rbits[kBitsThreads / 64 + w];
+            all_or |= rbits[kBitsWaves + w];
         }
         const uint32_t diff = all_and ^ all_or;
         const int hb = diff ? 31 - __clz((int)diff) : -1;
         kth = hb >= 31 ? 0u : hb < 0 ? all_or : (all_or & ~((2u << hb) - 1u));
         int slot = 1;
-        for (int bit = hb; bit >= 0; --bit) {
+        // phase 1: all registers; `below` = elements whose decided prefix is smaller than kth's (in the list for sure), `active` = those
+        // that share it (undecided)
+        int below = 0, active = n, bit = hb;
+        for (; bit >= 0 && active > kBitsCap; --bit) {
             const uint32_t test = kth | ((1u << bit) - 1u);
             int c = 0;
 #pragma unroll
             for (int i = 0; i < kBitsVPT; ++i) {
                 c += key[i] <= test ? 1 : 0;
-                if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler issues all 70 compares first and spills their masks)
+                if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler issues all compares first and spills their masks)
             }
 #pragma unroll
             for (int r = 0; r < kBitsLPT; ++r) c += lkey[r] <= test ? 1 : 0;
-            if (bits_block_sum(c, red, slot) < kp) kth |= 1u << bit;
+            const int cnt = bits_block_sum(c, red, slot);
             slot ^= 1;
+            if (cnt < kp) {
+                kth |= 1u << bit;
+                active -= cnt - below;
+                below = cnt;
+            } else {
+                active = cnt - below;
+            }
         }
-        // ties at the k'-th key: the lower rows win
-        int below = 0, ties = 0;
+        if (bit >= 0) {
+            // phase 2: the undecided elements (prefix above `bit` equal to kth's), compacted into LDS, kBitsAPT per thread
+            const uint32_t pm = bit >= 31 ? 0u : ~((2u << bit) - 1u);
+            const uint32_t pref = kth & pm;
+            int na = 0;
 #pragma unroll
-        for (int i = 0; i < kBitsVPT; ++i) {
-            below += key[i] < kth ? 1 : 0;
-            ties += key[i] == kth ? 1 : 0;
-        }
+            for (int r = 0; r < kBitsLPT; ++r) na += (lkey[r] != 0xffffffffu && (lkey[r] & pm) == pref) ? 1 : 0;
 #pragma unroll
-        for (int r = 0; r < kBitsLPT; ++r) {
-            below += lkey[r] < kth ? 1 : 0;
-            ties += lkey[r] == kth ? 1 : 0;
-        }
-        below = bits_block_sum(below, red, slot);
-        slot ^= 1;
-        ties = bits_block_sum(ties, red, slot);
-        slot ^= 1;
-        need_ties = kp - below;
-        if (ties > need_ties) {          // (uniform) the need_ties-th smallest row among the tied elements
-            uint32_t cut = 0;
-            for (int bit = 31; bit >= 0; --bit) {
-                const uint32_t test = cut | ((1u << bit) - 1u);
-                int c = 0;
-                // (a rare path: its loop-invariant parts — 70 tie masks, 64 row numbers — must NOT be hoisted out of the bit loop into
-                // registers the common path then pays for: both are derived from laundered values inside the loop)
-                uint32_t kth_l = kth, row_l = (uint32_t)idx_base + (uint32_t)tid * 4u;
-                asm volatile("" : "+v"(kth_l), "+v"(row_l));
+            for (int i = 0; i < kBitsVPT; ++i) na += (key[i] != 0xffffffffu && (key[i] & pm) == pref) ? 1 : 0;
+            int incl = na;
 #pragma unroll
-                for (int i = 0; i < kBitsVPT; ++i) {
-                    const uint32_t r_ = row_l + (uint32_t)((i >> 2) * kBitsThreads * 4 + (i & 3));
-                    c += (key[i] == kth_l && r_ <= test) ? 1 : 0;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(incl, o);
+                if (lane >= o) incl += up;
+            }
+            __syncthreads();                 // (`red` is free: every thread has left the last sum)
+            if (lane == 63) red[wave] = incl;
+            __syncthreads();
+            int pos = incl - na;
+#pragma unroll
+            for (int w = 0; w < kBitsWaves; ++w) pos += w < wave ? red[w] : 0;
+            {
+                uint32_t pm_l = pm, pref_l = pref;   // (not the masks of the counting pass again: they would be kept alive — see above)
+                asm volatile("" : "+v"(pm_l), "+v"(pref_l));
+#pragma unroll
+                for (int r = 0; r < kBitsLPT; ++r) {
+                    if (lkey[r] != 0xffffffffu && (lkey[r] & pm_l) == pref_l) {
+                        akey[pos] = lkey[r];
+                        arow[pos] = (uint32_t)lrow[r];
+                        ++pos;
+                    }
                 }
 #pragma unroll
-                for (int r = 0; r < kBitsLPT; ++r) c += (lkey[r] == kth_l && (uint32_t)lrow[r] <= test) ? 1 : 0;
-                if (bits_block_sum(c, red, slot) < need_ties) cut |= 1u << bit;
+                for (int i = 0; i < kBitsVPT; ++i) {
+                    if (key[i] != 0xffffffffu && (key[i] & pm_l) == pref_l) {
+                        akey[pos] = key[i];
+                        arow[pos] = col_row(i);
+                        ++pos;
+                    }
+                    if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();
+            uint32_t ak[kBitsAPT], ar[kBitsAPT];
+#pragma unroll
+            for (int j = 0; j < kBitsAPT; ++j) {
+                const int e = j * kBitsThreads + tid;
+                ak[j] = e < active ? akey[e] : 0xffffffffu;
+                ar[j] = e < active ? arow[e] : 0xffffffffu;
+            }
+            const int need = kp - below;     // the need-th smallest of the undecided elements is the k'-th overall
+            for (; bit >= 0; --bit) {
+                const uint32_t test = kth | ((1u << bit) - 1u);
+                int c = 0;
+#pragma unroll
+                for (int j = 0; j < kBitsAPT; ++j) c += ak[j] <= test ? 1 : 0;
+                if (bits_block_sum(c, red, slot) < need) kth |= 1u << bit;
                 slot ^= 1;
             }
-            row_cut = cut;
+            int lt = 0, eq = 0;
+#pragma unroll
+            for (int j = 0; j < kBitsAPT; ++j) {
+                lt += ak[j] < kth ? 1 : 0;
+                eq += ak[j] == kth ? 1 : 0;
+            }
+            lt = bits_block_sum(lt, red, slot);
+            slot ^= 1;
+            eq = bits_block_sum(eq, red, slot);
+            slot ^= 1;
+            const int need_ties = need - lt;
+            if (eq > need_ties) {            // (uniform) ties straddle the k'-th place: the need_ties-th smallest row among them
+                uint32_t cut = 0;
+                for (int b = 31; b >= 0; --b) {
+                    const uint32_t test = cut | ((1u << b) - 1u);
+                    int c = 0;
+#pragma unroll
+                    for (int j = 0; j < kBitsAPT; ++j) c += (ak[j] == kth && ar[j] <= test) ? 1 : 0;
+                    if (bits_block_sum(c, red, slot) < need_ties) cut |= 1u << b;
+                    slot ^= 1;
+                }
+                row_cut = cut;
+            }
+        } else {
+            // every bit was decided over the registers (more than kBitsCap elements share a long prefix: thousands of equal scores): ties
+            // over the registers as well
+            int lt = 0, eq = 0;
+#pragma unroll
+            for (int i = 0; i < kBitsVPT; ++i) {
+                lt += key[i] < kth ? 1 : 0;
+                eq += key[i] == kth ? 1 : 0;
+            }
+#pragma unroll
+            for (int r = 0; r < kBitsLPT; ++r) {
+                lt += lkey[r] < kth ? 1 : 0;
+                eq += lkey[r] == kth ? 1 : 0;
+            }
+            lt = bits_block_sum(lt, red, slot);
+            slot ^= 1;
+            eq = bits_block_sum(eq, red, slot);
+            slot ^= 1;
+            const int need_ties = kp - lt;
+            if (eq > need_ties) {
+                uint32_t cut = 0;
+                for (int b = 31; b >= 0; --b) {
+                    const uint32_t test = cut | ((1u << b) - 1u);
+                    int c = 0;
+                    // (a rare path: its loop-invariant parts — the tie masks, the row numbers — must NOT be hoisted out of the bit loop into
+                    // registers the common path then pays for: both are derived from laundered values inside the loop)
+                    uint32_t kth_l = kth, row_l = (uint32_t)idx_base + (uint32_t)tid * 4u;
+                    asm volatile("" : "+v"(kth_l), "+v"(row_l));
+#pragma unroll
+                    for (int i = 0; i < kBitsVPT; ++i) {
+                        const uint32_t r_ = row_l + (uint32_t)((i >> 2) * kBitsThreads * 4 + (i & 3));
+                        c += (key[i] == kth_l && r_ <= test) ? 1 : 0;
+                    }
+#pragma unroll
+                    for (int r = 0; r < kBitsLPT; ++r) c += (lkey[r] == kth_l && (uint32_t)lrow[r] <= test) ? 1 : 0;
+                    if (bits_block_sum(c, red, slot) < need_ties) cut |= 1u << b;
+                    slot ^= 1;
+                }
+                row_cut = cut;
+            }
         }
     }
     // ---- write the winners (a set: thread after thread, a thread's list entries before its columns), then the empty slots ---------------
     // (the verdict of every register is kept as one bit of a lane mask: recomputing the predicates in the write loop makes the compiler keep
-    // 70 compare results alive in scalar registers and spill them)
-    uint64_t selm = 0;
-    uint32_t lselm = 0;
+    // all the compare results alive in scalar registers and spill them)
+    uint32_t selm = 0, lselm = 0;
 #pragma unroll
     for (int r = 0; r < kBitsLPT; ++r)
         lselm |= (lkey[r] != 0xffffffffu && (lkey[r] < kth || (lkey[r] == kth && (uint32_t)lrow[r] <= row_cut))) ? (1u << r) : 0u;
 #pragma unroll
-    for (int i = 0; i < kBitsVPT; ++i) {
-        const uint32_t r_ = (uint32_t)(idx_base + ((int64_t)(i >> 2) * kBitsThreads + tid) * 4 + (i & 3));
-        selm |= (key[i] != 0xffffffffu && (key[i] < kth || (key[i] == kth && r_ <= row_cut))) ? (1ull << i) : 0ull;
-    }
+    for (int i = 0; i < kBitsVPT; ++i)
+        selm |= (key[i] != 0xffffffffu && (key[i] < kth || (key[i] == kth && col_row(i) <= row_cut))) ? (1u << i) : 0u;
+    static_assert(kBitsVPT <= 32 && kBitsLPT <= 32, "verdict masks");
     asm volatile("" : "+v"(selm), "+v"(lselm));
-    const int sel_cnt = __popcll(selm) + __popc(lselm);
+    const int sel_cnt = __popc(selm) + __popc(lselm);
     int incl = sel_cnt;                  // inclusive scan over the wave, then over the workgroup's waves
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -547,7 +648,7 @@ __global__ __launch_bounds__(kBitsThreads, 2) void select_dense_bits_kernel(cons
     int pos = incl - sel_cnt;
     int m = 0;
 #pragma unroll
-    for (int w = 0; w < kBitsThreads / 64; ++w) {
+    for (int w = 0; w < kBitsWaves; ++w) {
         pos += w < wave ? red[w] : 0;
         m += red[w];                     // = min(n, k')
     }
@@ -562,9 +663,9 @@ __global__ __launch_bounds__(kBitsThreads, 2) void select_dense_bits_kernel(cons
     }
 #pragma unroll
     for (int i = 0; i < kBitsVPT; ++i) {
-        if ((selm >> i) & 1ull) {
+        if ((selm >> i) & 1u) {
             ls[pos] = desc_key_to_float(key[i]);
-            li[pos] = (int32_t)(uint32_t)(idx_base + ((int64_t)(i >> 2) * kBitsThreads + tid) * 4 + (i & 3));
+            li[pos] = (int32_t)col_row(i);
             ++pos;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -627,18 +728,6 @@ __global__ __launch_bounds__(64 * QPW) void select_dense_wave_kernel(const float
         }
     }
     sel.finish(ls, li, tau ? tau + q : nullptr);
-}
-
-// wave-wide integer sum in 7 DPP adds + one readlane (quad swaps, row mirrors, row broadcasts: the total lands in lane 63): pure VALU —
-// counting with ballots costs scalar-unit issue slots, which the waves of a CU share, and a bpermute-based __shfl_xor reduction ~600 cycles
-__device__ __forceinline__ int wave_sum_dpp(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);   // row_half_mirror
-    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);   // row_mirror  -> every lane: its row's sum
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast15 into rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast31 into rows 2 and 3
-    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // dense source, rows of at most 64 * 8 * NRUN columns (4096 / 5120: the warm-up chunk of the fused scan, Flickr / COCO sized indexes):

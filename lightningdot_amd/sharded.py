@@ -232,7 +232,7 @@ class ShardedFlatIndexer:
         if self.profile_phases and torch.cuda.is_available():
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
-            self._marks.append((name, ev))
+            self._marks.append((getattr(self, '_mark_prefix', '') + name, ev))
 
     def _collect_phases(self) -> None:
         if not self.profile_phases or len(self._marks) < 2:
@@ -342,8 +342,11 @@ class ShardedFlatIndexer:
                     self._pooled_penalty = min(2 * self._pooled_penalty, 1024)
                 self._verdict = None
                 self._want_verdict = False
-                res = self._search(local_queries, k, out, False)
-                self._mark('repeat')
+                self._mark_prefix = 'repeat:'        # (the phases of the second search are reported apart from the first one's)
+                try:
+                    res = self._search(local_queries, k, out, False)
+                finally:
+                    self._mark_prefix = ''
                 self._collect_phases()
                 return res
             self._pooled_penalty = 16

@@ -39,9 +39,25 @@ def test_headline_line_has_the_contract_fields():
     assert 'error' not in sec, sec
     for name in ('flickr_1k', 'coco_5k'):
         assert sec[name]['ms_per_evaluation'] > 0 and sec[name]['recall_t2i@1'] == 1.0 and sec[name]['recall_i2t@1'] == 1.0
+        lat = sec[name]['latency_ms']                                                   # tails, not only medians
+        assert lat['calls'] >= 200 and 0 < lat['p50'] <= lat['p99'] <= lat['worst'] and lat['p50'] == sec[name]['ms_per_evaluation']
     for key in ('1q_x_headline_index', '64q_x_headline_index', '1q_x_123k', '64q_x_123k'):
         e = sec['serving_latency'][key]
         assert e['ms'] > 0 and 0.0 < e['hbm_frac_whole_search'] < 1.0 and e['rank1_ok']
+        assert e['latency_ms']['calls'] >= 200 and e['latency_ms']['p50'] <= e['latency_ms']['p99'] <= e['latency_ms']['worst']
+    # the mining searches of dvl/hn.py:45-66 at the Flickr30k train set's size, top-50 and top-1000, exact scores and ids-only
+    mn = sec['mining_flickr_train']
+    assert mn['images'] == 29000 and mn['captions'] == 145000 and 0 < mn['sampled_hard_negatives_wall_s'] < 2.0
+    for k in (50, 1000):
+        for name in (f't2i_145k_x_29k_top{k}', f'i2t_29k_x_145k_top{k}'):
+            row = mn['searches'][name]
+            for mode in ('exact_scores', 'ids_only'):
+                m = row[mode]
+                assert 0 < m['score_kernel_ms'] <= m['device_ms'] and 0 < m['score_kernel_frac'] < 1.0
+            assert 0 < row['ids_only']['candidates_rescored_share'] < 0.5
+            assert row['ids_only']['rows_gathered_GB'] < row['exact_scores']['rows_gathered_GB']
+        assert mn['searches'][f't2i_145k_x_29k_top{k}']['exact_scores']['rank1_ok'] and mn['searches'][f't2i_145k_x_29k_top{k}']['ids_only']['rank1_ok']
+        assert 'exact_scores' in mn['searches'][f'i2t_undeduplicated_145k_x_145k_top{k}']
     for key in ('512x512', '512x1536'):
         e = sec['loss_step'][key]
         assert 0 < e['device_us'] <= e['end_to_end_us'] * 1.5 and e['torch_end_to_end_us'] > 0 and e['torch_device_us'] > 0
@@ -71,3 +87,14 @@ def test_sharded_path_on_rccl_with_one_rank():
     parts = sum(v for k, v in ph.items() if k != 'total')
     assert abs(parts - ph['total']) <= 0.05 * ph['total'] and ph['total'] <= d['ms_per_step'] * 1.02
     assert ph['candidate_pass'] >= d['roofline']['kernel_ms_per_step'] * 0.98
+
+
+def test_sharded_forced_repeat_reports_the_verdict_and_repeat_phases():
+    """`--force-repeat`: every step runs the pooled scheme's verdict (all-reduce SUM of the counts + one host read) and then the whole search
+    again — what a failed pooled search costs, on RCCL with the one rank a GPU box offers."""
+    d = _run('--rows', '131072', '--queries', '1024', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-secondary',
+             '--force-sharded', '--force-repeat', '--backend', 'nccl')
+    assert d['ranks_seen'] == 1 and d['recall@1'] == 1.0 and d['results_sorted'] is True and 'forced_repeat' in d
+    ph, phm = d['phases_ms_per_step'], d['phases_ms_per_step_slowest_rank']
+    assert ph['verdict'] >= 0.0 and ph['repeat:candidate_pass'] > 0.0 and ph['repeat:merge'] > 0.0 and set(ph) == set(phm)
+    assert all(abs(ph[k_] - phm[k_]) < 1e-9 for k_ in ph)                               # one rank: the slowest rank is rank 0
