@@ -12,8 +12,8 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(PKG, 'libldot.so')
-SOURCES = ['api.hip', 'search.hip', 'scan.hip', 'ivf_api.hip', 'convert.hip', 'score_dense.hip', 'score_narrow.hip', 'score_filter.hip', 'select.hip', 'select_narrow.hip', 'rescore.hip', 'ivf.hip', 'loss.hip']
-HEADERS = ['ldot_common.h', 'gemm_ring.h', 'bitonic.h', 'kernels.h', 'index_state.h', os.path.join('..', '..', 'include', 'ldot.h')]
+SOURCES = ['api.hip', 'search.hip', 'scan.hip', 'ivf_api.hip', 'convert.hip', 'score_dense.hip', 'score_narrow.hip', 'score_filter.hip', 'select.hip', 'select_big.hip', 'select_narrow.hip', 'rescore.hip', 'ivf.hip', 'loss.hip']
+HEADERS = ['ldot_common.h', 'gemm_ring.h', 'bitonic.h', 'kernels.h', 'pool_walk.h', 'index_state.h', os.path.join('..', '..', 'include', 'ldot.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
 

@@ -121,6 +121,13 @@ int launch_ivf_final(const uint64_t* cand, int cap, int32_t* cnt, int64_t nq, co
 int launch_init_lists(float* list_s, int32_t* list_i, int64_t n, float* tau, int64_t nq, int64_t nq_pad, hipStream_t st);
 int launch_select_dense(const float* S, int64_t lds_elems, int64_t nq, int64_t ncols, int64_t idx_base,
                         float* list_s, int32_t* list_i, int kp, float* tau, hipStream_t st);
+// long lists (k' > 512; select_big.hip): a 256-thread workgroup per query, sample / list pivot + one streaming pass + bit search in registers
+bool select_big_dense_ok(int kp, int64_t ncols, int64_t idx_base);
+int launch_select_big_dense(const float* S, int64_t lds_elems, int64_t nq, int64_t ncols, int64_t idx_base, float* list_s, int32_t* list_i,
+                            int kp, float* tau, hipStream_t st);
+int launch_select_big_pools(const uint4* pool, int32_t* pool_cnt, int nsubs, int64_t nq, int32_t row_end, float* list_s, int32_t* list_i,
+                            int kp, float* tau, int32_t* overflow_flags, int32_t* over_sum, int32_t* qcnt, hipStream_t st, float* tau_opt,
+                            int opt_m);
 // segmented variant for few queries x many rows: grid (nq, nseg); every (query, segment) writes an independent partial
 // top-kp list part_[sl][seg][q][kp] (int64 labels) that launch_select_lists then merges
 int launch_select_dense_parts(const float* S, int64_t lds_elems, int64_t nq, int64_t ncols, int64_t seg_cols,

@@ -13,6 +13,7 @@
 
 #include "bitonic.h"
 #include "kernels.h"
+#include "pool_walk.h"
 
 namespace ldot {
 
@@ -365,316 +366,6 @@ __global__ __launch_bounds__(kSelThreads) void select_dense_kernel(const float* 
         }
     }
     sel.finish(ls, li, tau ? tau + q : nullptr);
-}
-
-// dense source, LONG lists (k' > 512: the mining searches of dvl/hn.py:53 at num_tops up to 1000, k' up to 3072): the streaming selector
-// above compacts its 4096-key LDS buffer with a bitonic sort once per 1024-column segment — 330 us per query over a 29 000-column row.  Here
-// the workgroup holds the WHOLE row of the chunk (<= 32 768 columns: 32 per thread) and the running list in registers and finds the
-// k'-th best key by a bit search: one compare-and-count pass over the registers + one workgroup reduction per bit, no sort; the k'
-// winners are then written out as a SET (the consumers — the next chunk's call, the pool select, the re-score — take lists as sets).
-// Two phases: the first bits are decided over all registers while the count of still undecided elements (those that share the decided
-// prefix) is tracked for free; as soon as they fit kBitsCap — after the sign, the exponent and a mantissa bit or two for scores of one
-// row: ~10 of 32 bits — they are compacted into LDS, four per thread, and the remaining bits cost 4 compares per thread instead of 35.
-// Key order = (score desc, row asc) as everywhere: rows break score ties by a second bit search over the tied rows, which runs only when the
-// ties straddle the k'-th place.  (First version, one phase, shuffle-based sums, 512 threads x 64 values: 59 us per query,
-// profiles/r06_mining_kernels_second.txt.)
-constexpr int kBitsThreads = 1024;
-constexpr int kBitsVPT = 32;                      // row values per thread (8 x f32x4): <= 32 768 columns per chunk
-constexpr int kBitsLPT = kMaxKp / kBitsThreads;   // list entries per thread
-constexpr int kBitsAPT = 4;                       // undecided elements per thread in the second phase
-constexpr int kBitsCap = kBitsAPT * kBitsThreads;
-constexpr int kBitsWaves = kBitsThreads / 64;
-static_assert(kMaxKp % kBitsThreads == 0, "list entries per thread");
-
-// sum over the workgroup: DPP wave sums, one LDS word per wave, ONE barrier (`slot` alternates between calls)
-__device__ __forceinline__ int bits_block_sum(int v, int* red, int slot) {
-    const int w = wave_sum_dpp(v);
-    if ((threadIdx.x & 63) == 0) red[slot * kBitsWaves + (threadIdx.x >> 6)] = w;
-    __syncthreads();
-    int t = 0;
-#pragma unroll
-    for (int i = 0; i < kBitsWaves; ++i) t += red[slot * kBitsWaves + i];
-    return t;
-}
-
-__global__ __launch_bounds__(kBitsThreads) void select_dense_bits_kernel(const float* __restrict__ S, int64_t lds_elems, int64_t ncols,
-                                                                         int64_t idx_base, float* __restrict__ list_s,
-                                                                         int32_t* __restrict__ list_i, int kp, float* __restrict__ tau) {
-    __shared__ int red[2 * kBitsWaves];
-    __shared__ uint32_t rbits[2 * kBitsWaves];
-    __shared__ uint32_t akey[kBitsCap], arow[kBitsCap];
-    const int64_t q = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* row = S + q * lds_elems;
-    float* ls = list_s + q * kp;
-    int32_t* li = list_i + q * kp;
-    // ---- the row and the running list -> descending keys in registers (0xffffffff = nothing) -------------------------------------
-    // (unconditional loads from clamped addresses, validity applied afterwards: a conditional load is a branch + a wait of its own.  The
-    // score rows are lds_elems >= round_up(ncols, 4) long; list slots past k' re-read the last one)
-    uint32_t key[kBitsVPT], lkey[kBitsLPT];
-    int32_t lrow[kBitsLPT];
-    int mine = 0;
-#pragma unroll
-    for (int j = 0; j < kBitsVPT / 4; ++j) {
-        const int64_t c = ((int64_t)j * kBitsThreads + tid) * 4;
-        const int64_t cl = c + 3 < lds_elems ? c : (lds_elems - 4 > 0 ? lds_elems - 4 : 0);
-        const f32x4 v = *(const f32x4*)(row + cl);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const bool ok = c + e < ncols && cl == c;
-            key[j * 4 + e] = ok ? desc_key(v[e]) : 0xffffffffu;
-            // (opaque from here on: otherwise every later `key != 0xffffffff` is rewritten in terms of `ok`, and the compare masks of all
-            // registers stay alive — spilled — from the loads to the write-out)
-            asm volatile("" : "+v"(key[j * 4 + e]));
-            mine += ok ? 1 : 0;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < kBitsLPT; ++r) {
-        const int e = r * kBitsThreads + tid;
-        const int el = e < kp ? e : kp - 1;
-        const int32_t lr = li[el];
-        const float lsv = ls[el];
-        lrow[r] = e < kp ? lr : -1;
-        lkey[r] = lrow[r] >= 0 ? desc_key(lsv) : 0xffffffffu;
-        asm volatile("" : "+v"(lkey[r]), "+v"(lrow[r]));
-        mine += lkey[r] != 0xffffffffu ? 1 : 0;
-    }
-    const int n = bits_block_sum(mine, red, 0);
-    auto col_row = [&](int i) { return (uint32_t)idx_base + (uint32_t)(((i >> 2) * kBitsThreads + tid) * 4 + (i & 3)); };
-    // ---- the k'-th smallest key (every element is selected when there are no more than k') -----------------------------------------
-    uint32_t kth = 0xffffffffu;
-    uint32_t row_cut = 0xffffffffu;      // of the elements with key == kth those with row <= row_cut belong to the list
-    if (n >= kp) {
-        uint32_t all_and = 0xffffffffu, all_or = 0u;
-#pragma unroll
-        for (int i = 0; i < kBitsVPT; ++i) {
-            all_and &= key[i];
-            all_or |= key[i] != 0xffffffffu ? key[i] : 0u;
-        }
-#pragma unroll
-        for (int r = 0; r < kBitsLPT; ++r) {
-            all_and &= lkey[r];
-            all_or |= lkey[r] != 0xffffffffu ? lkey[r] : 0u;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            all_and &= __shfl_xor(all_and, o);
-            all_or |= __shfl_xor(all_or, o);
-        }
-        if (lane == 0) {
-            rbits[wave] = all_and;
-            rbits[kBitsWaves + wave] = all_or;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < kBitsWaves; ++w) {
-            all_and &= rbits[w];
-            all_or |= rbits[kBitsWaves + w];
-        }
-        const uint32_t diff = all_and ^ all_or;
-        const int hb = diff ? 31 - __clz((int)diff) : -1;
-        kth = hb >= 31 ? 0u : hb < 0 ? all_or : (all_or & ~((2u << hb) - 1u));
-        int slot = 1;
-        // phase 1: all registers; `below` = elements whose decided prefix is smaller than kth's (in the list for sure), `active` = those
-        // that share it (undecided)
-        int below = 0, active = n, bit = hb;
-        for (; bit >= 0 && active > kBitsCap; --bit) {
-            const uint32_t test = kth | ((1u << bit) - 1u);
-            int c = 0;
-#pragma unroll
-            for (int i = 0; i < kBitsVPT; ++i) {
-                c += key[i] <= test ? 1 : 0;
-                if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler issues all compares first and spills their masks)
-            }
-#pragma unroll
-            for (int r = 0; r < kBitsLPT; ++r) c += lkey[r] <= test ? 1 : 0;
-            const int cnt = bits_block_sum(c, red, slot);
-            slot ^= 1;
-            if (cnt < kp) {
-                kth |= 1u << bit;
-                active -= cnt - below;
-                below = cnt;
-            } else {
-                active = cnt - below;
-            }
-        }
-        if (bit >= 0) {
-            // phase 2: the undecided elements (prefix above `bit` equal to kth's), compacted into LDS, kBitsAPT per thread
-            const uint32_t pm = bit >= 31 ? 0u : ~((2u << bit) - 1u);
-            const uint32_t pref = kth & pm;
-            int na = 0;
-#pragma unroll
-            for (int r = 0; r < kBitsLPT; ++r) na += (lkey[r] != 0xffffffffu && (lkey[r] & pm) == pref) ? 1 : 0;
-#pragma unroll
-            for (int i = 0; i < kBitsVPT; ++i) na += (key[i] != 0xffffffffu && (key[i] & pm) == pref) ? 1 : 0;
-            int incl = na;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int up = __shfl_up(incl, o);
-                if (lane >= o) incl += up;
-            }
-            __syncthreads();                 // (`red` is free: every thread has left the last sum)
-            if (lane == 63) red[wave] = incl;
-            __syncthreads();
-            int pos = incl - na;
-#pragma unroll
-            for (int w = 0; w < kBitsWaves; ++w) pos += w < wave ? red[w] : 0;
-            {
-                uint32_t pm_l = pm, pref_l = pref;   // (not the masks of the counting pass again: they would be kept alive — see above)
-                asm volatile("" : "+v"(pm_l), "+v"(pref_l));
-#pragma unroll
-                for (int r = 0; r < kBitsLPT; ++r) {
-                    if (lkey[r] != 0xffffffffu && (lkey[r] & pm_l) == pref_l) {
-                        akey[pos] = lkey[r];
-                        arow[pos] = (uint32_t)lrow[r];
-                        ++pos;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < kBitsVPT; ++i) {
-                    if (key[i] != 0xffffffffu && (key[i] & pm_l) == pref_l) {
-                        akey[pos] = key[i];
-                        arow[pos] = col_row(i);
-                        ++pos;
-                    }
-                    if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            __syncthreads();
-            uint32_t ak[kBitsAPT], ar[kBitsAPT];
-#pragma unroll
-            for (int j = 0; j < kBitsAPT; ++j) {
-                const int e = j * kBitsThreads + tid;
-                ak[j] = e < active ? akey[e] : 0xffffffffu;
-                ar[j] = e < active ? arow[e] : 0xffffffffu;
-            }
-            const int need = kp - below;     // the need-th smallest of the undecided elements is the k'-th overall
-            for (; bit >= 0; --bit) {
-                const uint32_t test = kth | ((1u << bit) - 1u);
-                int c = 0;
-#pragma unroll
-                for (int j = 0; j < kBitsAPT; ++j) c += ak[j] <= test ? 1 : 0;
-                if (bits_block_sum(c, red, slot) < need) kth |= 1u << bit;
-                slot ^= 1;
-            }
-            int lt = 0, eq = 0;
-#pragma unroll
-            for (int j = 0; j < kBitsAPT; ++j) {
-                lt += ak[j] < kth ? 1 : 0;
-                eq += ak[j] == kth ? 1 : 0;
-            }
-            lt = bits_block_sum(lt, red, slot);
-            slot ^= 1;
-            eq = bits_block_sum(eq, red, slot);
-            slot ^= 1;
-            const int need_ties = need - lt;
-            if (eq > need_ties) {            // (uniform) ties straddle the k'-th place: the need_ties-th smallest row among them
-                uint32_t cut = 0;
-                for (int b = 31; b >= 0; --b) {
-                    const uint32_t test = cut | ((1u << b) - 1u);
-                    int c = 0;
-#pragma unroll
-                    for (int j = 0; j < kBitsAPT; ++j) c += (ak[j] == kth && ar[j] <= test) ? 1 : 0;
-                    if (bits_block_sum(c, red, slot) < need_ties) cut |= 1u << b;
-                    slot ^= 1;
-                }
-                row_cut = cut;
-            }
-        } else {
-            // every bit was decided over the registers (more than kBitsCap elements share a long prefix: thousands of equal scores): ties
-            // over the registers as well
-            int lt = 0, eq = 0;
-#pragma unroll
-            for (int i = 0; i < kBitsVPT; ++i) {
-                lt += key[i] < kth ? 1 : 0;
-                eq += key[i] == kth ? 1 : 0;
-            }
-#pragma unroll
-            for (int r = 0; r < kBitsLPT; ++r) {
-                lt += lkey[r] < kth ? 1 : 0;
-                eq += lkey[r] == kth ? 1 : 0;
-            }
-            lt = bits_block_sum(lt, red, slot);
-            slot ^= 1;
-            eq = bits_block_sum(eq, red, slot);
-            slot ^= 1;
-            const int need_ties = kp - lt;
-            if (eq > need_ties) {
-                uint32_t cut = 0;
-                for (int b = 31; b >= 0; --b) {
-                    const uint32_t test = cut | ((1u << b) - 1u);
-                    int c = 0;
-                    // (a rare path: its loop-invariant parts — the tie masks, the row numbers — must NOT be hoisted out of the bit loop into
-                    // registers the common path then pays for: both are derived from laundered values inside the loop)
-                    uint32_t kth_l = kth, row_l = (uint32_t)idx_base + (uint32_t)tid * 4u;
-                    asm volatile("" : "+v"(kth_l), "+v"(row_l));
-#pragma unroll
-                    for (int i = 0; i < kBitsVPT; ++i) {
-                        const uint32_t r_ = row_l + (uint32_t)((i >> 2) * kBitsThreads * 4 + (i & 3));
-                        c += (key[i] == kth_l && r_ <= test) ? 1 : 0;
-                    }
-#pragma unroll
-                    for (int r = 0; r < kBitsLPT; ++r) c += (lkey[r] == kth_l && (uint32_t)lrow[r] <= test) ? 1 : 0;
-                    if (bits_block_sum(c, red, slot) < need_ties) cut |= 1u << b;
-                    slot ^= 1;
-                }
-                row_cut = cut;
-            }
-        }
-    }
-    // ---- write the winners (a set: thread after thread, a thread's list entries before its columns), then the empty slots ---------------
-    // (the verdict of every register is kept as one bit of a lane mask: recomputing the predicates in the write loop makes the compiler keep
-    // all the compare results alive in scalar registers and spill them)
-    uint32_t selm = 0, lselm = 0;
-#pragma unroll
-    for (int r = 0; r < kBitsLPT; ++r)
-        lselm |= (lkey[r] != 0xffffffffu && (lkey[r] < kth || (lkey[r] == kth && (uint32_t)lrow[r] <= row_cut))) ? (1u << r) : 0u;
-#pragma unroll
-    for (int i = 0; i < kBitsVPT; ++i)
-        selm |= (key[i] != 0xffffffffu && (key[i] < kth || (key[i] == kth && col_row(i) <= row_cut))) ? (1u << i) : 0u;
-    static_assert(kBitsVPT <= 32 && kBitsLPT <= 32, "verdict masks");
-    asm volatile("" : "+v"(selm), "+v"(lselm));
-    const int sel_cnt = __popc(selm) + __popc(lselm);
-    int incl = sel_cnt;                  // inclusive scan over the wave, then over the workgroup's waves
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int up = __shfl_up(incl, o);
-        if (lane >= o) incl += up;
-    }
-    __syncthreads();                     // (every thread has read its list entries: the list may be overwritten now; `red` is free again)
-    if (lane == 63) red[wave] = incl;
-    __syncthreads();
-    int pos = incl - sel_cnt;
-    int m = 0;
-#pragma unroll
-    for (int w = 0; w < kBitsWaves; ++w) {
-        pos += w < wave ? red[w] : 0;
-        m += red[w];                     // = min(n, k')
-    }
-#pragma unroll
-    for (int r = 0; r < kBitsLPT; ++r) {
-        if ((lselm >> r) & 1u) {
-            ls[pos] = desc_key_to_float(lkey[r]);
-            li[pos] = lrow[r];
-            ++pos;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int i = 0; i < kBitsVPT; ++i) {
-        if ((selm >> i) & 1u) {
-            ls[pos] = desc_key_to_float(key[i]);
-            li[pos] = (int32_t)col_row(i);
-            ++pos;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    for (int e = m + tid; e < kp; e += kBitsThreads) {
-        ls[e] = LDOT_PAD_SCORE;
-        li[e] = -1;
-    }
-    if (tau && tid == 0) tau[q] = n >= kp ? desc_key_to_float(kth) : -INFINITY;
 }
 
 // dense source, wave-per-query variant (k' <= 512): the same register selection as the pool select instead of LDS bitonic
@@ -1049,29 +740,6 @@ __device__ __forceinline__ int pool_rec_row(int j) { return j < 4 ? j : j - 4 + 
 // LDS per workgroup would cost a workgroup per CU: 160 KiB / 33 KiB = 4 instead of 5).
 constexpr int kSlotWin = 256;
 constexpr int kSlotKeys = kSlotWin / 8;
-
-// A sub-pool's counter word packs the counts of its four lane groups (kernels.h).  pool_counts: the word with every byte clamped to the
-// group capacity, the total, and whether a group overflowed.  pool_entry_of: the entry of the sub-pool's e-th record (records numbered
-// group by group): group g owns the entries [g * kPoolGroupCap, ...).
-__device__ __forceinline__ uint32_t pool_counts(uint32_t word, int& total, bool& over) {
-    uint32_t clamped = 0;
-    total = 0;
-#pragma unroll
-    for (int g = 0; g < kPoolGroups; ++g) {
-        const uint32_t b = (word >> (8 * g)) & 255u;
-        over |= b > (uint32_t)kPoolGroupCap;
-        const uint32_t cb = b < (uint32_t)kPoolGroupCap ? b : (uint32_t)kPoolGroupCap;
-        clamped |= cb << (8 * g);
-        total += (int)cb;
-    }
-    return clamped;
-}
-__device__ __forceinline__ int pool_entry_of(int e, uint32_t clamped) {
-    const int p0 = (int)(clamped & 255u), p1 = p0 + (int)((clamped >> 8) & 255u), p2 = p1 + (int)((clamped >> 16) & 255u);
-    const int g = (e >= p0) + (e >= p1) + (e >= p2);
-    const int before = g == 0 ? 0 : g == 1 ? p0 : g == 2 ? p1 : p2;
-    return g * kPoolGroupCap + (e - before);
-}
 
 // (c = the sub-pool's record total, cw = its clamped counter word)
 __device__ __forceinline__ void walk_subpools(WaveSelector& sel, const uint4* __restrict__ base, int nsubs, int s0, int c, uint32_t cw,
@@ -1561,12 +1229,8 @@ int launch_select_dense(const float* S, int64_t lds_elems, int64_t nq, int64_t n
         LDOT_HIP_CHECK(hipGetLastError());
         return LDOT_OK;
     }
-    if (kp > 512 && ncols <= (int64_t)kBitsThreads * kBitsVPT && idx_base + ncols < ((int64_t)1 << 31)) {   // long lists: bit search in registers
-        hipLaunchKernelGGL(select_dense_bits_kernel, dim3((unsigned)nq), dim3(kBitsThreads), 0, st, S, lds_elems, ncols, idx_base, list_s,
-                           list_i, kp, tau);
-        LDOT_HIP_CHECK(hipGetLastError());
-        return LDOT_OK;
-    }
+    if (select_big_dense_ok(kp, ncols, idx_base))   // long lists (round 6): pivot + one streaming pass + bit search in registers
+        return launch_select_big_dense(S, lds_elems, nq, ncols, idx_base, list_s, list_i, kp, tau, st);
     const int cap = select_cap(kp, 2048, 4 * kSelThreads);   // 16 KiB of keys for kp <= 1024
     hipLaunchKernelGGL(select_dense_kernel, dim3((unsigned)nq), dim3(kSelThreads), (size_t)cap * 8, st, S, lds_elems,
                        ncols, idx_base, list_s, list_i, kp, cap, tau);
@@ -1630,10 +1294,9 @@ int launch_select_pools(const uint4* pool, const int32_t* pool_cnt, int nsubs, i
         hipLaunchKernelGGL((select_pools_kernel<4, QPW>), dim3((unsigned)((nq + QPW - 1) / QPW)),
                            dim3(kPoolSelThreads * QPW), (size_t)cap * 8 * QPW, st, pool, (int32_t*)pool_cnt, nsubs, nq,
                            row_end, list_s, list_i, kp, cap, tau, overflow_flags, over_sum, qcnt, dbg, tau_opt, opt_m);
-    } else {   // kp > 512: LDS sort path, one wave per workgroup
-        hipLaunchKernelGGL((select_pools_kernel<4, 1>), dim3((unsigned)nq), dim3(kPoolSelThreads), (size_t)cap * 8 + kSlotWin, st,
-                           pool, (int32_t*)pool_cnt, nsubs, nq, row_end, list_s, list_i, kp, cap, tau, overflow_flags, over_sum, qcnt, dbg,
-                           tau_opt, opt_m);
+    } else {   // long lists (round 6): a 256-thread workgroup per query, bit search in registers (select_big.hip)
+        return launch_select_big_pools(pool, (int32_t*)pool_cnt, nsubs, nq, row_end, list_s, list_i, kp, tau, overflow_flags, over_sum, qcnt, st,
+                                       tau_opt, opt_m);
     }
     LDOT_HIP_CHECK(hipGetLastError());
     return LDOT_OK;

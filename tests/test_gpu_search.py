@@ -818,3 +818,43 @@ def test_error_paths_of_the_new_entry_points(L, tmp_path):
     if torch.cuda.device_count() > 1:
         with pytest.raises(ValueError):
             ix.search_tensors(torch.zeros(2, 32, device='cuda:1'), 3)
+
+
+@pytest.mark.parametrize('nq,n,d,k,mode', [
+    (100, 30000, 64, 1000, 'DENSE'),     # one chunk longer than the survivor buffer: the sample pivot (mining shape, dvl/hn.py:53 at num_tops 1000)
+    (60, 70000, 64, 1000, 'DENSE'),      # three dense chunks: the running list joins the selection
+    (40, 40000, 32, 2048, 'DENSE'),      # k' = 2560: the 8192-slot variant, two chunks
+    (300, 150000, 64, 600, 'FUSED'),     # fused scan with k' = 768: long-list pool select
+    (300, 150000, 64, 1000, 'AUTO'),     # ... k' = 1280 (the image -> text mining search's shape, reduced)
+    (4, 9000, 64, 700, 'DENSE'),         # a handful of queries
+])
+def test_long_lists_match_brute_force(L, nq, n, d, k, mode):
+    """k' > 512: select_big.hip (pivot + one streaming pass + bit search in registers) behind the dense and the fused path"""
+    rng = np.random.default_rng(n + k + nq)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    ix = _index(x, mode=getattr(L, 'MODE_' + mode))
+    s, l = ix.search(q, k)
+    assert_topk_matches(q, x, s, l, k)
+
+
+@pytest.mark.parametrize('mode', ['DENSE', 'FUSED'])
+def test_long_lists_with_thousands_of_equal_scores_take_the_slow_path(L, mode):
+    """10 000 copies of one row + distinct rows: every copy scores the same, the survivors of any pivot overflow the buffer and the selection
+    falls back to the streamed 64-bit bit search; ties go to the lower label (oracle.FlatIP's order)."""
+    rng = np.random.default_rng(11)
+    d, k = 64, 800
+    base = rng.standard_normal((1, d)).astype(np.float32)
+    x = np.concatenate([rng.standard_normal((30000, d)).astype(np.float32), np.repeat(base, 10000, axis=0),
+                        rng.standard_normal((60000, d)).astype(np.float32)])
+    q = np.concatenate([base + 0.01 * rng.standard_normal((1, d)).astype(np.float32) for _ in range(20)] +
+                       [rng.standard_normal((280, d)).astype(np.float32)])
+    ix = _index(x, mode=getattr(L, 'MODE_' + mode), optimistic=0)
+    s, l = ix.search(q, k)
+    so = O.FlatIP(d)
+    so.add(x)
+    so_s, so_l = so.search(q, k)
+    np.testing.assert_allclose(s, so_s, rtol=0, atol=1e-3)
+    # the 20 queries next to the repeated row: the copies fill the top k in label order
+    assert np.array_equal(l[:20], np.tile(np.arange(30000, 30000 + k), (20, 1)))
+    assert (l[20:, 0] == so_l[20:, 0]).all()
