@@ -295,6 +295,10 @@ def main():
             out['roofline']['traffic'] = t['hbm_bytes_per_launch']
             out['roofline']['traffic_source'] = 'offline constant: measured with rocprofv3 PMC passes of this command (profiles/traffic.json), not in this run'
             out['roofline']['traffic_note'] = t['note']
+            out['roofline']['traffic_hbm_side'] = t.get('hbm_side_bytes_per_pass')   # (None: no counter separates Infinity-Cache hits from HBM reads here)
+            out['roofline']['traffic_hbm_side_note'] = t.get('hbm_side_note')
+            out['roofline']['power_note'] = ('offline: while this loop runs the socket draws 1344 W of its 1400 W cap at sclk 1.96 GHz of 2.4 (rocm-smi, '
+                                             'profiles/r06_power_probe.txt): the score kernel is power-limited, its rate follows the energy per flop')
         except Exception:
             pass
     if not sharded:
@@ -396,7 +400,10 @@ def secondary_metrics(dev, flat_main, D, K):
         lat = _median_ms(step, 200, warm=6, full=True)   # (the first evaluations after fresh indexes / pinned buffers carry first-use stalls)
         ms = lat['p50']
         gt = torch.arange(txt.shape[0]) // 5
-        sec[name] = {'ms_per_evaluation': ms, 'timing': 'median of 200 individually timed evaluations', 'latency_ms': lat, 'ms_mean': lat['mean'], 'ms_worst': lat['worst'],
+        # the same pair with DEVICE outputs — what harness.eval_model_on_dataloader itself consumes (Recall@k is reduced on the device); the
+        # difference to the pinned-host figure is the 12 bytes per result that leave over PCIe from inside the re-score kernel
+        lat_dev = _median_ms(lambda: (ix_img.search_tensors(txt, K), ix_txt.search_tensors(img, K)), 100, warm=4, full=True)
+        sec[name] = {'ms_per_evaluation': ms, 'ms_per_evaluation_device_outputs': lat_dev['p50'], 'timing': 'median of 200 individually timed evaluations', 'latency_ms': lat, 'ms_mean': lat['mean'], 'ms_worst': lat['worst'],
                      'queries_searched': int(txt.shape[0] + n_img),
                      'queries_per_s': (txt.shape[0] + n_img) / ms * 1e3,
                      'recall_t2i@1': float((hl[0][:, 0] == gt).float().mean()),

@@ -126,7 +126,7 @@ __device__ __forceinline__ void filter_admit(const f32x4* lo, const f32x4* hi, i
     // (rb) — is derived here from lane_now(): values that live across the slab loop would be spilled (see there).
     const uint32_t ln = lane_now();
     const uint32_t g4 = ln >> 4;
-    const uint32_t vo0 = (((ln & 15u) * (pstep >> 4)) << 4) + g4 * (kPoolGroupCap * kPoolPlanes * 16u) * nsubs;
+    const uint32_t vo0 = (__umul24(ln & 15u, pstep >> 4) << 4) + __umul24(g4, (kPoolGroupCap * kPoolPlanes * 16u) * nsubs);   // (24-bit multiplies: full rate)
     const int32_t rb = row_w + 4 * (int32_t)g4 + p * 32;
 #pragma unroll
     for (int jj = 0; jj < kFiltCols; ++jj) {
@@ -138,7 +138,7 @@ __device__ __forceinline__ void filter_admit(const f32x4* lo, const f32x4* hi, i
                 // offset, so the lane's address is ONE register
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void*)(pool + pbase_u), 0, (int)(pstep * 16u * kT16ColBlocks), 0x00020000);
-                const uint32_t vo = vo0 + e * (kPoolPlanes * nsubs * 16u);
+                const uint32_t vo = vo0 + __umul24(e, kPoolPlanes * nsubs * 16u);
                 // (computed HERE, opaquely: left to itself the compiler hoists the 24 store offsets of a tile's columns and planes out of the tile
                 // loop into scalar registers, spills them, and this path reads them back lane by lane)
                 uint32_t so;

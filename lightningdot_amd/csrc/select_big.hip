@@ -17,6 +17,8 @@
 // elements, the workgroup takes the SLOW path — a bit search over the 64-bit keys that re-streams the source once per bit, no buffer at all.
 #include <math.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 #include "pool_walk.h"
 
@@ -63,11 +65,24 @@ __device__ __forceinline__ void big_and_or_max(uint32_t& a, uint32_t& o, uint32_
     }
 }
 
-// the elements of one row of a score chunk: f(descending score key, row id, valid) is called by ALL threads the same number of times
+// inclusive prefix sum over the wave, pure VALU: row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes (a lane without a source adds 0), then the
+// totals of the rows before (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3 — the last two steps of wave_sum_dpp)
+__device__ __forceinline__ int wave_incl_scan_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+
+// the elements of one row of a score chunk, handed to f in per-thread batches (descending score keys, row ids, valid bits); f is called by ALL threads the same number of times
 struct BigDenseSrc {
     const float* row;
     int64_t ncols, lds_elems;
     uint32_t idx_base;
+    // f(dk[16], rid[16], valid bits): the thread's 16 elements of a block of 4096 columns
     template <class F>
     __device__ __forceinline__ void stream(F&& f) const {
         constexpr int U = 4;   // vectors in flight per thread
@@ -84,13 +99,18 @@ struct BigDenseSrc {
                         if (c + e < ncols) v[u][e] = row[c + e];
                 }
             }
+            uint32_t dk[4 * U], rid[4 * U], valid = 0;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t c = c0 + ((int64_t)u * kBigT + threadIdx.x) * 4;
-                if (c0 + (int64_t)u * kBigT * 4 >= ncols) break;   // (uniform)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) f(desc_key(v[u][e]), idx_base + (uint32_t)(c + e), c + e < ncols);
+                for (int e = 0; e < 4; ++e) {
+                    dk[u * 4 + e] = desc_key(v[u][e]);
+                    rid[u * 4 + e] = idx_base + (uint32_t)(c + e);
+                    valid |= c + e < ncols ? 1u << (u * 4 + e) : 0u;
+                }
             }
+            f(std::integral_constant<int, 4 * U>{}, dk, rid, valid);
         }
     }
 };
@@ -103,6 +123,7 @@ struct BigPoolSrc {
     int32_t row_end;
     const uint32_t* cw;   // LDS: clamped counter words
     const int* pre;       // LDS
+    // f(dk[8], rid[8], valid bits): the 8 scores of the thread's record
     template <class F>
     __device__ __forceinline__ void stream(F&& f) const {
         for (int j0 = 0; j0 < total; j0 += kBigT) {
@@ -118,14 +139,16 @@ struct BigPoolSrc {
             const uint4* rec = base + (int64_t)e * kPoolPlanes * nsubs + lo;
             const uint4 p0 = rec[0], p1 = rec[nsubs];
             const int32_t r = (int32_t)rec[2 * nsubs].x;
-            f(desc_key(__uint_as_float(p0.x)), (uint32_t)(r + 0), have && r + 0 < row_end);
-            f(desc_key(__uint_as_float(p0.y)), (uint32_t)(r + 1), have && r + 1 < row_end);
-            f(desc_key(__uint_as_float(p0.z)), (uint32_t)(r + 2), have && r + 2 < row_end);
-            f(desc_key(__uint_as_float(p0.w)), (uint32_t)(r + 3), have && r + 3 < row_end);
-            f(desc_key(__uint_as_float(p1.x)), (uint32_t)(r + kPoolRecHiRow + 0), have && r + kPoolRecHiRow + 0 < row_end);
-            f(desc_key(__uint_as_float(p1.y)), (uint32_t)(r + kPoolRecHiRow + 1), have && r + kPoolRecHiRow + 1 < row_end);
-            f(desc_key(__uint_as_float(p1.z)), (uint32_t)(r + kPoolRecHiRow + 2), have && r + kPoolRecHiRow + 2 < row_end);
-            f(desc_key(__uint_as_float(p1.w)), (uint32_t)(r + kPoolRecHiRow + 3), have && r + kPoolRecHiRow + 3 < row_end);
+            uint32_t dk[8] = {desc_key(__uint_as_float(p0.x)), desc_key(__uint_as_float(p0.y)), desc_key(__uint_as_float(p0.z)), desc_key(__uint_as_float(p0.w)),
+                              desc_key(__uint_as_float(p1.x)), desc_key(__uint_as_float(p1.y)), desc_key(__uint_as_float(p1.z)), desc_key(__uint_as_float(p1.w))};
+            uint32_t rid[8], valid = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int32_t ri = r + (i < 4 ? i : i - 4 + kPoolRecHiRow);
+                rid[i] = (uint32_t)ri;
+                valid |= (have && ri < row_end) ? 1u << i : 0u;
+            }
+            f(std::integral_constant<int, 8>{}, dk, rid, valid);
         }
     }
 };
@@ -177,17 +200,30 @@ __device__ __forceinline__ BigResult big_select(const SRC& src, uint32_t pivot_i
     const uint32_t pivot_sure = pivot;                   // (what holds without the sample)
     if (sample_pivot) pivot = pivot < src.sample_pivot ? pivot : src.sample_pivot;
     // ---- one pass over the source: what passes the pivot -> LDS -------------------------------------------------------------------
-    src.stream([&](uint32_t dk, uint32_t rid, bool valid) {
-        const bool hit = valid && dk <= pivot;
-        const unsigned long long mask = __ballot(hit);
-        if (mask) {
+    // (a thread counts the hits among its elements, ONE wave scan and ONE LDS atomic per block place them: an atomic per element —
+    // 116 dependent LDS round trips per wave and row — was most of this pass)
+    src.stream([&](auto n_tag, const uint32_t* dk, const uint32_t* rid, uint32_t valid) {
+        constexpr int N = decltype(n_tag)::value;
+        uint32_t hit = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) hit |= (((valid >> i) & 1u) && dk[i] <= pivot) ? 1u << i : 0u;
+        const int cnt = __popc(hit);
+        const int incl = wave_incl_scan_dpp(cnt);
+        const int tot = __builtin_amdgcn_readlane(incl, 63);
+        if (tot) {   // (uniform)
             int base = 0;
-            if (lane == 0) base = atomicAdd(&sh.scount, __popcll(mask));
-            base = __builtin_amdgcn_readfirstlane(base);
-            const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
-            if (hit && pos < CAP) {
-                skey[pos] = dk;
-                srow[pos] = rid;
+            if (lane == 63) base = atomicAdd(&sh.scount, tot);
+            base = __builtin_amdgcn_readlane(base, 63);
+            int pos = base + incl - cnt;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                if ((hit >> i) & 1u) {
+                    if (pos < CAP) {
+                        skey[pos] = dk[i];
+                        srow[pos] = rid[i];
+                    }
+                    ++pos;
+                }
             }
         }
     });
@@ -320,7 +356,7 @@ __device__ __forceinline__ BigResult big_select(const SRC& src, uint32_t pivot_i
     } else {
         // ---- SLOW path: bit search over the 64-bit keys {score word, row}, the source streamed once per bit ---------------------------
         int vc = 0;
-        src.stream([&](uint32_t, uint32_t, bool valid) { vc += valid ? 1 : 0; });
+        src.stream([&](auto, const uint32_t*, const uint32_t*, uint32_t valid) { vc += __popc(valid); });
         n_all = n_list + big_sum(vc, sh.red, slot);
         auto tth64 = [&](int t) {
             uint64_t x = 0;
@@ -329,7 +365,10 @@ __device__ __forceinline__ BigResult big_select(const SRC& src, uint32_t pivot_i
                 int c = 0;
 #pragma unroll
                 for (int r = 0; r < kBigLPT; ++r) c += (lrow[r] >= 0 && (((uint64_t)lkey[r] << 32) | (uint32_t)lrow[r]) <= test) ? 1 : 0;
-                src.stream([&](uint32_t dk, uint32_t rid, bool valid) { c += (valid && (((uint64_t)dk << 32) | rid) <= test) ? 1 : 0; });
+                src.stream([&](auto n_tag, const uint32_t* dk, const uint32_t* rid, uint32_t valid) {
+#pragma unroll
+                    for (int i = 0; i < decltype(n_tag)::value; ++i) c += (((valid >> i) & 1u) && (((uint64_t)dk[i] << 32) | rid[i]) <= test) ? 1 : 0;
+                });
                 if (big_sum(c, sh.red, slot) < t) x |= 1ull << bit;
             }
             return x;
@@ -366,17 +405,28 @@ __device__ __forceinline__ BigResult big_select(const SRC& src, uint32_t pivot_i
                 ++pos;
             }
         }
-        src.stream([&](uint32_t dk, uint32_t rid, bool valid) {
-            const bool hit = valid && (((uint64_t)dk << 32) | rid) <= k64;
-            const unsigned long long mask = __ballot(hit);
-            if (mask) {
+        src.stream([&](auto n_tag, const uint32_t* dk, const uint32_t* rid, uint32_t valid) {
+            constexpr int N = decltype(n_tag)::value;
+            uint32_t hit = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) hit |= (((valid >> i) & 1u) && (((uint64_t)dk[i] << 32) | rid[i]) <= k64) ? 1u << i : 0u;
+            const int cnt = __popc(hit);
+            const int incl = wave_incl_scan_dpp(cnt);
+            const int tot = __builtin_amdgcn_readlane(incl, 63);
+            if (tot) {
                 int base = 0;
-                if (lane == 0) base = atomicAdd(&sh.wcount, __popcll(mask));
-                base = __builtin_amdgcn_readfirstlane(base);
-                const int p = m_list + base + __popcll(mask & ((1ull << lane) - 1ull));
-                if (hit && p < kp) {
-                    ls[p] = desc_key_to_float(dk);
-                    li[p] = (int32_t)rid;
+                if (lane == 63) base = atomicAdd(&sh.wcount, tot);
+                base = __builtin_amdgcn_readlane(base, 63);
+                int p = m_list + base + incl - cnt;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    if ((hit >> i) & 1u) {
+                        if (p < kp) {
+                            ls[p] = desc_key_to_float(dk[i]);
+                            li[p] = (int32_t)rid[i];
+                        }
+                        ++p;
+                    }
                 }
             }
         });
@@ -402,7 +452,7 @@ struct BigPoolSrcS : BigPoolSrc {
 
 // dense source: one row of a materialised score chunk + the running list -> the new running list (a set) and its threshold
 template <int APT>
-__global__ __launch_bounds__(kBigT) void select_big_dense_kernel(const float* __restrict__ S, int64_t lds_elems, int64_t ncols, int64_t idx_base,
+__global__ __launch_bounds__(kBigT, APT <= 16 ? 4 : 2) void select_big_dense_kernel(const float* __restrict__ S, int64_t lds_elems, int64_t ncols, int64_t idx_base,
                                                                 float* __restrict__ list_s, int32_t* __restrict__ list_i, int kp,
                                                                 float* __restrict__ tau) {
     extern __shared__ __attribute__((aligned(16))) uint32_t big_lds[];
@@ -457,7 +507,7 @@ __global__ __launch_bounds__(kBigT) void select_big_dense_kernel(const float* __
 // bookkeeping of select_pools_kernel (select.hip): thresholds never go down, the optimistic scan's next threshold / final check, the
 // per-query record count, pool overflows.
 template <int APT>
-__global__ __launch_bounds__(kBigT) void select_big_pools_kernel(const uint4* __restrict__ pool, int32_t* __restrict__ pool_cnt, int nsubs,
+__global__ __launch_bounds__(kBigT, 4) void select_big_pools_kernel(const uint4* __restrict__ pool, int32_t* __restrict__ pool_cnt, int nsubs,
                                                                 int64_t nq, int32_t row_end, float* __restrict__ list_s,
                                                                 int32_t* __restrict__ list_i, int kp, float* __restrict__ tau,
                                                                 int32_t* __restrict__ overflow, int32_t* __restrict__ over_sum,
