@@ -346,7 +346,7 @@ def _time_ms(fn, n, warm=3):
             gc.enable()
 
 
-def _median_ms(fn, n, warm=3, full=False):
+def _median_ms(fn, n, warm=3, full=False, sync=True):
     """median wall time of n individually timed calls, each one complete on the device before the next starts.  One-off host stalls
     (profiles/r05_secondary_outliers.txt: 50-70 ms once in a while, with or without anything this library does differently) do not
     enter; a slowdown that lasts does."""
@@ -361,7 +361,8 @@ def _median_ms(fn, n, warm=3, full=False):
         for _ in range(n):
             t0 = time.perf_counter()
             fn()
-            torch.cuda.synchronize()
+            if sync:   # (sync=False: fn returns with its results in place — search_into waits for its own stream — and a second, redundant
+                torch.cuda.synchronize()   # device synchronisation would add its ~10 us of host time to a 80-us latency)
             ts.append((time.perf_counter() - t0) * 1e3)
     finally:
         if was:
@@ -424,7 +425,7 @@ def secondary_metrics(dev, flat_main, D, K):
             q = base + 0.5 * torch.randn(nq, D, generator=g).to(dev)
             hs_ = torch.empty((nq, K), dtype=torch.float32).pin_memory()
             hl_ = torch.empty((nq, K), dtype=torch.int64).pin_memory()
-            lat = _median_ms(lambda: ix.search_into(q, K, hs_, hl_), 200, full=True)
+            lat = _median_ms(lambda: ix.search_into(q, K, hs_, hl_), 200, full=True, sync=False)   # (search_into returns when the results are in hs_ / hl_)
             ms = lat['p50']
             serving[f'{nq}q_x_{label}'] = {'rows': int(n), 'ms': ms, 'latency_ms': lat, 'hbm_frac_whole_search': n * D * 2 / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                                            'rank1_ok': bool((hl_[:, 0] == rows).all())}
